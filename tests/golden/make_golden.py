@@ -1,0 +1,123 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference's own Python in the authoring container.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+(needs /root/reference; the GPU box does not have it, which is why the vectors are committed).
+
+What is captured (SURVEY.md section 8(c) "oracle plan" items 2-3) -- data only, no reference source:
+  corr_pyramid.npz   CorrBlock(fmap1, fmap2).corr_pyramid          dbaf/modules/corr.py:24-38,63-71
+  schur_solve.npz    geom.chol.schur_solve / block_solve           dbaf/geom/chol.py:32-73
+  pinhole.npz        pops.coords_grid / iproj / proj               dbaf/geom/projective_ops.py:11-65
+  projective.npz     pops.projective_transform(jacobian=True)      dbaf/geom/projective_ops.py:96-125
+The native CUDA path (src/*.cu) cannot be built or run here (no nvcc / Eigen / NVIDIA device), and
+lietorch / torch_scatter / droid_backends are absent: `lietorch` resolves to this repo's SE3 shim,
+the other two to empty stubs (none of the captured functions call into them).
+projective_ops.py:105 hard-codes device="cuda"; torch.as_tensor is wrapped to drop that argument.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference/dbaf"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "dba-fusion_amd"))  # lietorch shim
+sys.path.insert(0, REF)
+for name in ("droid_backends", "torch_scatter"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["torch_scatter"].scatter_sum = None
+sys.modules["torch_scatter"].scatter_mean = None
+
+_as_tensor = torch.as_tensor
+
+
+def _as_tensor_cpu(*a, **k):
+    k.pop("device", None)
+    return _as_tensor(*a, **k)
+
+
+torch.as_tensor = _as_tensor_cpu
+
+import geom.projective_ops as pops  # noqa: E402
+from geom.chol import schur_solve, block_solve  # noqa: E402
+from modules.corr import CorrBlock  # noqa: E402
+from lietorch import SE3  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "dba-fusion_amd"))
+from dbaf_amd import synthetic as syn  # noqa: E402
+
+
+def gen_corr():
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for tag, (n, C, h, w) in {"a": (1, 128, 16, 16), "b": (1, 32, 16, 24)}.items():
+        f1 = torch.randn(1, n, C, h, w, generator=g)
+        f2 = torch.randn(1, n, C, h, w, generator=g)
+        cb = CorrBlock(f1, f2, num_levels=4, radius=3)
+        out[f"{tag}_fmap1"] = f1[0].numpy()
+        out[f"{tag}_fmap2"] = f2[0].numpy()
+        for l, p in enumerate(cb.corr_pyramid):
+            out[f"{tag}_lvl{l}"] = p.numpy()
+    np.savez_compressed(os.path.join(HERE, "corr_pyramid.npz"), **out)
+
+
+def gen_schur():
+    g = torch.Generator().manual_seed(1)
+    B, P, M, D, HW = 1, 3, 4, 6, 20
+    J = torch.randn(B, P * D, 64, generator=g, dtype=torch.float64)
+    H = (J @ J.transpose(1, 2)).view(B, P, D, P, D).permute(0, 1, 3, 2, 4).contiguous()
+    E = 0.1 * torch.randn(B, P, M, D, HW, generator=g, dtype=torch.float64)
+    C = 1.0 + torch.rand(B, M, HW, generator=g, dtype=torch.float64)
+    v = torch.randn(B, P, D, generator=g, dtype=torch.float64)
+    w = torch.randn(B, M, HW, generator=g, dtype=torch.float64)
+    dx, dz = schur_solve(H, E, C, v, w, ep=0.1, lm=1e-4)
+    dxb = block_solve(H, v, ep=0.1, lm=1e-4)
+    np.savez_compressed(os.path.join(HERE, "schur_solve.npz"), H=H.numpy(), E=E.numpy(), C=C.numpy(),
+                        v=v.numpy(), w=w.numpy(), dx=dx.numpy(), dz=dz.numpy(), dx_block=dxb.numpy(),
+                        ep=0.1, lm=1e-4)
+
+
+def gen_pinhole():
+    g = torch.Generator().manual_seed(2)
+    ht, wd = 6, 9
+    disps = 0.2 + torch.rand(1, 2, ht, wd, generator=g)
+    intr = torch.tensor([[[7.5, 7.1, 4.4, 2.9], [7.5, 7.1, 4.4, 2.9]]])
+    grid = pops.coords_grid(ht, wd)
+    pts, _ = pops.iproj(disps, intr)
+    Xs = torch.randn(1, 2, ht, wd, 4, generator=g)
+    Xs[..., 2] = Xs[..., 2].abs() * 2.0  # some below 0.1 exercise the Z clamp (:44)
+    xy, _ = pops.proj(Xs, intr)
+    xyd, _ = pops.proj(Xs, intr, return_depth=True)
+    np.savez_compressed(os.path.join(HERE, "pinhole.npz"), disps=disps.numpy(), intr=intr.numpy(),
+                        grid=grid.numpy(), pts=pts.numpy(), Xs=Xs.numpy(), xy=xy.numpy(), xyd=xyd.numpy())
+
+
+def gen_projective():
+    out = {}
+    for tag, W in {"a": syn.window_tiny_a(3), "b": syn.window_tiny_b(4)}.items():
+        # fp32 like the runtime (projective_ops.py:105 writes a float32 literal into Gij.data)
+        poses = SE3(torch.from_numpy(W.poses)[None])
+        disps = torch.from_numpy(W.disps)[None]
+        intr = torch.from_numpy(np.tile(W.intrinsics, (W.B, 1)))[None]
+        ii, jj = torch.from_numpy(W.ii), torch.from_numpy(W.jj)
+        coords, valid, (Ji, Jj, Jz) = pops.projective_transform(poses, disps, intr, ii, jj, jacobian=True)
+        coords32, valid32 = pops.projective_transform(poses, disps, intr, ii, jj)
+        out.update({f"{tag}_poses": W.poses, f"{tag}_disps": W.disps, f"{tag}_intr": W.intrinsics,
+                    f"{tag}_ii": W.ii, f"{tag}_jj": W.jj,
+                    f"{tag}_coords": coords32[0].numpy(), f"{tag}_valid": valid32[0].numpy()})
+        if tag == "a":  # jacobians only for the small window (keeps the fixture small)
+            out.update({f"{tag}_Ji": Ji[0].numpy(), f"{tag}_Jj": Jj[0].numpy(), f"{tag}_Jz": Jz[0].numpy()})
+    np.savez_compressed(os.path.join(HERE, "projective.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_corr()
+    gen_schur()
+    gen_pinhole()
+    gen_projective()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
