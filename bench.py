@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- DBA hot-path throughput on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+A "step" is one `dba_update` = the in-scope part of one CovisibleGraph.update()
+(/root/reference/dbaf/covisible_graph.py:214-342) on one synthetic keyframe window:
+    reproject(N edges) -> 4-level correlation lookup(N edges) -> ba(iterations=2)
+The ConvGRU between lookup and BA is out of scope.
+N=1 workload = BASELINE.json configs[1] shape: 25 KF / 96 edges / 512x512 frames (64x64 maps).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  For N > 1 the edge set is sharded by source frame over the ranks, the
+reduced camera system is all-reduced over RCCL once per Gauss-Newton iteration and updated inverse depths
+are all-gathered (strong scaling of the same window).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dba-fusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def lookup_algorithmic_bytes(n_edges, hw, levels=4, radius=3, elt=2):
+    """per edge L*(2r+2)^2*HW*2 (taps) + 2*HW*4 (coords) + L*(2r+1)^2*HW*2 (out)."""
+    taps = levels * (2 * radius + 2) ** 2 * hw * elt
+    coords = 2 * hw * 4
+    out = levels * (2 * radius + 1) ** 2 * hw * elt
+    return n_edges * (taps + coords + out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from dbaf_amd import synthetic as syn
+    from dbaf_amd import projective_ops as pops
+    from dbaf_amd.corr import CorrBlock
+    from dbaf_amd import _lib
+    import droid_backends
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.load()
+
+    # ---- workload: 25 KF / 96 edges / 64x64 (synthetic) --------------------------------
+    W = syn.window_25_96(args.seed)
+    h, w, HW, N = W.h, W.w, W.h * W.w, W.N
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    poses0, disps0 = t(W.poses), t(W.disps)
+    intr, dsens, eta = t(W.intrinsics), t(W.disps_sens), t(W.eta)
+    K = intr[None, None].expand(1, W.B, 4).contiguous()
+
+    if world > 1:
+        from dbaf_amd.sharded import ShardedWindow
+        shard = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+        sel = shard.local_edges
+    else:
+        shard = None
+        sel = np.arange(N)
+    ii, jj = t(W.ii[sel]), t(W.jj[sel])
+    target, weight = t(W.target[sel]), t(W.weight[sel])
+    n_loc = len(sel)
+
+    fmaps = t(syn.make_fmaps(W.B, 128, h, w, args.seed + 1000))
+    corr = None
+    if n_loc > 0:  # volumes of this rank's edges, built in chunks to bound the staging memory
+        for c0 in range(0, n_loc, 32):
+            s_ = slice(c0, min(c0 + 32, n_loc))
+            cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3)
+            corr = cb if corr is None else corr.cat(cb)
+    poses, disps = poses0.clone(), disps0.clone()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
+
+    def step(i):
+        poses.copy_(poses0)
+        disps.copy_(disps0)
+        coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
+        ev[2 * i].record()
+        c = corr(coords1) if corr is not None else None
+        ev[2 * i + 1].record()
+        if shard is None:
+            droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep,
+                              False)
+        else:
+            shard.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, dist)
+        disps.clamp_(min=0.001)  # depth_video.py:560
+        return c
+
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    lookup_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
+    lookup_ms = float(np.mean(lookup_ms)) if (lookup_ms and corr is not None) else float("nan")
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / max(args.steps, 1)
+        value = args.steps / dt
+        alg_bytes = lookup_algorithmic_bytes(n_loc, HW)
+        achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
+        out = {
+            "metric": "DBA iterations/sec (25-KF, 96-edge, 512x512) [dba_update/s]",
+            "value": round(value, 3),
+            "unit": "dba_update/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
+            "data": "synthetic",
+            "config": {"workload": "TUM-VI-shape 512x512 -> 64x64 maps, 25-KF window, 96 edges, "
+                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step",
+                       "keyframes": 25, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world},
+            "roofline": {
+                "kernel": "corr_lookup_kernel<f16,r=3> (fused 4-level lookup, %d edges on rank 0)" % n_loc,
+                "bound": "hbm",
+                "achieved": round(achieved, 1) if achieved else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(lookup_ms, 5) if lookup_ms == lookup_ms else None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(W, corr, fmaps, ii, jj)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(W, corr, fmaps, ii, jj, sample_edges=8):
+    """The CPU oracle (a port: the reference has no CPU implementation of this path) timed on the host cores
+    for the same dba_update, on a bounded sample: full ba(itrs=2) on the 25/96 window, reprojection of all
+    edges, and the 4-level lookup on `sample_edges` edges (volumes copied from the device) scaled to 96."""
+    from oracle import oracle as orc
+    orc.lib()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 4.0 and reps < 50):
+        orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+               W.lm, W.ep, False, 0.05, np.float32)
+        reps += 1
+    t_ba = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    coords, _ = orc.reproject(W.poses, W.disps, W.intrinsics, W.ii, W.jj, np.float32)
+    t_rep = time.perf_counter() - t0
+    ne = min(sample_edges, W.N)
+    pyr = [p[:ne].cpu().numpy() for p in corr.corr_pyramid]
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 6.0 and reps < 20):
+        orc.corr_lookup_pyramid(pyr, coords[:ne], 3)
+        reps += 1
+    t_look = (time.perf_counter() - t0) / reps * (W.N / ne)
+    total = t_ba + t_rep + t_look
+    return {"value": round(1.0 / total, 4), "unit": "dba_update/s", "cores": cores, "kind": "port",
+            "sample": "oracle (C, -O3 -march=native, OpenMP over edges/pixels): ba(itrs=2) on the full 25-KF/96-edge "
+                      "window %.1f ms + reprojection %.1f ms + 4-level lookup on %d of 96 edges scaled x%.0f = %.1f ms"
+                      % (1e3 * t_ba, 1e3 * t_rep, ne, W.N / ne, 1e3 * t_look)}
+
+
+if __name__ == "__main__":
+    main()

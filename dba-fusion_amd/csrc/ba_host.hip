@@ -1,0 +1,288 @@
+// Host side of the BA stages: workspace planning and launches (C ABI of include/dba_hip.h).
+// Nothing here synchronises the stream except the two BACore calls that must hand float64 host
+// buffers to the caller (the GTSAM side of DBA-Fusion, dbaf/depth_video.py:524-558).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ba_kernels.h"
+
+namespace dba {
+
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char *what, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s -> %s", what, hipGetErrorString(e));
+}
+
+int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan) {
+  if (N < 0 || B <= 0 || ht <= 0 || wd <= 0 || t1 < t0 || t0 < 0 || t1 > B) return DBA_ERR_ARG;
+  const int P = t1 - t0;
+  const int HW = ht * wd;
+  const int Mmax = (P + N < B) ? (P + N) : B;
+  const int nchunks = (HW + 255) / 256;
+  const int nparts = nchunks * 4;
+  const int n6 = 6 * P;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  dba_ba_layout L;
+  memset(&L, 0, sizeof(L));
+  L.meta = take(sizeof(int) * 8);
+  L.kx = take(sizeof(int) * (size_t)(Mmax > 0 ? Mmax : 1));
+  const size_t o_fslot = take(sizeof(int) * (size_t)B);
+  const size_t o_eoff = take(sizeof(int) * (size_t)(Mmax + 1));
+  const size_t o_elist = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
+  L.Q = take(sizeof(float) * (size_t)Mmax * HW);
+  L.w = take(sizeof(float) * (size_t)Mmax * HW);
+  const size_t o_hpart = take(sizeof(float) * (size_t)(N > 0 ? N : 1) * nparts * HP_STRIDE);
+  L.dx = take(sizeof(float) * (size_t)(n6 > 0 ? n6 : 1));
+  L.H = take(sizeof(double) * (size_t)(n6 > 0 ? n6 * (size_t)n6 : 1));
+  L.b = take(sizeof(double) * (size_t)(n6 > 0 ? n6 : 1));
+  size_t o_lscratch = 0;
+  const bool lds_fits = ba_solve_fits_lds(n6);
+  if (!lds_fits) o_lscratch = take(sizeof(double) * (size_t)n6 * (n6 + 1) / 2);
+  L.P = P;
+  L.Mmax = Mmax;
+  L.nchunks = nchunks;
+  plan->layout = L;
+  plan->bytes = off;
+  plan->P = P;
+  plan->N = N;
+  plan->B = B;
+  plan->HW = HW;
+  plan->nchunks = nchunks;
+  if (ws) {
+    if (ws_bytes < off) return DBA_ERR_WORKSPACE;
+    char *base = static_cast<char *>(ws);
+    plan->T.meta = reinterpret_cast<int *>(base + L.meta);
+    plan->T.kx = reinterpret_cast<int *>(base + L.kx);
+    plan->T.frame_slot = reinterpret_cast<int *>(base + o_fslot);
+    plan->T.eoff = reinterpret_cast<int *>(base + o_eoff);
+    plan->T.elist = reinterpret_cast<int *>(base + o_elist);
+    plan->T.Mmax = Mmax;
+    plan->T.B = B;
+    plan->W.E = reinterpret_cast<float *>(base + L.E);
+    plan->W.Q = reinterpret_cast<float *>(base + L.Q);
+    plan->W.w = reinterpret_cast<float *>(base + L.w);
+    plan->W.Hpart = reinterpret_cast<float *>(base + o_hpart);
+    plan->W.dx = reinterpret_cast<float *>(base + L.dx);
+    plan->W.H = reinterpret_cast<double *>(base + L.H);
+    plan->W.b = reinterpret_cast<double *>(base + L.b);
+    plan->W.Lscratch = lds_fits ? nullptr : reinterpret_cast<double *>(base + o_lscratch);
+    plan->W.nparts = nparts;
+  }
+  return DBA_OK;
+}
+
+}  // namespace dba
+
+using namespace dba;
+
+extern "C" {
+
+const char *dba_version(void) { return "dba_hip 0.1 (gfx950)"; }
+const char *dba_last_error(void) { return g_last_error; }
+
+size_t dba_ba_workspace_bytes(int N, int B, int ht, int wd, int t0, int t1) {
+  BaPlan plan;
+  if (ba_plan(N, B, ht, wd, t0, t1, nullptr, 0, &plan) != DBA_OK) return 0;
+  return plan.bytes;
+}
+
+int dba_ba_get_layout(int N, int B, int ht, int wd, int t0, int t1, dba_ba_layout *out) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, nullptr, 0, &plan);
+  if (rc != DBA_OK) return rc;
+  *out = plan.layout;
+  return DBA_OK;
+}
+
+int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
+                   void *ws, size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (N > 0 && (!ii || !jj)) return DBA_ERR_ARG;
+  const size_t lds = sizeof(int) * ((size_t)B + plan.T.Mmax + 1 + 1024);
+  if (lds > 160 * 1024) return DBA_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_prepare_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
+                     plan.T);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+int dba_ba_linearize(const float *poses, const float *disps, const float *intrinsics,
+                     const float *disps_sens, const float *targets, const float *weights,
+                     const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                     const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                     float alpha, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  (void)ii;
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (!poses || !disps || !intrinsics || !disps_sens || !eta || eta_rows < 1) return DBA_ERR_ARG;
+  if (N > 0 && (!targets || !weights || !jj)) return DBA_ERR_ARG;
+  dim3 grid(plan.nchunks, plan.T.Mmax + 1);
+  hipLaunchKernelGGL(ba_linearize_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, intrinsics,
+                     disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, plan.HW, wd, t0,
+                     plan.P, alpha, plan.T, plan.W);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
+                  int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  const int blocks = plan.P + N + (N + 1) / 2;
+  if (blocks == 0) return DBA_OK;
+  hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,
+                     N, plan.HW, t0, plan.P, motion_only, plan.T, plan.W);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
+                 dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  return launch_ba_solve(plan.W.H, plan.W.b, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
+                         plan.W.Lscratch, (hipStream_t)stream);
+}
+
+int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj,
+                  const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int update_poses,
+                  int update_disps, float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  (void)ii;
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  dim3 grid(plan.nchunks, plan.T.Mmax + 1);
+  hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, jj, frame_owned,
+                     plan.HW, t0, plan.P, update_poses, update_disps, dz_out, plan.T, plan.W);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+           const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+           const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+           float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
+           dba_stream_t stream) {
+  BaPlan plan;
+  int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  const float alpha = 0.05f;  // droid_kernels.cu:1474
+  for (int itr = 0; itr < iterations; itr++) {
+    rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj,
+                          nullptr, N, B, ht, wd, t0, t1, alpha, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+    rc = dba_ba_reduce(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+    rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+    const bool last = (itr == iterations - 1);
+    rc = dba_ba_update(poses, disps, ii, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
+                       last ? dz_out : nullptr, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+  }
+  if (dx_out && iterations > 0 && plan.P > 0) {
+    const int n = 6 * plan.P;
+    hipLaunchKernelGGL(ba_copy_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.dx,
+                       dx_out, n);
+    DBA_LAUNCH_CHECK();
+  }
+  return DBA_OK;
+}
+
+int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,
+                       const float *disps_sens, const float *targets, const float *weights,
+                       const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
+                       int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
+                       size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, nullptr,
+                        N, B, ht, wd, t0, t1, 0.001f /* :1872 */, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  rc = dba_ba_reduce(ii, jj, nullptr, N, B, ht, wd, t0, t1, 0, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  const size_t n = (size_t)6 * plan.P;
+  if (n && H_host)
+    DBA_HIP_CHECK(hipMemcpyAsync(H_host, plan.W.H, sizeof(double) * n * n, hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream));
+  if (n && v_host)
+    DBA_HIP_CHECK(hipMemcpyAsync(v_host, plan.W.b, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream));
+  DBA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return DBA_OK;
+}
+
+int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int N, int B, int ht,
+                       int wd, int t0, int t1, const double *dx_host, float *dx_out, float *dz_out, void *ws,
+                       size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  const int n = 6 * plan.P;
+  if (n > 0) {
+    if (!dx_host) return DBA_ERR_ARG;
+    std::vector<float> dxf((size_t)n);
+    for (int i = 0; i < n; i++) dxf[i] = (float)dx_host[i];  // f64 -> f32 (:1929-1930)
+    DBA_HIP_CHECK(hipMemcpyAsync(plan.W.dx, dxf.data(), sizeof(float) * n, hipMemcpyHostToDevice,
+                                 (hipStream_t)stream));
+    DBA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // dxf goes out of scope
+  }
+  rc = dba_ba_update(poses, disps, ii, jj, nullptr, N, B, ht, wd, t0, t1, 1, 1, dz_out, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  if (dx_out && n > 0) {
+    hipLaunchKernelGGL(ba_copy_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.dx,
+                       dx_out, n);
+    DBA_LAUNCH_CHECK();
+  }
+  return DBA_OK;
+}
+
+int dba_bacore_optimize(const double *H_host, const double *v_host, int N, int B, int ht, int wd, int t0,
+                        int t1, float lm, float ep, float *dx_out, void *ws, size_t ws_bytes,
+                        dba_stream_t stream) {
+  BaPlan plan;
+  int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  const size_t n = (size_t)6 * plan.P;
+  if (n == 0) return DBA_OK;
+  if (!H_host || !v_host) return DBA_ERR_ARG;
+  DBA_HIP_CHECK(hipMemcpyAsync(plan.W.H, H_host, sizeof(double) * n * n, hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+  DBA_HIP_CHECK(hipMemcpyAsync(plan.W.b, v_host, sizeof(double) * n, hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+  rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  if (dx_out) {
+    hipLaunchKernelGGL(ba_copy_f32_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       plan.W.dx, dx_out, (int)n);
+    DBA_LAUNCH_CHECK();
+  }
+  DBA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // host buffers may be freed on return
+  return DBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Internal declarations shared by the BA kernels and their host launcher.
+#pragma once
+#include "common.h"
+
+namespace dba {
+
+constexpr int HP_STRIDE = 96;  // floats per per-wave J^T W J partial (90 used)
+
+// device index tables (all int32, inside the workspace)
+struct BaTables {
+  int *meta;        // [0] = |kx|, [1] = last solve failed, [2] = kx overflowed Mmax (cannot happen)
+  int *kx;          // [Mmax]   frame id of slot m (sorted unique of arange(t0,t1) U ii)
+  int *frame_slot;  // [B]      slot of frame f, -1 if absent
+  int *eoff;        // [Mmax+1] CSR offsets of the out-edges of slot m
+  int *elist;       // [N]      edge ids, ascending within a slot
+  int Mmax, B;
+};
+
+struct BaBuffers {
+  float *E;      // [(P+N), 6, HW]  rows 0..P-1 = Ei (pose i of frame t0+p), rows P+n = Eij of edge n
+  float *Q;      // [Mmax, HW]      1 / C
+  float *w;      // [Mmax, HW]
+  float *Hpart;  // [N, nparts, HP_STRIDE]
+  double *H;     // [6P, 6P]
+  double *b;     // [6P]
+  float *dx;     // [P, 6]
+  double *Lscratch;  // packed lower triangle for systems too large for LDS
+  int nparts;    // pixel slices (waves) per frame
+};
+
+struct BaPlan {  // host-side view of the workspace
+  BaTables T;
+  BaBuffers W;
+  dba_ba_layout layout;
+  size_t bytes;
+  int P, N, B, HW, nchunks;
+};
+
+int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan);
+
+// kernels (ba_kernels.hip / ba_solve.hip)
+__global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1,
+                                  BaTables T);
+__global__ void ba_linearize_kernel(const float *poses, const float *disps, const float *intrinsics,
+                                    const float *disps_sens, const float *targets, const float *weights,
+                                    const float *eta, int eta_rows, const int64_t *jj,
+                                    const uint8_t *frame_owned, int N, int HW, int wd, int t0, int P,
+                                    float alpha, BaTables T, BaBuffers W);
+__global__ void ba_reduce_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
+                                 int HW, int t0, int P, int motion_only, BaTables T, BaBuffers W);
+__global__ void ba_update_kernel(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned,
+                                 int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
+                                 BaTables T, BaBuffers W);
+__global__ void ba_copy_dx_kernel(const double *src, float *dst, int n);
+__global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
+
+// damped float64 Cholesky solve of H x = b, one workgroup
+int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
+                    double *Lscratch, hipStream_t stream);
+bool ba_solve_fits_lds(int n);
+constexpr int SOLVE_MAX_LDS_BYTES = 160 * 1024;
+
+}  // namespace dba

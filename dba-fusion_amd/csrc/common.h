@@ -1,0 +1,119 @@
+// Shared device helpers for the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dba_hip.h"
+
+namespace dba {
+
+constexpr int WAVE = 64;
+
+// ---- host-side error plumbing -------------------------------------------------------------
+void set_last_error(const char *what, hipError_t e);
+
+#define DBA_HIP_CHECK(expr)                                \
+  do {                                                     \
+    hipError_t e_ = (expr);                                \
+    if (e_ != hipSuccess) {                                \
+      ::dba::set_last_error(#expr, e_);                    \
+      return DBA_ERR_HIP;                                  \
+    }                                                      \
+  } while (0)
+
+#define DBA_LAUNCH_CHECK() DBA_HIP_CHECK(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- wave64 cross-lane reductions with DPP ------------------------------------------------
+// Sum over the 64 lanes of a wavefront.  row_shr 1,2,4,8 fold each 16-lane row into its lane 15,
+// row_bcast:15 / row_bcast:31 carry the row totals across rows; the total lands in lane 63.
+// (DPP modifiers fuse into v_add_f32, so one value costs six VALU instructions and no LDS traffic.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false);
+  return x + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float x) {
+  x = dpp_add<0x111, 0xf>(x);  // row_shr:1
+  x = dpp_add<0x112, 0xf>(x);  // row_shr:2
+  x = dpp_add<0x114, 0xf>(x);  // row_shr:4
+  x = dpp_add<0x118, 0xf>(x);  // row_shr:8
+  x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 -> rows 1,3
+  x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 -> rows 2,3
+  return x;
+}
+
+// total broadcast to every lane (via SGPR)
+__device__ __forceinline__ float wave_sum(float x) {
+  x = wave_sum_to_lane63(x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// Place the lane-63 value of `reduced` into lane `LANE` of `dst` (v_readlane + v_cndmask; clang has no
+// writelane builtin and hazards inside inline asm are not padded by the compiler).
+template <int LANE>
+__device__ __forceinline__ float deposit_lane63(float dst, float reduced, int lane) {
+  const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(reduced), 63));
+  return (lane == LANE) ? s : dst;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- SE3 helpers on (t, q_xyzw) -----------------------------------------------------------
+struct Rot3 {
+  float r[9];  // row-major
+};
+
+__device__ __forceinline__ Rot3 quat_to_rot(const float *q) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  Rot3 R;
+  // v + 2 w (q x v) + 2 q x (q x v), expanded (not assuming |q| = 1 would differ only at O(|q|^2-1))
+  R.r[0] = 1.f - 2.f * (y * y + z * z);
+  R.r[1] = 2.f * (x * y - w * z);
+  R.r[2] = 2.f * (x * z + w * y);
+  R.r[3] = 2.f * (x * y + w * z);
+  R.r[4] = 1.f - 2.f * (x * x + z * z);
+  R.r[5] = 2.f * (y * z - w * x);
+  R.r[6] = 2.f * (x * z - w * y);
+  R.r[7] = 2.f * (y * z + w * x);
+  R.r[8] = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+
+// rotate v by quaternion q (same formula as the reference's actSO3, droid_kernels.cu:61-71)
+__device__ __forceinline__ void quat_rotate(const float *q, const float *X, float *Y) {
+  const float uv0 = 2.f * (q[1] * X[2] - q[2] * X[1]);
+  const float uv1 = 2.f * (q[2] * X[0] - q[0] * X[2]);
+  const float uv2 = 2.f * (q[0] * X[1] - q[1] * X[0]);
+  Y[0] = X[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+  Y[1] = X[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+  Y[2] = X[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+}
+
+// Gij = Tj * Ti^-1 (droid_kernels.cu:99-110)
+__device__ __forceinline__ void rel_pose(const float *Pi, const float *Pj, float *tij, float *qij) {
+  const float *ti = Pi, *qi = Pi + 3, *tj = Pj, *qj = Pj + 3;
+  qij[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+  qij[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+  qij[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+  qij[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+  float rt[3];
+  quat_rotate(qij, ti, rt);
+  tij[0] = tj[0] - rt[0];
+  tij[1] = tj[1] - rt[1];
+  tij[2] = tj[2] - rt[2];
+}
+
+// relative pose of an edge, with the stereo special case (ix == jx) of droid_kernels.cu:263-273
+__device__ __forceinline__ void edge_pose(const float *poses, int ix, int jx, float *tij, float *qij) {
+  if (ix == jx) {
+    tij[0] = -0.1f; tij[1] = 0.f; tij[2] = 0.f;
+    qij[0] = 0.f; qij[1] = 0.f; qij[2] = 0.f; qij[3] = 1.f;
+  } else {
+    rel_pose(poses + 7 * ix, poses + 7 * jx, tij, qij);
+  }
+}
+
+}  // namespace dba

@@ -1,0 +1,257 @@
+// Windowed bilinear lookup from the all-pairs correlation volume, gfx950.
+//
+// Replaces corr_index_forward_kernel / corr_index_backward_kernel
+// (/root/reference/src/correlation_kernels.cu:19-124) and, in its fused form, the four per-level
+// launches + torch.cat of CorrBlock.__call__ (/root/reference/dbaf/modules/corr.py:40-50).
+//
+// The reference scatters every tap into four outputs with read-modify-write `+=` on c10::Half in global
+// memory (4 RMW x 64 taps per pixel).  Here one lane owns one (edge, pixel, level): it pulls the
+// (2r+2)^2 window of its private (h2,w2) plane into registers with 16-byte row loads (the plane rows
+// are the only HBM traffic: 8 x 16 B per pixel and level), forms each of the (2r+1)^2 outputs from its
+// four taps in the reference's accumulation order with the same round-to-half after every operation
+// (bit-exact), and writes every output once, coalesced across the wave.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+// bit-exact parity with the reference arithmetic: no mul+add fusion anywhere in this file
+#pragma clang fp contract(off)
+
+namespace dba {
+
+constexpr int MAX_LEVELS = 8;
+
+struct LookupLevels {
+  const void *vol[MAX_LEVELS];
+};
+
+struct __attribute__((packed, aligned(2))) Half8 {
+  _Float16 v[8];
+};
+struct __attribute__((packed, aligned(4))) Float8 {
+  float v[8];
+};
+
+template <typename T>
+struct Arith;
+
+// c10::Half semantics: every operator computes in float and rounds the result to half.
+template <>
+struct Arith<_Float16> {
+  // scalar_t(dx * dy): the product is rounded to f32 first, then to half.  v_fma_mixlo_f16 (which the
+  // compiler would pick for mul+convert) rounds the exact product once, which differs in ~1e-4 of the
+  // cases, so the f32 value is pinned in a register before the conversion.
+  __device__ static __forceinline__ float weight(float w) {
+    asm volatile("" : "+v"(w));
+    return (float)(_Float16)w;
+  }
+  __device__ static __forceinline__ float mul(float s, float w) { return (float)(_Float16)(s * w); }
+  __device__ static __forceinline__ float add(float a, float b) { return (float)(_Float16)(a + b); }
+};
+template <>
+struct Arith<float> {
+  __device__ static __forceinline__ float weight(float w) { return w; }
+  __device__ static __forceinline__ float mul(float s, float w) { return __fmul_rn(s, w); }
+  __device__ static __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+};
+
+// COORD_NHW2: coords laid out [n,h1,w1,2] (projective_transform output) instead of [n,2,h1,w1]
+template <typename T, int R, bool COORD_NHW2>
+__global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const float *__restrict__ coords,
+                                                          T *__restrict__ out, int n, int h1, int w1, int h2,
+                                                          int w2, int num_levels) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  const int HW1 = h1 * w1;
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long)n * HW1) return;
+  const int lvl = blockIdx.y;
+  const int e = (int)(pix / HW1), rem = (int)(pix - (long)e * HW1);
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+
+  float cx, cy;
+  if constexpr (COORD_NHW2) {
+    const float2 c = reinterpret_cast<const float2 *>(coords)[pix];
+    cx = c.x;
+    cy = c.y;
+  } else {
+    cx = coords[((size_t)e * 2 + 0) * HW1 + rem];
+    cy = coords[((size_t)e * 2 + 1) * HW1 + rem];
+  }
+  // `coords / 2**i` (corr.py:47): exact power-of-two division
+  const float scale = 1.0f / (float)(1 << lvl);
+  const float x0 = cx * scale, y0 = cy * scale;
+  const float fx = floorf(x0), fy = floorf(y0);
+  const float dx = x0 - fx, dy = y0 - fy;
+  // coordinates far outside any plane (or non-finite) see no in-bounds tap at all
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const int ix0 = sane ? (int)fx - R : -(1 << 20);
+  const int iy0 = sane ? (int)fy - R : -(1 << 20);
+
+  const T *plane = static_cast<const T *>(L.vol[lvl]) + (size_t)pix * h2l * w2l;
+
+  float win[WN][WN];  // [row j (y)][col i (x)]
+  const bool interior = (ix0 >= 0) && (iy0 >= 0) && (ix0 + WN <= w2l) && (iy0 + WN <= h2l);
+  if (WN == 8 && interior) {
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      const T *row = plane + (size_t)(iy0 + j) * w2l + ix0;
+      if constexpr (sizeof(T) == 2) {
+        const Half8 v = *reinterpret_cast<const Half8 *>(row);
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[j][i] = (float)v.v[i];
+      } else {
+        const Float8 v = *reinterpret_cast<const Float8 *>(row);
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[j][i] = v.v[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      const int y1 = iy0 + j;
+      const bool rok = (y1 >= 0) && (y1 < h2l);
+#pragma unroll
+      for (int i = 0; i < WN; i++) {
+        const int x1 = ix0 + i;
+        const bool ok = rok && (x1 >= 0) && (x1 < w2l);
+        win[j][i] = ok ? (float)plane[(size_t)y1 * w2l + x1] : 0.f;  // out-of-bounds taps contribute +0
+      }
+    }
+  }
+
+  const float w00 = Arith<T>::weight((1.0f - dx) * (1.0f - dy));
+  const float w01 = Arith<T>::weight((1.0f - dx) * dy);
+  const float w10 = Arith<T>::weight(dx * (1.0f - dy));
+  const float w11 = Arith<T>::weight(dx * dy);
+
+  T *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + rem;
+#pragma unroll
+  for (int a = 0; a < RD; a++) {    // x offset (outer loop i of the reference)
+#pragma unroll
+    for (int b = 0; b < RD; b++) {  // y offset
+      // accumulation order of correlation_kernels.cu:55-65 seen from output (a,b):
+      //   tap(a,b)*(1-dx)(1-dy), tap(a,b+1)*(1-dx)dy, tap(a+1,b)*dx(1-dy), tap(a+1,b+1)*dx*dy
+      float acc = Arith<T>::mul(win[b][a], w00);  // 0 + p == p
+      acc = Arith<T>::add(acc, Arith<T>::mul(win[b + 1][a], w01));
+      acc = Arith<T>::add(acc, Arith<T>::mul(win[b][a + 1], w10));
+      acc = Arith<T>::add(acc, Arith<T>::mul(win[b + 1][a + 1], w11));
+      o[(size_t)(a * RD + b) * HW1] = (T)acc;
+    }
+  }
+}
+
+// adjoint (training only): every (pixel, tap) owns its volume_grad element, no atomics needed
+template <int R>
+__global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float *__restrict__ coords,
+                                                                   const float *__restrict__ corr_grad,
+                                                                   float *__restrict__ volume_grad, int n,
+                                                                   int h1, int w1, int h2, int w2) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  const int HW1 = h1 * w1;
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long)n * HW1) return;
+  const int e = (int)(pix / HW1), rem = (int)(pix - (long)e * HW1);
+  const float x0 = coords[((size_t)e * 2 + 0) * HW1 + rem];
+  const float y0 = coords[((size_t)e * 2 + 1) * HW1 + rem];
+  const float fx = floorf(x0), fy = floorf(y0);
+  const float dx = x0 - fx, dy = y0 - fy;
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  if (!sane) return;
+  const int ix0 = (int)fx - R, iy0 = (int)fy - R;
+  const float *g = corr_grad + (size_t)e * RD * RD * HW1 + rem;
+  float *plane = volume_grad + (size_t)pix * h2 * w2;
+#pragma unroll
+  for (int i = 0; i < WN; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      const int x1 = ix0 + i, y1 = iy0 + j;
+      if (x1 < 0 || x1 >= w2 || y1 < 0 || y1 >= h2) continue;
+      float acc = 0.f;
+      if (i > 0 && j > 0) acc = __fadd_rn(acc, __fmul_rn(g[(size_t)((i - 1) * RD + (j - 1)) * HW1], dx * dy));
+      if (i > 0 && j < RD) acc = __fadd_rn(acc, __fmul_rn(g[(size_t)((i - 1) * RD + j) * HW1], dx * (1.0f - dy)));
+      if (i < RD && j > 0) acc = __fadd_rn(acc, __fmul_rn(g[(size_t)(i * RD + (j - 1)) * HW1], (1.0f - dx) * dy));
+      if (i < RD && j < RD) acc = __fadd_rn(acc, __fmul_rn(g[(size_t)(i * RD + j) * HW1], (1.0f - dx) * (1.0f - dy)));
+      plane[(size_t)y1 * w2 + x1] += acc;
+    }
+}
+
+template <typename T, bool NHW2>
+static int launch_lookup(const LookupLevels &L, const float *coords, void *out, int n, int h1, int w1, int h2,
+                         int w2, int num_levels, int radius, hipStream_t stream) {
+  const long total = (long)n * h1 * w1;
+  if (total == 0) return DBA_OK;
+  dim3 grid((unsigned)((total + 255) / 256), num_levels);
+#define LAUNCH_R(RR)                                                                                     \
+  hipLaunchKernelGGL((corr_lookup_kernel<T, RR, NHW2>), grid, dim3(256), 0, stream, L, coords, (T *)out, n, \
+                     h1, w1, h2, w2, num_levels)
+  switch (radius) {
+    case 1: LAUNCH_R(1); break;
+    case 2: LAUNCH_R(2); break;
+    case 3: LAUNCH_R(3); break;
+    case 4: LAUNCH_R(4); break;
+    default: return DBA_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH_R
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+}  // namespace dba
+
+using namespace dba;
+
+extern "C" {
+
+int dba_corr_index_forward(const void *volume, const float *coords, void *corr, int n, int h1, int w1, int h2,
+                           int w2, int radius, int dtype, dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0) return DBA_ERR_ARG;
+  if (n > 0 && (!volume || !coords || !corr)) return DBA_ERR_ARG;
+  LookupLevels L;
+  for (int l = 0; l < MAX_LEVELS; l++) L.vol[l] = volume;
+  if (dtype == DBA_F16)
+    return launch_lookup<_Float16, false>(L, coords, corr, n, h1, w1, h2, w2, 1, radius, (hipStream_t)stream);
+  if (dtype == DBA_F32)
+    return launch_lookup<float, false>(L, coords, corr, n, h1, w1, h2, w2, 1, radius, (hipStream_t)stream);
+  return DBA_ERR_UNSUPPORTED;
+}
+
+int dba_corr_lookup_pyramid(const void *const *volumes, const float *coords_nhw2, void *corr, int n, int h1,
+                            int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                            dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > MAX_LEVELS)
+    return DBA_ERR_ARG;
+  if (n > 0 && (!volumes || !coords_nhw2 || !corr)) return DBA_ERR_ARG;
+  LookupLevels L;
+  for (int l = 0; l < MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? volumes[l] : nullptr;
+  if (dtype == DBA_F16)
+    return launch_lookup<_Float16, true>(L, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius,
+                                         (hipStream_t)stream);
+  if (dtype == DBA_F32)
+    return launch_lookup<float, true>(L, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius,
+                                      (hipStream_t)stream);
+  return DBA_ERR_UNSUPPORTED;
+}
+
+int dba_corr_index_backward(const float *coords, const float *corr_grad, float *volume_grad, int n, int h1,
+                            int w1, int h2, int w2, int radius, dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0) return DBA_ERR_ARG;
+  const long total = (long)n * h1 * w1;
+  if (total == 0) return DBA_OK;
+  dim3 grid((unsigned)((total + 255) / 256));
+#define LAUNCH_R(RR)                                                                                          \
+  hipLaunchKernelGGL((corr_lookup_backward_kernel<RR>), grid, dim3(256), 0, (hipStream_t)stream, coords, corr_grad, \
+                     volume_grad, n, h1, w1, h2, w2)
+  switch (radius) {
+    case 1: LAUNCH_R(1); break;
+    case 2: LAUNCH_R(2); break;
+    case 3: LAUNCH_R(3); break;
+    case 4: LAUNCH_R(4); break;
+    default: return DBA_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH_R
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+}  // extern "C"

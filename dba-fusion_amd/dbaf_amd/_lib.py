@@ -1,0 +1,77 @@
+"""Loader for the gfx950 C-ABI library (dba-fusion_amd/lib/libdba_hip.so, include/dba_hip.h).
+
+The library is built in-tree by `make lib` / `__graft_entry__.build()`.  There is NO fallback: if the
+shared object is missing or a call fails, the product path raises -- it never computes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdba_hip.so")
+
+DBA_F32, DBA_F16, DBA_F64 = 0, 1, 2
+_ERR = {-1: "DBA_ERR_ARG", -2: "DBA_ERR_WORKSPACE", -3: "DBA_ERR_HIP", -4: "DBA_ERR_UNSUPPORTED"}
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+
+class BaLayout(ctypes.Structure):
+    _fields_ = [(n, c_size_t) for n in ("H", "b", "dx", "meta", "E", "Q", "w", "kx")] + \
+               [("P", c_int), ("Mmax", c_int), ("nchunks", c_int)]
+
+
+# every exported symbol of include/dba_hip.h with its (restype, argtypes); pointers are void*
+_P = c_void_p
+SYMBOLS = {
+    "dba_version": (ctypes.c_char_p, []),
+    "dba_last_error": (ctypes.c_char_p, []),
+    "dba_ba_workspace_bytes": (c_size_t, [c_int] * 6),
+    "dba_ba_get_layout": (c_int, [c_int] * 6 + [ctypes.POINTER(BaLayout)]),
+    "dba_ba_prepare": (c_int, [_P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
+    "dba_ba_linearize": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
+    "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
+    "dba_ba_solve": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
+    "dba_ba_update": (c_int, [_P] * 5 + [c_int] * 8 + [_P, _P, c_size_t, _P]),
+    "dba_ba": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
+                                                                     c_size_t, _P]),
+    "dba_bacore_hessian": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P]),
+    "dba_bacore_retract": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
+    "dba_bacore_optimize": (c_int, [_P, _P] + [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),
+    "dba_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "dba_corr_lookup_pyramid": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P]),
+    "dba_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
+    "dba_corr_volume_scratch_bytes": (c_size_t, [c_int] * 6),
+    "dba_corr_volume_build": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
+    "dba_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P]),
+    "dba_reproject": (c_int, [_P] * 5 + [c_int] * 3 + [_P, _P, _P]),
+    "dba_frame_distance": (c_int, [_P] * 5 + [c_int] * 3 + [c_float, _P, _P]),
+    "dba_projmap": (c_int, [_P] * 5 + [c_int] * 3 + [_P, _P, _P]),
+    "dba_iproj": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
+    "dba_depth_filter": (c_int, [_P] * 5 + [c_int] * 4 + [_P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and type every entry point. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "dba_hip: %s not found -- build it with `make lib` (hipcc --offload-arch=gfx950); "
+                "there is no CPU fallback for the DBA hot path" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, str(rc))
+        detail = load().dba_last_error().decode() if rc == -3 else ""
+        raise RuntimeError("dba_hip: %s failed with %s %s" % (what, msg, detail))

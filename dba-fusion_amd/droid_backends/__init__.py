@@ -1,0 +1,330 @@
+"""`droid_backends` for MI355X -- drop-in for the pybind11 module of the same name that the reference
+builds from src/droid.cpp (bindings at /root/reference/src/droid.cpp:297-316).
+
+Same functions, argument order, in-place semantics and error behaviour (a non-contiguous tensor raises
+RuntimeError like TORCH_CHECK at droid.cpp:105-106); every call is a thin adapter over the C ABI of
+include/dba_hip.h (libdba_hip.so, hand-written HIP for gfx950).  Tensors must live on the HIP device
+("cuda" in PyTorch-ROCm): there is no CPU path, calls with CPU tensors raise.
+
+Call sites in the reference that run unmodified against this module:
+  dbaf/depth_video.py:255-265,331-346,392-397,469-478,527,558   (frame_distance, ba, BACore)
+  dbaf/modules/corr.py:9-13,17-20,79-88                          (corr_index_*, altcorr_*)
+  dbaf/dbaf.py:76-79,119-121                                     (iproj, depth_filter)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from dbaf_amd import _lib
+from dbaf_amd._lib import DBA_F16, DBA_F32
+
+__all__ = ["ba", "ba_extend", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
+           "altcorr_backward", "corr_index_forward", "corr_index_backward", "BACore"]
+
+
+def _check(x, name, dtype=None):
+    if not isinstance(x, torch.Tensor):
+        raise RuntimeError("%s must be a torch.Tensor" % name)
+    if not x.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)  # CHECK_CONTIGUOUS, droid.cpp:105
+    if not x.is_cuda:
+        raise RuntimeError("droid_backends (MI355X): %s must be a HIP device tensor; there is no CPU path" % name)
+    if dtype is not None and x.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, x.dtype))
+    return x
+
+
+def _ptr(x):
+    return ctypes.c_void_p(x.data_ptr()) if x is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(N, B, ht, wd, t0, t1, device):
+    nbytes = _lib.load().dba_ba_workspace_bytes(N, B, ht, wd, t0, t1)
+    if nbytes == 0:
+        raise RuntimeError("dba_ba_workspace_bytes: invalid sizes N=%d B=%d ht=%d wd=%d t0=%d t1=%d"
+                           % (N, B, ht, wd, t0, t1))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def _num_kx(eta, ii, t0, t1, ht, wd):
+    """|kx| = |unique(arange(t0,t1) U ii)| without a device sync when eta has one row per kx entry
+    (as DBA-Fusion always passes it, covisible_graph.py:330)."""
+    rows = eta.numel() // (ht * wd)
+    if rows > 1:
+        return rows
+    ts = torch.arange(t0, t1, device=ii.device, dtype=ii.dtype)
+    return int(torch.unique(torch.cat([ts, ii])).numel())
+
+
+def _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj):
+    _check(targets, "targets", torch.float32)
+    _check(weights, "weights", torch.float32)
+    _check(poses, "poses", torch.float32)
+    _check(disps, "disps", torch.float32)
+    _check(intrinsics, "intrinsics", torch.float32)
+    _check(disps_sens, "disps_sens", torch.float32)
+    _check(ii, "ii", torch.int64)
+    _check(jj, "jj", torch.int64)
+    if not eta.is_contiguous():
+        eta = eta.contiguous()  # the reference takes eta.view(-1, ht*wd) of whatever it is given
+    eta = _check(eta, "eta", torch.float32)
+    B, ht, wd = disps.shape
+    return eta, int(ii.shape[0]), int(B), int(ht), int(wd), int(eta.numel() // (ht * wd))
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+       motion_only):
+    """Dense bundle adjustment, in place on poses[t0:t1] and disps[kx] (droid.cpp:109-138)."""
+    eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
+    t0, t1 = int(t0), int(t1)
+    P = t1 - t0
+    ws, nbytes = _ws(N, B, ht, wd, t0, t1, poses.device)
+    dx = torch.zeros(P, 6, dtype=torch.float32, device=poses.device)
+    Mmax = min(B, P + N)
+    dz_full = torch.zeros(Mmax, ht * wd, dtype=torch.float32, device=poses.device)
+    rc = _lib.load().dba_ba(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
+                            _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1,
+                            int(iterations), float(lm), float(ep), int(bool(motion_only)), _ptr(dx),
+                            _ptr(dz_full), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "dba_ba")
+    if motion_only:
+        return [dx, None]
+    return [dx, dz_full[:_num_kx(eta, ii, t0, t1, ht, wd)]]
+
+
+def ba_extend(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, H, v, A_prior, t0, t1,
+              iterations, lm, ep, motion_only, skip_solve):
+    """Debug variant bound at droid.cpp:140-178 (never called by the DBA-Fusion runtime): per iteration
+    the reduced system is exported to the CPU float64 tensors H, v; unless skip_solve, it is solved with
+    the prior added (solveDense, droid_kernels.cu:180-198) and the state retracted."""
+    eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
+    t0, t1 = int(t0), int(t1)
+    P = t1 - t0
+    lib = _lib.load()
+    ws, nbytes = _ws(N, B, ht, wd, t0, t1, poses.device)
+    dx = dz = None
+    if motion_only:
+        return ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm,
+                  ep, True)
+    _lib.check(lib.dba_ba_prepare(_ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1, _ptr(ws), nbytes, _stream()),
+               "dba_ba_prepare")
+    Hn = np.zeros((6 * P, 6 * P), np.float64)
+    vn = np.zeros((6 * P,), np.float64)
+    for _ in range(int(iterations)):
+        _lib.check(lib.dba_ba_linearize(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens),
+                                        _ptr(targets), _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj),
+                                        None, N, B, ht, wd, t0, t1, 0.05, _ptr(ws), nbytes, _stream()),
+                   "dba_ba_linearize")
+        _lib.check(lib.dba_ba_reduce(_ptr(ii), _ptr(jj), None, N, B, ht, wd, t0, t1, 0, _ptr(ws), nbytes,
+                                     _stream()), "dba_ba_reduce")
+        lay = _lib.BaLayout()
+        lib.dba_ba_get_layout(N, B, ht, wd, t0, t1, ctypes.byref(lay))
+        n = 6 * P
+        Hd = ws[lay.H:lay.H + 8 * n * n].view(torch.float64).view(n, n)
+        bd = ws[lay.b:lay.b + 8 * n].view(torch.float64)
+        Hn[:] = Hd.cpu().numpy()
+        vn[:] = bd.cpu().numpy()
+        H.copy_(torch.from_numpy(Hn)[:H.shape[0], :H.shape[1]])
+        v.copy_(torch.from_numpy(vn)[:v.shape[0]])
+        if skip_solve:
+            return [dx, dz]
+        prior = Hn.copy()  # Adprior = Ad, then overwritten where A_prior is defined (:1624-1630)
+        Ap = A_prior.detach().cpu().numpy().astype(np.float64)
+        prior[:Ap.shape[0], :Ap.shape[1]] = Ap
+        Ht = np.ascontiguousarray(Hn + prior)
+        dx = torch.zeros(P, 6, dtype=torch.float32, device=poses.device)
+        _lib.check(lib.dba_bacore_optimize(Ht.ctypes.data_as(ctypes.c_void_p),
+                                           vn.ctypes.data_as(ctypes.c_void_p), N, B, ht, wd, t0, t1,
+                                           float(lm), float(ep), _ptr(dx), _ptr(ws), nbytes, _stream()),
+                   "dba_bacore_optimize")
+        Mmax = min(B, P + N)
+        dz_full = torch.zeros(Mmax, ht * wd, dtype=torch.float32, device=poses.device)
+        _lib.check(lib.dba_ba_update(_ptr(poses), _ptr(disps), _ptr(ii), _ptr(jj), None, N, B, ht, wd, t0, t1,
+                                     1, 1, _ptr(dz_full), _ptr(ws), nbytes, _stream()), "dba_ba_update")
+        dz = dz_full[:_num_kx(eta, ii, t0, t1, ht, wd)]
+    return [dx, dz]
+
+
+class BACore:
+    """Split-phase BA for the GTSAM fusion path (src/bacore.h:4-70, droid_kernels.cu:1786-1956):
+    init caches the problem, hessian(H, v) fills CPU float64 H [6P,6P], v [6P] with the Schur-reduced
+    camera system (alpha = 0.001), retract(dx) applies an externally solved float64 update."""
+
+    def __init__(self):
+        self._ready = False
+
+    def init(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm,
+             ep, motion_only):
+        eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
+        self.poses, self.disps, self.intrinsics, self.disps_sens = poses, disps, intrinsics, disps_sens
+        self.targets, self.weights, self.eta, self.ii, self.jj = targets, weights, eta, ii, jj
+        self.t0, self.t1, self.lm, self.ep = int(t0), int(t1), float(lm), float(ep)
+        self.N, self.B, self.ht, self.wd, self.eta_rows = N, B, ht, wd, eta_rows
+        self.P = self.t1 - self.t0
+        self.ws, self.nbytes = _ws(N, B, ht, wd, self.t0, self.t1, poses.device)
+        self.dx = None
+        self._ready = True
+
+    def _dims(self):
+        return (self.N, self.B, self.ht, self.wd, self.t0, self.t1)
+
+    def hessian(self, H, v):
+        assert self._ready, "BACore.init must be called first"
+        if H.is_cuda or v.is_cuda or H.dtype != torch.float64 or v.dtype != torch.float64:
+            raise RuntimeError("BACore.hessian: H, v must be CPU float64 tensors (droid_kernels.cu:1889-1890)")
+        n = 6 * self.P
+        Hh = H if (H.is_contiguous() and tuple(H.shape) == (n, n)) else torch.zeros(n, n, dtype=torch.float64)
+        vh = v if (v.is_contiguous() and tuple(v.shape) == (n,)) else torch.zeros(n, dtype=torch.float64)
+        rc = _lib.load().dba_bacore_hessian(
+            _ptr(self.poses), _ptr(self.disps), _ptr(self.intrinsics), _ptr(self.disps_sens), _ptr(self.targets),
+            _ptr(self.weights), _ptr(self.eta), self.eta_rows, _ptr(self.ii), _ptr(self.jj), *self._dims(),
+            ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream())
+        _lib.check(rc, "dba_bacore_hessian")
+        if Hh is not H:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
+            H.copy_(Hh[:H.shape[0], :H.shape[1]])
+        if vh is not v:
+            v.copy_(vh[:v.shape[0]])
+
+    def optimize(self, H, v):
+        assert self._ready, "BACore.init must be called first"
+        n = 6 * self.P
+        Hh = H.detach().to("cpu", torch.float64).contiguous()
+        vh = v.detach().to("cpu", torch.float64).contiguous()
+        self.dx = torch.zeros(self.P, 6, dtype=torch.float32, device=self.poses.device)
+        rc = _lib.load().dba_bacore_optimize(ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()),
+                                             *self._dims(), self.lm, self.ep, _ptr(self.dx), _ptr(self.ws),
+                                             self.nbytes, _stream())
+        _lib.check(rc, "dba_bacore_optimize")
+        assert Hh.shape[0] >= n
+
+    def retract(self, _dx):
+        assert self._ready, "BACore.init must be called first"
+        dxh = _dx.detach().to("cpu", torch.float64).contiguous().view(-1)
+        if dxh.numel() < 6 * self.P:
+            raise RuntimeError("BACore.retract: dx must have %d entries" % (6 * self.P))
+        dev = self.poses.device
+        dx = torch.zeros(self.P, 6, dtype=torch.float32, device=dev)
+        Mmax = min(self.B, self.P + self.N)
+        dz_full = torch.zeros(Mmax, self.ht * self.wd, dtype=torch.float32, device=dev)
+        rc = _lib.load().dba_bacore_retract(_ptr(self.poses), _ptr(self.disps), _ptr(self.ii), _ptr(self.jj),
+                                            *self._dims(), ctypes.c_void_p(dxh.data_ptr()), _ptr(dx),
+                                            _ptr(dz_full), _ptr(self.ws), self.nbytes, _stream())
+        _lib.check(rc, "dba_bacore_retract")
+        self.dx = dx
+        return [dx, dz_full[:_num_kx(self.eta, self.ii, self.t0, self.t1, self.ht, self.wd)]]
+
+
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    """droid.cpp:181-197."""
+    for x, nm, dt in ((poses, "poses", torch.float32), (disps, "disps", torch.float32),
+                      (intrinsics, "intrinsics", torch.float32), (ii, "ii", torch.int64), (jj, "jj", torch.int64)):
+        _check(x, nm, dt)
+    N = int(ii.shape[0])
+    _, ht, wd = disps.shape
+    dist = torch.zeros(N, dtype=torch.float32, device=poses.device)
+    _lib.check(_lib.load().dba_frame_distance(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj), N,
+                                              int(ht), int(wd), float(beta), _ptr(dist), _stream()),
+               "dba_frame_distance")
+    return dist
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    """droid.cpp:200-215."""
+    for x, nm, dt in ((poses, "poses", torch.float32), (disps, "disps", torch.float32),
+                      (intrinsics, "intrinsics", torch.float32), (ii, "ii", torch.int64), (jj, "jj", torch.int64)):
+        _check(x, nm, dt)
+    N = int(ii.shape[0])
+    _, ht, wd = disps.shape
+    coords = torch.zeros(N, ht, wd, 3, dtype=torch.float32, device=poses.device)
+    valid = torch.zeros(N, ht, wd, 1, dtype=torch.float32, device=poses.device)
+    _lib.check(_lib.load().dba_projmap(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj), N, int(ht),
+                                       int(wd), _ptr(coords), _ptr(valid), _stream()), "dba_projmap")
+    return [coords, valid]
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """droid.cpp:281-295."""
+    for x, nm, dt in ((poses, "poses", torch.float32), (disps, "disps", torch.float32),
+                      (intrinsics, "intrinsics", torch.float32), (ix, "ix", torch.int64),
+                      (thresh, "thresh", torch.float32)):
+        _check(x, nm, dt)
+    num = int(ix.shape[0])
+    nbuf, ht, wd = disps.shape
+    counter = torch.zeros(num, ht, wd, dtype=disps.dtype, device=disps.device)
+    _lib.check(_lib.load().dba_depth_filter(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ix), _ptr(thresh), num,
+                                            int(nbuf), int(ht), int(wd), _ptr(counter), _stream()),
+               "dba_depth_filter")
+    return counter
+
+
+def iproj(poses, disps, intrinsics):
+    """droid.cpp:218-227."""
+    for x, nm in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _check(x, nm, torch.float32)
+    nm_, ht, wd = disps.shape
+    points = torch.zeros(nm_, ht, wd, 3, dtype=disps.dtype, device=disps.device)
+    _lib.check(_lib.load().dba_iproj(_ptr(poses), _ptr(disps), _ptr(intrinsics), int(nm_), int(ht), int(wd),
+                                     _ptr(points), _stream()), "dba_iproj")
+    return points
+
+
+def _vol_dtype(t):
+    if t.dtype == torch.float16:
+        return DBA_F16
+    if t.dtype == torch.float32:
+        return DBA_F32
+    raise RuntimeError("corr_index: volume dtype %s not supported on the MI355X path (half / float)" % t.dtype)
+
+
+def corr_index_forward(volume, coords, radius):
+    """droid.cpp:231-239: volume [n,h1,w1,h2,w2] (half/float), coords [n,2,h1,w1] f32 -> [corr]."""
+    _check(volume, "volume")
+    _check(coords, "coords", torch.float32)
+    n, h1, w1, h2, w2 = volume.shape
+    r = int(radius)
+    corr = torch.empty(n, 2 * r + 1, 2 * r + 1, h1, w1, dtype=volume.dtype, device=volume.device)
+    _lib.check(_lib.load().dba_corr_index_forward(_ptr(volume), _ptr(coords), _ptr(corr), int(n), int(h1), int(w1),
+                                                  int(h2), int(w2), r, _vol_dtype(volume), _stream()),
+               "dba_corr_index_forward")
+    return [corr]
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    """droid.cpp:241-252 (training only)."""
+    _check(volume, "volume")
+    _check(coords, "coords", torch.float32)
+    _check(corr_grad, "corr_grad")
+    n, h1, w1, h2, w2 = volume.shape
+    vg = torch.zeros(volume.shape, dtype=torch.float32, device=volume.device)
+    cg = corr_grad.float().contiguous()
+    _lib.check(_lib.load().dba_corr_index_backward(_ptr(coords), _ptr(cg), _ptr(vg), int(n), int(h1), int(w1),
+                                                   int(h2), int(w2), int(radius), _stream()),
+               "dba_corr_index_backward")
+    return [vg.to(volume.dtype)]
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """droid.cpp:254-264: fmap [B,H,W,C] channels-last, coords [B,S,H1,W1,2] -> [corr [B,S,rd*rd,H1,W1]]."""
+    _check(fmap1, "fmap1")
+    _check(fmap2, "fmap2")
+    _check(coords, "coords", torch.float32)
+    f1 = fmap1 if fmap1.dtype == torch.float32 else fmap1.float()
+    f2 = fmap2 if fmap2.dtype == torch.float32 else fmap2.float()
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = f2.shape
+    r = int(radius)
+    corr = torch.empty(B, S, (2 * r + 1) ** 2, H1, W1, dtype=torch.float32, device=coords.device)
+    _lib.check(_lib.load().dba_altcorr_forward(_ptr(f1), _ptr(f2), _ptr(coords), _ptr(corr), int(B), int(S),
+                                               int(H1), int(W1), int(H2), int(W2), int(C), r, _stream()),
+               "dba_altcorr_forward")
+    return [corr.to(fmap1.dtype)]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """droid.cpp:266-278 (training only; dead in the DBA-Fusion runtime).  Not built yet."""
+    raise NotImplementedError("altcorr_backward: training-only op, not part of the MI355X hot path yet")

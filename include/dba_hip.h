@@ -1,0 +1,209 @@
+/* dba_hip.h -- C ABI of the MI355X (gfx950) dense-bundle-adjustment / correlation backend.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers, sizes and a HIP stream; no
+ * torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to GREAT-WHU/DBA-Fusion, i.e. /root/reference).  The reference binds these
+ * operations through the pybind11 module `droid_backends` (src/droid.cpp:297-316); the module of
+ * the same name under dba-fusion_amd/droid_backends/ is a thin adapter over this ABI
+ * (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers unless the parameter name ends in _host;
+ *   - tensors are dense row-major ("contiguous"), shapes given in comments;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised,
+ *     unless stated otherwise; results are visible to later work on the same stream;
+ *   - return value: 0 = DBA_OK, negative = error (see enum); numerical failure of the pose
+ *     solve is NOT an error: like the reference it yields a zero update
+ *     (src/droid_kernels.cu:193-196, :1263-1266).
+ */
+#ifndef DBA_HIP_H
+#define DBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DBA_OK = 0,
+  DBA_ERR_ARG = -1,       /* bad size / null pointer */
+  DBA_ERR_WORKSPACE = -2, /* workspace too small */
+  DBA_ERR_HIP = -3,       /* a HIP runtime call failed (see dba_last_error) */
+  DBA_ERR_UNSUPPORTED = -4
+};
+
+enum { DBA_F32 = 0, DBA_F16 = 1, DBA_F64 = 2 }; /* element type selector for volume/corr buffers */
+
+typedef void *dba_stream_t;
+
+const char *dba_version(void);
+const char *dba_last_error(void); /* text of the last DBA_ERR_HIP on this thread */
+
+/* ------------------------------------------------------------------------------------------
+ * Dense bundle adjustment: droid_backends.ba  (src/droid.cpp:109-138 -> ba_cuda,
+ * src/droid_kernels.cu:1394-1512) and class BACore (src/bacore.h:4-70,
+ * src/droid_kernels.cu:1786-1956).
+ *
+ *   poses       [B,7]   f32 (tx,ty,tz,qx,qy,qz,qw) world->camera; rows [t0,t1) updated in place
+ *   disps       [B,ht,wd] f32 inverse depth; rows kx = unique(arange(t0,t1) U ii) updated in place
+ *   intrinsics  [4]     f32 (fx,fy,cx,cy) at 1/8 resolution
+ *   disps_sens  [B,ht,wd] f32, 0 = no depth measurement
+ *   targets, weights [N,2,ht,wd] f32 (ch0 = x/u, ch1 = y/v)
+ *   eta         [eta_rows,ht,wd] f32, eta_rows == |kx| or 1 (broadcast)
+ *   ii, jj      [N] int64 on the device
+ *   frame_owned [B] uint8 or NULL: multi-GPU edge sharding by source frame -- a rank linearises
+ *               the edges it was given and updates depth only for frames it owns (NULL = all)
+ *
+ * The workspace (device memory, dba_ba_workspace_bytes) holds the index tables, the
+ * depth/pose coupling rows E, Q = 1/C, w, the reduced camera system (float64) and dx.
+ * ---------------------------------------------------------------------------------------- */
+
+size_t dba_ba_workspace_bytes(int N, int B, int ht, int wd, int t0, int t1);
+
+/* byte offsets inside the workspace of the pieces a host may need to touch between stages
+ * (multi-GPU all-reduce of H/b; BACore handing H/v to the caller).  H is [6P,6P] float64 row-major,
+ * b is [6P] float64, dx is [P,6] float32, meta[0] = |kx| (int32), meta[1] = 1 if the last solve failed. */
+typedef struct {
+  size_t H, b, dx, meta, E, Q, w, kx;
+  int P, Mmax, nchunks;
+} dba_ba_layout;
+int dba_ba_get_layout(int N, int B, int ht, int wd, int t0, int t1, dba_ba_layout *out);
+
+/* stage 0: index sets on the device (replaces the per-iteration host bookkeeping of
+ * ba_cuda :1416-1424, accum_cuda :993-1043 and schur_block :1307-1347). */
+int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
+                   void *ws, size_t ws_bytes, dba_stream_t stream);
+
+/* stage 1: fused per-source-frame linearisation (projective_transform_kernel :220-468 +
+ * accum_kernel :899-919 + C/w/Q assembly :1474-1478); also clears H, b.  alpha = 0.05 for
+ * droid_backends.ba (:1474), 0.001 for BACore::hessian (:1872). */
+int dba_ba_linearize(const float *poses, const float *disps, const float *intrinsics,
+                     const float *disps_sens, const float *targets, const float *weights,
+                     const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                     const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                     float alpha, void *ws, size_t ws_bytes, dba_stream_t stream);
+
+/* stage 2: reduced camera system  H = A - E Q E^T,  b = v - E Q w  in float64
+ * (SparseBlock::update_lhs/rhs :1176-1218, schur_block + EEt6x6/Ev6x1 :1046-1138, :1297-1391).
+ * motion_only != 0 assembles A, v alone (:1464-1471). */
+int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
+                  int ht, int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes,
+                  dba_stream_t stream);
+
+/* stage 3: damped dense Cholesky solve in float64 on the device
+ * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx. */
+int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws,
+                 size_t ws_bytes, dba_stream_t stream);
+
+/* stage 4: back-substitution + retraction (EvT6x1_kernel :1140-1160, dz :1495,
+ * pose_retr_kernel :943-976, disp_retr_kernel :978-991).  dz_out [>=|kx|, ht*wd] may be NULL.
+ * update_poses / update_disps select which retractions are applied. */
+int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj,
+                  const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                  int update_poses, int update_disps, float *dz_out, void *ws, size_t ws_bytes,
+                  dba_stream_t stream);
+
+/* droid_backends.ba: `iterations` x (stage 1..4), all enqueued on `stream` with no host sync.
+ * dx_out [P,6] and dz_out [>=|kx|, ht*wd] receive the last iteration's update (either may be NULL). */
+int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+           const float *targets, const float *weights, const float *eta, int eta_rows,
+           const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
+           int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
+           void *ws, size_t ws_bytes, dba_stream_t stream);
+
+/* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
+ * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */
+int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,
+                       const float *disps_sens, const float *targets, const float *weights,
+                       const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N,
+                       int B, int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
+                       size_t ws_bytes, dba_stream_t stream);
+
+/* BACore::retract: dx_host [6P] float64 (HOST) -> f32 on device, then stage 4 using the E, Q, w
+ * cached by the last dba_bacore_hessian on the same workspace. */
+int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int N, int B,
+                       int ht, int wd, int t0, int t1, const double *dx_host, float *dx_out,
+                       float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream);
+
+/* BACore::optimize: damped dense solve of a caller-supplied HOST system (solveDenseD :200-218);
+ * result kept in the workspace dx slot and copied to dx_out (device, may be NULL). */
+int dba_bacore_optimize(const double *H_host, const double *v_host, int N, int B, int ht, int wd,
+                        int t0, int t1, float lm, float ep, float *dx_out, void *ws, size_t ws_bytes,
+                        dba_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Correlation volume: CorrBlock (dbaf/modules/corr.py:24-71) and its lookup
+ * droid_backends.corr_index_forward (src/droid.cpp:231-239, src/correlation_kernels.cu:19-70,126-155).
+ * ---------------------------------------------------------------------------------------- */
+
+/* corr_index_forward: volume [n,h1,w1,h2,w2] (dtype), coords [n,2,h1,w1] f32 (ch0 = x, ch1 = y)
+ * -> corr [n,2r+1,2r+1,h1,w1] (dtype), channel = x_offset*(2r+1) + y_offset.  Bit-exact with the
+ * reference arithmetic (four c10::Half read-modify-writes per tap in a fixed order). */
+int dba_corr_index_forward(const void *volume, const float *coords, void *corr, int n, int h1, int w1,
+                           int h2, int w2, int radius, int dtype, dba_stream_t stream);
+
+/* fused CorrBlock.__call__ (corr.py:40-50): all pyramid levels in one launch, reading
+ * coords [n,h1,w1,2] as produced by projective_transform and writing the concatenated
+ * [n, L*(2r+1)^2, h1, w1] tensor directly (no per-level tensors, no torch.cat).
+ * level l volume: [n,h1,w1,h2>>l,w2>>l]; coords are divided by 2^l per level. */
+int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device ptrs */,
+                            const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
+                            int w2, int num_levels, int radius, int dtype, dba_stream_t stream);
+
+/* corr_index_backward (src/correlation_kernels.cu:73-124,157-185): adjoint of the lookup;
+ * volume_grad [n,h1,w1,h2,w2] must be zero-initialised by the caller. f32 only. */
+int dba_corr_index_backward(const float *coords, const float *corr_grad, float *volume_grad, int n,
+                            int h1, int w1, int h2, int w2, int radius, dba_stream_t stream);
+
+/* CorrBlock.corr + pyramid (corr.py:24-38, :63-71): fmap1, fmap2 [n,C,h,w] f16 ->
+ * level l [n,h1,w1,h2>>l,w2>>l] f16 for l < num_levels.  corr = (f1/4)^T (f2/4), fp32 accumulate on
+ * MFMA, rounded once to f16; levels l>0 = 2x2 average of the rounded level l-1 (F.avg_pool2d).
+ * scratch: device bytes from dba_corr_volume_scratch_bytes (channels-last staging of the fmaps). */
+size_t dba_corr_volume_scratch_bytes(int n, int C, int h1, int w1, int h2, int w2);
+int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *levels /* host array */,
+                          int n, int C, int h1, int w1, int h2, int w2, int num_levels, void *scratch,
+                          size_t scratch_bytes, dba_stream_t stream);
+
+/* altcorr_forward (src/droid.cpp:254-264, src/altcorr_kernel.cu:27-149,290-319): on-the-fly
+ * windowed correlation. fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last f32,
+ * coords [B,S,H1,W1,2] f32 -> corr [B,S,(2r+1)^2,H1,W1] f32, channel = y_offset + (2r+1)*x_offset. */
+int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr, int B,
+                        int S, int H1, int W1, int H2, int W2, int C, int radius, dba_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry.
+ * ---------------------------------------------------------------------------------------- */
+
+/* pops.projective_transform without jacobians (dbaf/geom/projective_ops.py:96-125) as one kernel:
+ * intrinsics [B,4] per frame; coords [N,ht,wd,2], valid [N,ht,wd,1] f32. */
+int dba_reproject(const float *poses, const float *disps, const float *intrinsics_b4,
+                  const int64_t *ii, const int64_t *jj, int N, int ht, int wd, float *coords,
+                  float *valid, dba_stream_t stream);
+
+/* droid_backends.frame_distance (src/droid.cpp:181-197, src/droid_kernels.cu:562-702). dist [N]. */
+int dba_frame_distance(const float *poses, const float *disps, const float *intrinsics,
+                       const int64_t *ii, const int64_t *jj, int N, int ht, int wd, float beta,
+                       float *dist, dba_stream_t stream);
+
+/* droid_backends.projmap (src/droid.cpp:200-215, src/droid_kernels.cu:471-560).
+ * coords [N,ht,wd,3] (3rd channel left 0), valid [N,ht,wd,1]. */
+int dba_projmap(const float *poses, const float *disps, const float *intrinsics, const int64_t *ii,
+                const int64_t *jj, int N, int ht, int wd, float *coords, float *valid,
+                dba_stream_t stream);
+
+/* droid_backends.iproj (src/droid.cpp:218-227, src/droid_kernels.cu:824-895). points [nm,ht,wd,3]. */
+int dba_iproj(const float *poses, const float *disps, const float *intrinsics, int nm, int ht, int wd,
+              float *points, dba_stream_t stream);
+
+/* droid_backends.depth_filter (src/droid.cpp:281-295, src/droid_kernels.cu:706-820).
+ * counter [num,ht,wd] zero-initialised by the caller; nbuf = disps.size(0). */
+int dba_depth_filter(const float *poses, const float *disps, const float *intrinsics,
+                     const int64_t *inds, const float *thresh, int num, int nbuf, int ht, int wd,
+                     float *counter, dba_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBA_HIP_H */

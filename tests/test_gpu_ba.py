@@ -1,0 +1,140 @@
+"""GPU parity: droid_backends.ba / BACore (HIP, through the C ABI) vs the CPU oracle on identical inputs.
+Tolerances are the ones BASELINE.json's north_star states: inverse depths 1e-4 relative, poses 1e-5 m /
+1e-6 rad."""
+import numpy as np
+import pytest
+import torch
+
+from dbaf_amd import synthetic as syn
+from util import to_dev, check_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def _run_gpu_ba(W, itrs=2, motion_only=False, lm=None, ep=None):
+    import droid_backends
+    d = to_dev(W)
+    dx, dz = droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"],
+                               d["eta"], d["ii"], d["jj"], W.t0, W.t1, itrs, W.lm if lm is None else lm,
+                               W.ep if ep is None else ep, motion_only)
+    torch.cuda.synchronize()
+    return d["poses"].cpu().numpy(), d["disps"].cpu().numpy(), dx.cpu().numpy(), None if dz is None else dz.cpu().numpy()
+
+
+WINDOWS = {
+    "tiny_a": lambda: syn.window_tiny_a(11),
+    "tiny_b_stereo_fixed_sensor": lambda: syn.window_tiny_b(12),
+    "kitti_shape_8kf": lambda: syn.make_window(*syn.graph_banded(8, 2), 8, 28, 107, seed=13,
+                                               intr=(69.0, 69.5, 53.2, 14.1)),
+    "25kf_96edges_64x64": lambda: syn.window_25_96(0),
+}
+
+
+@pytest.mark.parametrize("name", list(WINDOWS))
+def test_ba_matches_oracle(name):
+    orc = _oracle()
+    W = WINDOWS[name]()
+    args = (W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+            W.lm, W.ep, False, 0.05)
+    r32 = orc.ba(*args, np.float32)
+    r64 = orc.ba(*args, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    assert dz.shape == r32["dz"].shape
+    # a14: DepthVideo.ba clamps all disps after the call (depth_video.py:560)
+    clamp = lambda a: np.maximum(a, 0.001)  # noqa: E731
+    print(name, "vs fp64 arbiter:", check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
+                                                ref32_disps=clamp(r32["disps"])))
+    np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
+
+
+def test_ba_single_iteration_and_dz():
+    orc = _oracle()
+    W = syn.window_tiny_b(21)
+    r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 1,
+                 W.lm, W.ep, False, 0.05, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W, itrs=1)
+    check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
+    scale = np.maximum(np.abs(r64["dz"]), np.abs(W.disps[W.kx].reshape(W.M, -1)))
+    assert (np.abs(dz - r64["dz"]) <= 1e-4 * scale + 1e-7).all()
+
+
+def test_ba_motion_only():
+    orc = _oracle()
+    W = syn.window_tiny_b(31)
+    r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+                 W.lm, W.ep, True, 0.05, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W, motion_only=True)
+    assert dz is None
+    assert np.array_equal(disps, W.disps)  # depth untouched
+    check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
+
+
+def test_ba_zero_residual_is_fixed_point():
+    """target = reprojection of the state, no noise => dx = dz = 0 up to rounding (SURVEY 8(c) KAT)."""
+    W = syn.make_window(*syn.graph_banded(5, 2), 5, 24, 32, seed=41, intr=(12.0, 11.5, 15.6, 12.2),
+                        pose_noise=0.0, disp_noise=0.0, target_noise=0.0)
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    assert np.abs(dx).max() < 2e-5
+    assert np.abs(poses - W.poses).max() < 2e-5
+    assert np.abs(disps - W.disps)[:5].max() < 2e-3
+
+
+def test_ba_cholesky_failure_gives_zero_pose_update():
+    """non-SPD system: the reference returns dx = 0 (droid_kernels.cu:1263-1266) and still back-substitutes"""
+    orc = _oracle()
+    W = syn.window_tiny_a(51)
+    r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 1,
+                 W.lm, -1.0e6, False, 0.05, np.float64)
+    assert not r64["ok"]
+    poses, disps, dx, dz = _run_gpu_ba(W, itrs=1, ep=-1.0e6)
+    assert np.array_equal(dx, np.zeros_like(dx))
+    np.testing.assert_allclose(poses, W.poses, rtol=0, atol=1e-7)
+    check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
+
+
+def test_bacore_hessian_and_retract():
+    import droid_backends
+    orc = _oracle()
+    W = syn.window_tiny_b(61)
+    oc = orc.BACore(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1,
+                    W.lm, W.ep, np.float64)
+    Ho, vo = oc.hessian()
+    d = to_dev(W)
+    core = droid_backends.BACore()
+    core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+              d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    n = 6 * (W.t1 - W.t0)
+    H = torch.zeros(n, n, dtype=torch.float64)
+    v = torch.zeros(n, dtype=torch.float64)
+    core.hessian(H, v)
+    np.testing.assert_allclose(H.numpy(), Ho, rtol=0, atol=2e-5 * np.abs(Ho).max())
+    np.testing.assert_allclose(v.numpy(), vo, rtol=0, atol=2e-5 * np.abs(vo).max())
+    # external solve (stands in for GTSAM, depth_video.py:528-557), then retract on both sides
+    L = Ho + np.diag(W.ep + W.lm * np.diag(Ho))
+    dx = np.linalg.solve(L, vo)
+    dxo, dzo = oc.retract(dx)
+    dxg, dzg = core.retract(torch.from_numpy(dx))
+    torch.cuda.synchronize()
+    check_state(d["poses"].cpu().numpy(), d["disps"].cpu().numpy(), oc.poses, oc.disps, W.disps)
+    assert dzg.shape == dzo.shape
+    # optimize(): damped dense solve of a caller-supplied system
+    core.optimize(torch.from_numpy(Ho), torch.from_numpy(vo))
+    np.testing.assert_allclose(core.dx.cpu().numpy().reshape(-1), dx, rtol=1e-4, atol=1e-7)
+    del core
+
+
+def test_ba_rejects_cpu_and_noncontiguous():
+    import droid_backends
+    W = syn.window_tiny_a(71)
+    d = to_dev(W)
+    with pytest.raises(RuntimeError):
+        droid_backends.ba(d["poses"].cpu(), d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"],
+                          d["eta"], d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    with pytest.raises(RuntimeError):
+        droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"].transpose(2, 3),
+                          d["weight"], d["eta"], d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)

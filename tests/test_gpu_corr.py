@@ -1,0 +1,139 @@
+"""GPU parity for the correlation half: lookup (bit-exact), volume build (<= 1 fp16 ulp), altcorr."""
+import numpy as np
+import pytest
+import torch
+
+from dbaf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle as orc
+    return orc
+
+
+def _coords(rng, n, h1, w1, h2, w2, oob=0.1):
+    c = np.stack([rng.uniform(-2, w2 + 1, size=(n, h1, w1)), rng.uniform(-2, h2 + 1, size=(n, h1, w1))], 1)
+    far = rng.uniform(size=(n, h1, w1)) < oob
+    c[:, 0][far] += rng.choice([-1, 1], size=int(far.sum())) * rng.uniform(10, 500, size=int(far.sum()))
+    c[0, :, 0, 0] = [3.0, 4.0]        # integer coordinates: dx = dy = 0
+    c[0, :, 0, 1] = [-0.5, h2 - 0.5]  # straddles the border
+    return c.astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 16, 3), (3, 7, 13, 9, 21, 3), (1, 8, 8, 8, 8, 3),
+                                   (2, 6, 5, 12, 10, 2), (1, 5, 6, 11, 9, 4), (2, 4, 4, 20, 20, 1)])
+def test_corr_index_forward_bit_exact(dtype, shape):
+    import droid_backends
+    orc = _oracle()
+    n, h1, w1, h2, w2, r = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    vol = (rng.standard_normal((n, h1, w1, h2, w2)) * 4).astype(dtype)
+    coords = _coords(rng, n, h1, w1, h2, w2)
+    ref = orc.corr_index_forward(vol, coords, r)
+    out, = droid_backends.corr_index_forward(torch.from_numpy(vol).cuda(), torch.from_numpy(coords).cuda(), r)
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    if dtype == np.float16:
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), \
+            "max abs diff %g" % np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()
+    else:
+        assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
+
+
+def test_corr_index_forward_empty_and_errors():
+    import droid_backends
+    vol = torch.zeros(0, 4, 4, 4, 4, dtype=torch.float16, device="cuda")
+    coords = torch.zeros(0, 2, 4, 4, device="cuda")
+    out, = droid_backends.corr_index_forward(vol, coords, 3)
+    assert out.shape == (0, 7, 7, 4, 4)
+    with pytest.raises(RuntimeError):
+        droid_backends.corr_index_forward(torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 2, 4, 4), 3)  # CPU tensors
+
+
+def test_corrblock_pyramid_lookup_matches_per_level_oracle():
+    """fused CorrBlock.__call__ == 4x corr_index_forward(coords / 2^l) + cat (corr.py:40-50)"""
+    from dbaf_amd.corr import CorrBlock
+    orc = _oracle()
+    rng = np.random.default_rng(5)
+    n, C, h, w = 3, 32, 16, 24
+    f1 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
+    f2 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
+    cb = CorrBlock(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), num_levels=4, radius=3)
+    pyr_gpu = [p.cpu().numpy() for p in cb.corr_pyramid]
+    coords = _coords(rng, n, h, w, h, w).transpose(0, 2, 3, 1)  # [n,h,w,2]
+    out = cb(torch.from_numpy(np.ascontiguousarray(coords))[None].cuda()).cpu().numpy()[0]
+    ref = orc.corr_lookup_pyramid(pyr_gpu, coords, 3)  # oracle lookup on the GPU-built pyramid
+    assert out.shape == ref.shape == (n, 196, h, w)
+    assert np.array_equal(out.view(np.uint16), ref.view(np.uint16))
+
+
+def _ulp_diff_f16(a, b):
+    ai = a.view(np.int16).astype(np.int32)
+    bi = b.view(np.int16).astype(np.int32)
+    ai = np.where(ai < 0, -(ai & 0x7fff), ai)
+    bi = np.where(bi < 0, -(bi & 0x7fff), bi)
+    return np.abs(ai - bi)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16), (1, 64, 11, 13), (1, 128, 8, 40)])
+def test_corr_volume_build_matches_oracle(shape):
+    from dbaf_amd.corr import CorrBlock
+    orc = _oracle()
+    n, C, h, w = shape
+    rng = np.random.default_rng(7)
+    f1 = rng.standard_normal((n, C, h, w)).astype(np.float16)
+    f2 = rng.standard_normal((n, C, h, w)).astype(np.float16)
+    nl = 4 if min(h, w) >= 16 else 2
+    pyr = CorrBlock.build_pyramid(torch.from_numpy(f1)[None].cuda(), torch.from_numpy(f2)[None].cuda(), nl)
+    ref = orc.corr_pyramid(f1, f2, nl)
+    # level 0 = fp16(round) of an fp32-accumulated 128-term dot product.  The MFMA accumulation order differs
+    # from any sequential order, so compare with the exact (float64) product: half an fp16 ulp of rounding
+    # plus the fp32 accumulation error bound K * eps32 * sum|a b| (here ~1e-5).
+    g0 = pyr[0].cpu().numpy()
+    assert g0.shape == ref[0].shape
+    a = (f1.astype(np.float64) / 4).reshape(n, C, h * w)
+    b = (f2.astype(np.float64) / 4).reshape(n, C, h * w)
+    exact = np.einsum("ncp,ncq->npq", a, b).reshape(g0.shape)
+    bound = C * 6e-8 * np.einsum("ncp,ncq->npq", np.abs(a), np.abs(b)).reshape(g0.shape)
+    ulp16 = np.maximum(np.spacing(np.abs(exact).astype(np.float16)).astype(np.float64), 2.0 ** -24)
+    assert (np.abs(g0.astype(np.float64) - exact) <= 0.5 * ulp16 + bound).all()
+    ulp = _ulp_diff_f16(g0, ref[0])  # and against the sequential-order oracle: identical but for rare 1-ulp ties
+    assert (ulp > 0).mean() < 0.01 and ulp[np.abs(ref[0].astype(np.float32)) > 0.01].max() <= 1
+    # pooled levels are exact functions of the level below: check against the oracle pooling of the GPU level
+    for l in range(1, nl):
+        below = pyr[l - 1].cpu().numpy()
+        want = orc.avg_pool2(below)
+        got = pyr[l].cpu().numpy()
+        assert got.shape == want.shape
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+def test_altcorr_forward_matches_oracle():
+    import droid_backends
+    orc = _oracle()
+    rng = np.random.default_rng(9)
+    B, S, H1, W1, H2, W2, C, r = 2, 2, 9, 12, 5, 7, 64, 3
+    f1 = rng.standard_normal((B, H1, W1, C)).astype(np.float32)
+    f2 = rng.standard_normal((B, H2, W2, C)).astype(np.float32)
+    coords = np.stack([rng.uniform(-2, W2 + 1, size=(B, S, H1, W1)), rng.uniform(-2, H2 + 1, size=(B, S, H1, W1))],
+                      -1).astype(np.float32)
+    ref = orc.altcorr_forward(f1, f2, coords, r)
+    out, = droid_backends.altcorr_forward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
+                                          torch.from_numpy(coords).cuda(), r)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_corr_index_backward_matches_oracle():
+    import droid_backends
+    orc = _oracle()
+    rng = np.random.default_rng(10)
+    n, h1, w1, h2, w2, r = 2, 6, 7, 9, 8, 3
+    coords = _coords(rng, n, h1, w1, h2, w2)
+    cg = rng.standard_normal((n, 7, 7, h1, w1)).astype(np.float32)
+    ref = orc.corr_index_backward((n, h1, w1, h2, w2), coords, cg, r)
+    vol = torch.zeros(n, h1, w1, h2, w2, device="cuda")
+    out, = droid_backends.corr_index_backward(vol, torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda(), r)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
