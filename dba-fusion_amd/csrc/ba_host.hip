@@ -47,7 +47,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   L.b = take(sizeof(double) * (size_t)(n6 > 0 ? n6 : 1));
   size_t o_lscratch = 0;
   const bool lds_fits = ba_solve_fits_lds(n6);
-  if (!lds_fits) o_lscratch = take(sizeof(double) * (size_t)n6 * (n6 + 1) / 2);
+  if (!lds_fits) o_lscratch = take(sizeof(double) * ba_solve_scratch_doubles(n6));
   L.P = P;
   L.Mmax = Mmax;
   L.nchunks = nchunks;

@@ -56,8 +56,9 @@ __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
 
 // damped float64 Cholesky solve of H x = b, one workgroup
 int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream);
+                    double *Lscratch, hipStream_t stream, long long *prof = nullptr);
 bool ba_solve_fits_lds(int n);
+size_t ba_solve_scratch_doubles(int n);
 constexpr int SOLVE_MAX_LDS_BYTES = 160 * 1024;
 
 }  // namespace dba

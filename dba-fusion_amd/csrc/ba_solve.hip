@@ -3,18 +3,93 @@
 // Replaces SparseBlock::solve / solveDenseD of the reference
 // (/root/reference/src/droid_kernels.cu:200-218, :1248-1269: Eigen SimplicialLLT / LLT on the host,
 // preceded by D2H copies of Hs, vs, S, v and followed by an H2D copy of dx): here the system never
-// leaves the device.  n = 6P is 144 for a 25-keyframe window; the packed lower triangle
-// (n(n+1)/2 doubles = 83.5 KB at n = 144) lives in LDS for n <= 200 and in an L2-resident global
-// scratch otherwise.  Right-looking blocked LL^T with block size NB = 12 (two pose blocks):
-//   diag factor (one lane, registers) -> panel solve (one row per thread) -> trailing update.
+// leaves the device.  n = 6P is 144 for a 25-keyframe window; the packed lower triangle of the system
+// AUGMENTED with the right-hand side as an extra row ((n+1)(n+2)/2 doubles = 84.7 KB at n = 144) lives in
+// LDS for n <= 199 and in an L2-resident global scratch otherwise.
+//
+// Right-looking blocked LL^T, block size NB = 12 (two pose blocks), three barriers per block step:
+//   D  the 12x12 diagonal block is factored by ONE WAVE with its rows spread over lanes: the pivot and the
+//      column entries travel by v_readlane, the square root is v_rsq_f64 + Newton steps (no f64 divide /
+//      sqrt sequences on the critical path);
+//   P  panel: one row per lane solves X L11^T = A21; the augmented row (the rhs) rides along, which is the
+//      forward substitution L y = b for free;
+//   U  trailing update A22 -= X X^T in 4x4 register tiles, skipping tiles whose panel rows are exactly
+//      zero (the reduced camera matrix of a sliding window is block-banded, so most tiles are skipped).
+// The backward substitution L^T x = y runs block-wise with the 12x12 triangle solved across lanes.
 #include "ba_kernels.h"
 
 namespace dba {
 
+#ifdef PROFILE_SOLVE
+#define PROF_DECL long long t_prev_ = wall_clock64()
+#define PROF(slot)                                       \
+  do {                                                   \
+    if (threadIdx.x == 0 && prof) {                      \
+      long long t_ = wall_clock64();                     \
+      prof[slot] += t_ - t_prev_;                        \
+      t_prev_ = t_;                                      \
+    }                                                    \
+  } while (0)
+#else
+#define PROF_DECL
+#define PROF(slot)
+#endif
+
 constexpr int NB = 12;
-constexpr int SOLVE_THREADS = 512;  // 2 waves/SIMD -> 256 VGPRs: the register-resident 12x12 blocks do not spill
+constexpr int SOLVE_THREADS = 512;  // 2 waves/SIMD: 256 VGPRs, enough to hoist a whole 4x4 tile's operands
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
+
+template <int LANE>
+__device__ __forceinline__ double readlane_f64(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to double precision: v_rsq_f64 seed + two Newton steps (d > 0).  Only the reciprocal of the
+// diagonal sits on the factorisation's critical path; sqrt(d) = d * r is formed off it.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double hd = -0.5 * d;
+  y = y * fma(hd, y * y, 1.5);
+  y = y * fma(hd, y * y, 1.5);
+  return y;
+}
+
+// ---- D: factor the diagonal block with rows across lanes (right-looking, column J) ---------------
+template <int J, int K>
+__device__ __forceinline__ void diag_rank1(double (&a)[NB], double col) {
+  if constexpr (K < NB) {
+    const double ck = readlane_f64<K>(col);
+    a[K] = fma(-col, ck, a[K]);
+    diag_rank1<J, K + 1>(a, col);
+  }
+}
+
+template <int J>
+__device__ __forceinline__ void diag_column(double (&a)[NB], int lane, bool &bad, double *invd) {
+  double d = readlane_f64<J>(a[J]);
+  if (!(d > 0.0)) { bad = true; d = 1.0; }
+  const double r = rsqrt_nr(d);
+  const double col = (lane == J) ? d * r : a[J] * r;
+  a[J] = col;
+  if (lane == 0) invd[J] = r;
+  if constexpr (J + 1 < NB) {
+    diag_rank1<J, J + 1>(a, col);  // a[k] -= col_i * col_k for k > J
+    diag_column<J + 1>(a, lane, bad, invd);
+  }
+}
+
+// ---- backward triangle: solve L11^T x = t with columns across lanes ------------------------------
+// lane c holds t[c], rd = 1/L[c][c] and lcol[j] = L[j][c] for j > c.
+template <int J>
+__device__ __forceinline__ void back_column(const double (&lcol)[NB], double &t, int lane, double rd) {
+  const double xj = readlane_f64<J>(t * rd);
+  if (lane == J) t = xj;
+  else if (lane < J) t = fma(-lcol[J], xj, t);
+  if constexpr (J > 0) back_column<J - 1>(lcol, t, lane, rd);
+}
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *__restrict__ H,
@@ -22,26 +97,30 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
                                                                  double lm, double ep,
                                                                  float *__restrict__ dx,
                                                                  int *__restrict__ meta,
-                                                                 double *__restrict__ Lglobal) {
+                                                                 double *__restrict__ Lglobal,
+                                                                 long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // layout: [A packed (LDS mode only)] [x: n] [rdiag: n] [D: NB*NB] [invd: NB] [fail flag]
+  // layout: [A packed, n+1 rows (LDS mode only)] [rdiag: n] [D: NB*NB] [invd: NB] [rowflag: n+1 ints] [fail]
+  const int n1 = n + 1;
   double *A;
-  double *x;
+  double *rdiag;
   if constexpr (USE_LDS) {
     A = smem;
-    x = smem + (size_t)n * (n + 1) / 2;
+    rdiag = smem + (size_t)n1 * (n1 + 1) / 2;
   } else {
     A = Lglobal;
-    x = smem;
+    rdiag = smem;
   }
-  double *rdiag = x + n;      // 1 / L_jj for every column
-  double *D = rdiag + n;      // current diagonal block, row-major NB x NB
-  double *invd = D + NB * NB; // reciprocal diagonal of the current block
-  int *fail = (int *)(invd + NB);
+  double *D = rdiag + n;
+  double *invd = D + NB * NB;
+  int *rowflag = (int *)(invd + NB);
+  int *fail = rowflag + n1 + 1;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
 
+  PROF_DECL;
   if (tid == 0) *fail = 0;
-  // load lower triangle with damping: diag += ep + lm * diag (:1252-1253)
+  // load the lower triangle with damping diag += ep + lm * diag (:1252-1253); row n = rhs
   for (int e = tid; e < n * n; e += nt) {
     const int i = e / n, j = e - i * n;
     if (j > i) continue;
@@ -49,150 +128,138 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
     if (i == j) v += ep + lm * v;
     A[tri(i, j)] = v;
   }
-  for (int i = tid; i < n; i += nt) x[i] = bvec[i];
+  for (int j = tid; j <= n; j += nt) A[tri(n, j)] = (j < n) ? bvec[j] : 0.0;
   __syncthreads();
+  PROF(0);
 
   for (int kb = 0; kb < n; kb += NB) {
     const int nb = min(NB, n - kb);
-    // (1) factor the diagonal block in registers of one lane
-    if (tid == 0) {
-      double a[NB][NB];
+    // ---- D
+    if (wave == 0) {
+      double a[NB];
 #pragma unroll
-      for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++) a[i][j] = (i < nb) ? A[tri(kb + i, kb + j)] : (i == j ? 1.0 : 0.0);
+      for (int c = 0; c < NB; c++) {
+        double v = (lane >= nb && c == lane) ? 1.0 : 0.0;  // identity rows pad a ragged last block
+        if (lane < nb && c <= lane) v = A[tri(kb + lane, kb + c)];
+        a[c] = v;
+      }
       bool bad = false;
+      diag_column<0>(a, lane, bad, invd);
+      if (lane < NB) {
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        double d = a[j][j];
-#pragma unroll
-        for (int c = 0; c < j; c++) d -= a[j][c] * a[j][c];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double s = sqrt(d);
-        const double inv = 1.0 / s;
-        a[j][j] = s;
-        invd[j] = inv;
-        if (j < nb) rdiag[kb + j] = inv;
-#pragma unroll
-        for (int i = j + 1; i < NB; i++) {
-          double t = a[i][j];
-#pragma unroll
-          for (int c = 0; c < j; c++) t -= a[i][c] * a[j][c];
-          a[i][j] = t * inv;
+        for (int c = 0; c < NB; c++) {
+          D[lane * NB + c] = (c <= lane) ? a[c] : 0.0;
+          if (lane < nb && c <= lane) A[tri(kb + lane, kb + c)] = a[c];
         }
       }
-      if (bad) *fail = 1;
-#pragma unroll
-      for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++) {
-          D[i * NB + j] = a[i][j];
-          if (i < nb) A[tri(kb + i, kb + j)] = a[i][j];
-        }
+      if (bad && lane == 0) *fail = 1;
     }
     __syncthreads();
+    PROF(1);
     const int r0 = kb + nb;  // first trailing row
-    // (2) panel: rows below solve X L11^T = A21
-    for (int i = r0 + tid; i < n; i += nt) {
+    // ---- P: rows r0..n (row n is the right-hand side)
+    for (int i = r0 + tid; i <= n; i += nt) {
       double xr[NB];
       const int base = tri(i, kb);
 #pragma unroll
       for (int j = 0; j < NB; j++) xr[j] = (j < nb) ? A[base + j] : 0.0;
+      bool nz = false;
+      // right-looking substitution: two dependent ops per column instead of a j-long chain
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        double t = xr[j];
+      for (int c = 0; c < NB; c++) {
+        xr[c] *= invd[c];
+        nz |= (xr[c] != 0.0);
 #pragma unroll
-        for (int c = 0; c < j; c++) t -= xr[c] * D[j * NB + c];
-        xr[j] = t * invd[j];
+        for (int j = c + 1; j < NB; j++) xr[j] = fma(-xr[c], D[j * NB + c], xr[j]);
       }
 #pragma unroll
       for (int j = 0; j < NB; j++)
         if (j < nb) A[base + j] = xr[j];
+      rowflag[i] = nz ? 1 : 0;
     }
+    if (tid < nb) rdiag[kb + tid] = invd[tid];
     __syncthreads();
-    // (3) trailing update A22 -= L21 L21^T : wave per row, lanes across columns
+    PROF(2);
+    // ---- U: A22 -= X X^T in 4x4 tiles over rows r0..n, columns r0..n-1
     {
-      const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-      for (int i = r0 + wave; i < n; i += nw) {
-        double li[NB];
-        const int bi = tri(i, kb);
+      const int Tn = (n1 - r0 + 3) >> 2;  // row tiles
+      const int ntiles = Tn * (Tn + 1) / 2;
+      for (int e = tid; e < ntiles; e += nt) {
+        int ti = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > e) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= e) ti++;
+        const int tj = e - ti * (ti + 1) / 2;
+        const int i0 = r0 + 4 * ti, j0 = r0 + 4 * tj;
+        int fi = 0, fj = 0;
+        int bi[4], bj[4];
 #pragma unroll
-        for (int c = 0; c < NB; c++) li[c] = (c < nb) ? A[bi + c] : 0.0;
-        for (int j = r0 + lane; j <= i; j += 64) {
-          const int bj = tri(j, kb);
-          double s = 0.0;
-#pragma unroll
-          for (int c = 0; c < NB; c++) s += li[c] * ((c < nb) ? A[bj + c] : 0.0);
-          A[tri(i, j)] -= s;
+        for (int q = 0; q < 4; q++) {
+          const int i = min(i0 + q, n), j = min(j0 + q, n);
+          fi |= rowflag[i];
+          fj |= rowflag[j];
+          bi[q] = tri(i, kb);
+          bj[q] = tri(j, kb);
         }
+        if (!(fi && fj)) continue;
+        // all 8 x 12 operands are fetched before the first FMA (16 independent chains of 12)
+        double xi[4][NB], xj[4][NB];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int c = 0; c < NB; c++) {
+            xi[q][c] = (c < nb) ? A[bi[q] + c] : 0.0;
+            xj[q][c] = (c < nb) ? A[bj[q] + c] : 0.0;
+          }
+        double acc[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; c++) t = fma(xi[p][c], xj[q][c], t);
+            acc[p][q] = t;
+          }
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = i0 + p, j = j0 + q;
+            if (i <= n && j < n && j <= i) A[tri(i, j)] -= acc[p][q];
+          }
       }
     }
     __syncthreads();
+    PROF(3);
   }
 
-  // forward substitution L y = b (blocked; the nb x nb triangle is solved in one lane's registers,
-  // multiplying by the reciprocal diagonal kept from the factorisation)
-  for (int kb = 0; kb < n; kb += NB) {
-    const int nb = min(NB, n - kb);
-    if (tid == 0) {
-      double l[NB][NB], y[NB], rd[NB];
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        y[j] = (j < nb) ? x[kb + j] : 0.0;
-        rd[j] = (j < nb) ? rdiag[kb + j] : 1.0;
-#pragma unroll
-        for (int c = 0; c < j; c++) l[j][c] = (j < nb) ? A[tri(kb + j, kb + c)] : 0.0;
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        double t = y[j];
-#pragma unroll
-        for (int c = 0; c < j; c++) t -= l[j][c] * y[c];
-        y[j] = t * rd[j];
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        if (j < nb) x[kb + j] = y[j];
-    }
-    __syncthreads();
-    for (int i = kb + nb + tid; i < n; i += nt) {
-      double t = x[i];
-      const int bi = tri(i, kb);
-      for (int c = 0; c < nb; c++) t -= A[bi + c] * x[kb + c];
-      x[i] = t;
-    }
-    __syncthreads();
-  }
-  // backward substitution L^T x = y (blocked, bottom-up)
+  // row n now holds y = L^-1 b.  Backward substitution L^T x = y, block-wise bottom-up; x overwrites row n.
+  double *x = A + tri(n, 0);
   for (int kb = ((n - 1) / NB) * NB; kb >= 0; kb -= NB) {
     const int nb = min(NB, n - kb);
-    if (tid == 0) {
-      double l[NB][NB], y[NB], rd[NB];
+    if (wave == 0) {
+      double lcol[NB];
+      const int c = min(lane, nb - 1);
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        y[j] = (j < nb) ? x[kb + j] : 0.0;
-        rd[j] = (j < nb) ? rdiag[kb + j] : 1.0;
-#pragma unroll
-        for (int c = 0; c < j; c++) l[j][c] = (j < nb) ? A[tri(kb + j, kb + c)] : 0.0;
+        double v = 0.0;
+        if (lane < nb && j > lane && j < nb) v = A[tri(kb + j, kb + c)];
+        lcol[j] = v;
       }
-#pragma unroll
-      for (int j = NB - 1; j >= 0; j--) {
-        double t = y[j];
-#pragma unroll
-        for (int c = j + 1; c < NB; c++) t -= l[c][j] * y[c];
-        y[j] = t * rd[j];
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        if (j < nb) x[kb + j] = y[j];
+      double t = (lane < nb) ? x[kb + c] : 0.0;
+      const double rd = (lane < nb) ? rdiag[kb + c] : 0.0;
+      back_column<NB - 1>(lcol, t, lane, rd);
+      if (lane < nb) x[kb + lane] = t;
     }
     __syncthreads();
+    PROF(6);
     for (int i = tid; i < kb; i += nt) {
       double t = x[i];
-      for (int c = 0; c < nb; c++) t -= A[tri(kb + c, i)] * x[kb + c];
+      for (int c = 0; c < nb; c++) t = fma(-A[tri(kb + c, i)], x[kb + c], t);
       x[i] = t;
     }
     __syncthreads();
+    PROF(7);
   }
 
   // non-finite results count as failure too; failure => zero update (:1263-1266)
@@ -204,19 +271,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
   const int failed = *fail;
   for (int i = tid; i < n; i += nt) dx[i] = failed ? 0.f : (float)x[i];
   if (tid == 0) meta[1] = failed;
+  PROF(8);
 }
+
+static size_t solve_small_bytes(int n) {
+  return ((size_t)n + NB * NB + NB) * sizeof(double) + ((size_t)n + 4) * sizeof(int) + 16;
+}
+static size_t solve_packed_bytes(int n) { return (size_t)(n + 1) * (n + 2) / 2 * sizeof(double); }
 
 bool ba_solve_fits_lds(int n) {
-  const size_t small = ((size_t)2 * n + NB * NB + NB + 2) * sizeof(double);
-  const size_t packed = (size_t)n * (n + 1) / 2 * sizeof(double);
-  return packed + small <= (size_t)SOLVE_MAX_LDS_BYTES;
+  return solve_packed_bytes(n) + solve_small_bytes(n) <= (size_t)SOLVE_MAX_LDS_BYTES;
 }
 
+size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
+
 int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream) {
+                    double *Lscratch, hipStream_t stream, long long *prof) {
   if (n <= 0) return DBA_OK;
-  const size_t small = ((size_t)2 * n + NB * NB + NB + 2) * sizeof(double);
-  const size_t packed = (size_t)n * (n + 1) / 2 * sizeof(double);
+  const size_t small = solve_small_bytes(n), packed = solve_packed_bytes(n);
   if (packed + small <= (size_t)SOLVE_MAX_LDS_BYTES) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -225,10 +297,11 @@ int launch_ba_solve(const double *H, const double *b, int n, double lm, double e
       attr_set = true;
     }
     hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), packed + small, stream, H, b, n,
-                       lm, ep, dx, meta, Lscratch);
+                       lm, ep, dx, meta, Lscratch, prof);
   } else {
+    if (!Lscratch) return DBA_ERR_WORKSPACE;
     hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), small, stream, H, b, n, lm, ep,
-                       dx, meta, Lscratch);
+                       dx, meta, Lscratch, prof);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;
