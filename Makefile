@@ -18,7 +18,7 @@ oracle:
 
 # kernels whose results must be bit-identical to the reference arithmetic: no mul+add fusion
 # (HIP's default -ffp-contract=fast fuses in the backend regardless of source pragmas)
-EXACT := corr_lookup altcorr
+EXACT := corr_lookup corr_sheared altcorr
 $(foreach f,$(EXACT),$(eval $(BUILD)/$(f).o: EXTRA := -ffp-contract=off))
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)

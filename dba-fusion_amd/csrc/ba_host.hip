@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -22,7 +23,18 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const int P = t1 - t0;
   const int HW = ht * wd;
   const int Mmax = (P + N < B) ? (P + N) : B;
-  const int nchunks = (HW + 255) / 256;
+  // pixels per lane of the linearisation: enough waves to cover the 1024 SIMDs about once; fewer, fatter
+  // waves beyond that (each wave-level reduction of the J^T W J sums is amortised over PPL pixels)
+  int ppl = 1;
+  {
+    const char *env = getenv("DBA_LINEARIZE_PPL");
+    const long waves1 = (long)Mmax * ((HW + 63) / 64);
+    if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4)) ppl = atoi(env);
+    else if (waves1 >= 4 * 1024) ppl = 4;
+    else if (waves1 >= 1536) ppl = 2;
+  }
+  const int nchunks = (HW + 256 * ppl - 1) / (256 * ppl);
+  const int nparts_max = ((HW + 255) / 256) * 4;  // workspace is sized for ppl = 1
   const int nparts = nchunks * 4;
   const int n6 = 6 * P;
   size_t off = 0;
@@ -41,7 +53,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
-  const size_t o_hpart = take(sizeof(float) * (size_t)(N > 0 ? N : 1) * nparts * HP_STRIDE);
+  const size_t o_hparte = take(sizeof(float) * (size_t)(N > 0 ? N : 1) * nparts_max * HPE_STRIDE);
+  const size_t o_hpartf = take(sizeof(float) * (size_t)(Mmax > 0 ? Mmax : 1) * nparts_max * HPF_STRIDE);
   L.dx = take(sizeof(float) * (size_t)(n6 > 0 ? n6 : 1));
   L.H = take(sizeof(double) * (size_t)(n6 > 0 ? n6 * (size_t)n6 : 1));
   L.b = take(sizeof(double) * (size_t)(n6 > 0 ? n6 : 1));
@@ -71,12 +84,14 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->W.E = reinterpret_cast<float *>(base + L.E);
     plan->W.Q = reinterpret_cast<float *>(base + L.Q);
     plan->W.w = reinterpret_cast<float *>(base + L.w);
-    plan->W.Hpart = reinterpret_cast<float *>(base + o_hpart);
+    plan->W.HpartE = reinterpret_cast<float *>(base + o_hparte);
+    plan->W.HpartF = reinterpret_cast<float *>(base + o_hpartf);
     plan->W.dx = reinterpret_cast<float *>(base + L.dx);
     plan->W.H = reinterpret_cast<double *>(base + L.H);
     plan->W.b = reinterpret_cast<double *>(base + L.b);
     plan->W.Lscratch = lds_fits ? nullptr : reinterpret_cast<double *>(base + o_lscratch);
     plan->W.nparts = nparts;
+    plan->W.ppl = ppl;
   }
   return DBA_OK;
 }
@@ -134,9 +149,14 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
   if (!poses || !disps || !intrinsics || !disps_sens || !eta || eta_rows < 1) return DBA_ERR_ARG;
   if (N > 0 && (!targets || !weights || !jj)) return DBA_ERR_ARG;
   dim3 grid(plan.nchunks, plan.T.Mmax + 1);
-  hipLaunchKernelGGL(ba_linearize_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, intrinsics,
-                     disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, plan.HW, wd, t0,
-                     plan.P, alpha, plan.T, plan.W);
+#define LAUNCH_LIN(PPL)                                                                                       \
+  hipLaunchKernelGGL(ba_linearize_kernel<PPL>, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, intrinsics, \
+                     disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, plan.HW, wd, t0, plan.P, \
+                     alpha, plan.T, plan.W)
+  if (plan.W.ppl == 4) LAUNCH_LIN(4);
+  else if (plan.W.ppl == 2) LAUNCH_LIN(2);
+  else LAUNCH_LIN(1);
+#undef LAUNCH_LIN
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -146,11 +166,17 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  const int blocks = plan.P + N + (N + 1) / 2;
-  if (blocks == 0) return DBA_OK;
-  hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,
-                     N, plan.HW, t0, plan.P, motion_only, plan.T, plan.W);
-  DBA_LAUNCH_CHECK();
+  const int ablocks = (N + 3) / 4 + (plan.T.Mmax + 7) / 8;
+  if (ablocks > 0 && plan.P > 0) {
+    hipLaunchKernelGGL(ba_assemble_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,
+                       N, t0, plan.P, plan.T, plan.W);
+    DBA_LAUNCH_CHECK();
+  }
+  if (!motion_only && plan.P + N > 0 && plan.P > 0) {
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N, SCHUR_KP, SCHUR_CH), dim3(256), 0, (hipStream_t)stream,
+                       ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
+    DBA_LAUNCH_CHECK();
+  }
   return DBA_OK;
 }
 
@@ -170,7 +196,7 @@ int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  dim3 grid(plan.nchunks, plan.T.Mmax + 1);
+  dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1);
   hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, jj, frame_owned,
                      plan.HW, t0, plan.P, update_poses, update_disps, dz_out, plan.T, plan.W);
   DBA_LAUNCH_CHECK();

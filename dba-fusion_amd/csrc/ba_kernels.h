@@ -4,7 +4,10 @@
 
 namespace dba {
 
-constexpr int HP_STRIDE = 96;  // floats per per-wave J^T W J partial (90 used)
+constexpr int HPE_STRIDE = 64;  // floats per per-wave, per-edge partial (63 used: Hji, Hjj, vj)
+constexpr int HPF_STRIDE = 32;  // floats per per-wave, per-frame partial (27 used: Hii, vi)
+constexpr int SCHUR_KP = 8;     // partner slots of the Schur grid
+constexpr int SCHUR_CH = 2;     // pixel chunks of the Schur grid
 
 // device index tables (all int32, inside the workspace)
 struct BaTables {
@@ -20,12 +23,14 @@ struct BaBuffers {
   float *E;      // [(P+N), 6, HW]  rows 0..P-1 = Ei (pose i of frame t0+p), rows P+n = Eij of edge n
   float *Q;      // [Mmax, HW]      1 / C
   float *w;      // [Mmax, HW]
-  float *Hpart;  // [N, nparts, HP_STRIDE]
+  float *HpartE; // [N, nparts, HPE_STRIDE]
+  float *HpartF; // [Mmax, nparts, HPF_STRIDE]
   double *H;     // [6P, 6P]
   double *b;     // [6P]
   float *dx;     // [P, 6]
   double *Lscratch;  // packed lower triangle for systems too large for LDS
-  int nparts;    // pixel slices (waves) per frame
+  int nparts;    // pixel slices (waves) per frame for the chosen pixels-per-lane
+  int ppl;       // pixels per lane of the linearisation kernel (1, 2 or 4)
 };
 
 struct BaPlan {  // host-side view of the workspace
@@ -41,13 +46,16 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
 // kernels (ba_kernels.hip / ba_solve.hip)
 __global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1,
                                   BaTables T);
+template <int PPL>
 __global__ void ba_linearize_kernel(const float *poses, const float *disps, const float *intrinsics,
                                     const float *disps_sens, const float *targets, const float *weights,
                                     const float *eta, int eta_rows, const int64_t *jj,
                                     const uint8_t *frame_owned, int N, int HW, int wd, int t0, int P,
                                     float alpha, BaTables T, BaBuffers W);
-__global__ void ba_reduce_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
-                                 int HW, int t0, int P, int motion_only, BaTables T, BaBuffers W);
+__global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
+                                   int t0, int P, BaTables T, BaBuffers W);
+__global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
+                                int t0, int P, BaTables T, BaBuffers W);
 __global__ void ba_update_kernel(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned,
                                  int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
                                  BaTables T, BaBuffers W);

