@@ -156,7 +156,7 @@ def main():
                                    "reproject + 4-level r=3 lookup + ba(itrs=2) per step",
                        "keyframes": 25, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world},
             "roofline": {
-                "kernel": "corr_lookup_kernel<f16,r=3> (fused 4-level lookup, %d edges on rank 0)" % n_loc,
+                "kernel": "corr_lookup_sheared_kernel<3> (fused 4-level r=3 lookup, f16, %d edges on rank 0)" % n_loc,
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
                 "peak": HBM_PEAK_GBS,
@@ -192,7 +192,9 @@ def cpu_baseline(W, corr, fmaps, ii, jj, sample_edges=8):
     coords, _ = orc.reproject(W.poses, W.disps, W.intrinsics, W.ii, W.jj, np.float32)
     t_rep = time.perf_counter() - t0
     ne = min(sample_edges, W.N)
-    pyr = [p[:ne].cpu().numpy() for p in corr.corr_pyramid]
+    from dbaf_amd.corr import CorrBlock
+    # reference-layout volumes of the sample edges, built on the device and copied to the host
+    pyr = [p.cpu().numpy() for p in CorrBlock.build_pyramid(fmaps[ii[:ne]][None], fmaps[jj[:ne]][None], 4)]
     t0 = time.perf_counter()
     reps = 0
     while reps < 2 or (time.perf_counter() - t0 < 6.0 and reps < 20):

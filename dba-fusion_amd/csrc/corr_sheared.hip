@@ -23,7 +23,7 @@
 namespace dba {
 
 constexpr int SH_MAX_LEVELS = 8;
-constexpr int SH_CAP = 160;  // plane-rows (128 B each) a wave may stage in LDS: 20 KB
+constexpr int SH_CAP = 112;  // plane-rows (128 B each) a wave may stage in LDS: 14 KB -> 11 waves per CU
 
 struct ShLevels {
   const _Float16 *vol[SH_MAX_LEVELS];
@@ -114,32 +114,57 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
   const int nx = any ? (bx1 - bx0 + WN) : 0, ny = any ? (by1 - by0 + WN) : 0;
   const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1;
 
-  float win[WN][WN];
+  _Float16 win[WN][WN];
   const bool staged = any && (nx * ny <= SH_CAP) && ((w1 & 7) == 0) && (xt * 64 + 64 <= w1);
   if (staged) {
-    // 8 lanes x 16 B fetch one 128-byte plane-row; 8 plane-rows per wave-instruction
+    // 8 lanes x 16 B fetch one 128-byte plane-row; 8 plane-rows per wave-instruction.  Elements whose
+    // target pixel is out of bounds are zeroed HERE (a contiguous run of x1 per plane-row), so the 64 tap
+    // reads per lane below need no bounds logic at all.
     const int sub = lane & 7, rsel = lane >> 3;
+    const int xs = xt * 64 + sub * 8;  // first x1 of this lane's 8 elements
+    // (nx >= 8, so the 8 row selectors start in plane-row 0 and each step wraps at most once)
+    int jy = 0, jx = rsel;
+    int dym = by0 % h2l, dxm = (bx0 + jx) % w2l;
+    dym += (dym < 0) ? h2l : 0;
+    dxm += (dxm < 0) ? w2l : 0;
+    const unsigned HWu = (unsigned)HW1;
     for (int r = rsel; r < nx * ny; r += 8) {
-      const int jy = r / nx, jx = r - jy * nx;
-      int dym = (by0 + jy) % h2l, dxm = (bx0 + jx) % w2l;
-      dym += (dym < 0) ? h2l : 0;
-      dxm += (dxm < 0) ? w2l : 0;
-      const Half8v v = *reinterpret_cast<const Half8v *>(vol + ((size_t)dym * w2l + dxm) * HW1 + xt * 64 + sub * 8);
+      const int dyv = by0 + jy, dxv = bx0 + jx;
+      const unsigned off = ((unsigned)dym * (unsigned)w2l + (unsigned)dxm) * HWu + (unsigned)xs;  // < 2^32 per edge
+      Half8v v = *reinterpret_cast<const Half8v *>(vol + off);
+      const int ty = sy + dyv;
+      // valid q: 0 <= ((xs + q) >> lvl) + dxv < w2l  <=>  qa <= q < qb
+      const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
+      const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
+      int qa = max(0, lo - xs), qb = min(8, hi - xs);
+      if (ty < 0 || ty >= h2l) qb = 0;
+      if (qa > 0 || qb < 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < qa || q >= qb) v.v[q] = (_Float16)0.f;
+      }
       *reinterpret_cast<Half8v *>(&stage[r * 64 + sub * 8]) = v;
+      jx += 8;
+      dxm += 8;
+      if (jx >= nx) {  // next plane-row
+        jx -= nx;
+        jy++;
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+        dxm = (bx0 + jx) % w2l;
+        dxm += (dxm < 0) ? w2l : 0;
+      } else {
+        while (dxm >= w2l) dxm -= w2l;
+      }
     }
     __syncthreads();  // single wave: just the LDS write -> read ordering
-    const int rx = ox - bx0, ry = oy - by0;
+    // lanes that touch nothing read row 0 (their weights are zero and their outputs are forced to zero)
+    const int rx = touches ? ox - bx0 : 0, ry = touches ? oy - by0 : 0;
+    const _Float16 *tp = stage + (ry * nx + rx) * 64 + lane;
+    const int rstride = nx * 64;
 #pragma unroll
     for (int j = 0; j < WN; j++) {
-      const int ty = iy0 + j;
-      const bool rok = touches && (ty >= 0) && (ty < h2l);
 #pragma unroll
-      for (int i = 0; i < WN; i++) {
-        const int tx = ix0 + i;
-        const bool ok = rok && (tx >= 0) && (tx < w2l);
-        const int r = (ry + j) * nx + (rx + i);
-        win[j][i] = ok ? (float)stage[r * 64 + lane] : 0.f;
-      }
+      for (int i = 0; i < WN; i++) win[j][i] = tp[j * rstride + i * 64];
     }
   } else {
     // incoherent flow (or ragged width): gather straight from the sheared volume
@@ -155,30 +180,30 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
         const bool ok = rok && (tx >= 0) && (tx < w2l);
         int dxm = (ox + i) % w2l;
         dxm += (dxm < 0) ? w2l : 0;
-        win[j][i] = ok ? (float)vol[((size_t)dym * w2l + dxm) * HW1 + x1] : 0.f;
+        win[j][i] = ok ? vol[((size_t)dym * w2l + dxm) * HW1 + x1] : (_Float16)0.f;
       }
     }
   }
   if (!active) return;
 
-  // scalar_t(dx * dy): f32 product rounded to half (see corr_lookup.hip)
+  // scalar_t(dx * dy): f32 product rounded to half (see corr_lookup.hip).
   float w00 = (1.0f - dx) * (1.0f - dy), w01 = (1.0f - dx) * dy, w10 = dx * (1.0f - dy), w11 = dx * dy;
   if (!touches) w00 = w01 = w10 = w11 = 0.f;  // nothing in bounds (incl. NaN / inf coords): exact zeros
   asm volatile("" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11));
-  w00 = (float)(_Float16)w00;
-  w01 = (float)(_Float16)w01;
-  w10 = (float)(_Float16)w10;
-  w11 = (float)(_Float16)w11;
+  const _Float16 h00 = (_Float16)w00, h01 = (_Float16)w01, h10 = (_Float16)w10, h11 = (_Float16)w11;
+  // c10::Half `a * b` / `a + b` compute in float and round to half; for two halves that is exactly the
+  // IEEE half operation (the float product is exact; a float sum rounded to half cannot double-round because
+  // 24 >= 2*11 + 2), so native v_mul_f16 / v_add_f16 are bit-identical.  No fusion: -ffp-contract=off.
   _Float16 *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + (size_t)y1 * w1 + x1;
 #pragma unroll
   for (int a = 0; a < RD; a++) {
 #pragma unroll
     for (int b = 0; b < RD; b++) {
-      float acc = (float)(_Float16)(win[b][a] * w00);
-      acc = (float)(_Float16)(acc + (float)(_Float16)(win[b + 1][a] * w01));
-      acc = (float)(_Float16)(acc + (float)(_Float16)(win[b][a + 1] * w10));
-      acc = (float)(_Float16)(acc + (float)(_Float16)(win[b + 1][a + 1] * w11));
-      o[(size_t)(a * RD + b) * HW1] = (_Float16)acc;
+      _Float16 acc = win[b][a] * h00;
+      acc = acc + win[b + 1][a] * h01;
+      acc = acc + win[b][a + 1] * h10;
+      acc = acc + win[b + 1][a + 1] * h11;
+      o[(size_t)(a * RD + b) * HW1] = touches ? acc : (_Float16)0.f;
     }
   }
 }
