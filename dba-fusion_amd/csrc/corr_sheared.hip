@@ -23,7 +23,6 @@
 namespace dba {
 
 constexpr int SH_MAX_LEVELS = 8;
-constexpr int SH_CAP = 112;  // plane-rows (128 B each) a wave may stage in LDS: 14 KB -> 11 waves per CU
 
 struct ShLevels {
   const _Float16 *vol[SH_MAX_LEVELS];
@@ -75,13 +74,24 @@ struct __attribute__((aligned(16))) Half8v {
   _Float16 v[8];
 };
 
-// one wave per workgroup; wave = 64 consecutive x1 of one source row, one pyramid level
+// one wave per workgroup; wave = 64 consecutive x1 of one source row, one pyramid level.
+//
+// Streaming form: the wave walks the plane-rows dy = by0 .. by1+7 of the union window one at a time.  Step jy
+// brings the nx (<= SH_NX) 128-byte lines (dy, bx0 .. bx0+nx-1) into a 2 KB LDS row (16-B loads issued one step
+// ahead, so they are in flight while the previous row is consumed); a lane whose own window starts ry rows
+// into the union reads its 8 taps of tap-row j = jy - ry, combines them with the previous tap-row it kept in
+// registers, and emits the 7 outputs (a, b = j-1).  LDS per wave is 2 KB, so occupancy is bounded by registers
+// (8 waves/SIMD), not by staging space.
+constexpr int SH_NX = 16;   // plane-rows per step held in LDS (union width in x: 8 + spread <= 16)
+constexpr int SH_NY = 72;   // longest union in y walked by the streaming path
+
 template <int R>
 __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, const float2 *__restrict__ coords,
                                                                  _Float16 *__restrict__ out, int n, int h1,
                                                                  int w1, int h2, int w2, int num_levels) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
-  __shared__ __attribute__((aligned(16))) _Float16 stage[SH_CAP * 64];
+  static_assert(WN == 8, "the streaming lookup is written for radius 3");
+  __shared__ __attribute__((aligned(16))) _Float16 stage[SH_NX * 64];
   const int lane = threadIdx.x;
   const int xtiles = (w1 + 63) / 64;
   const int xt = blockIdx.x % xtiles;
@@ -114,78 +124,6 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
   const int nx = any ? (bx1 - bx0 + WN) : 0, ny = any ? (by1 - by0 + WN) : 0;
   const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1;
 
-  _Float16 win[WN][WN];
-  const bool staged = any && (nx * ny <= SH_CAP) && ((w1 & 7) == 0) && (xt * 64 + 64 <= w1);
-  if (staged) {
-    // 8 lanes x 16 B fetch one 128-byte plane-row; 8 plane-rows per wave-instruction.  Elements whose
-    // target pixel is out of bounds are zeroed HERE (a contiguous run of x1 per plane-row), so the 64 tap
-    // reads per lane below need no bounds logic at all.
-    const int sub = lane & 7, rsel = lane >> 3;
-    const int xs = xt * 64 + sub * 8;  // first x1 of this lane's 8 elements
-    // (nx >= 8, so the 8 row selectors start in plane-row 0 and each step wraps at most once)
-    int jy = 0, jx = rsel;
-    int dym = by0 % h2l, dxm = (bx0 + jx) % w2l;
-    dym += (dym < 0) ? h2l : 0;
-    dxm += (dxm < 0) ? w2l : 0;
-    const unsigned HWu = (unsigned)HW1;
-    for (int r = rsel; r < nx * ny; r += 8) {
-      const int dyv = by0 + jy, dxv = bx0 + jx;
-      const unsigned off = ((unsigned)dym * (unsigned)w2l + (unsigned)dxm) * HWu + (unsigned)xs;  // < 2^32 per edge
-      Half8v v = *reinterpret_cast<const Half8v *>(vol + off);
-      const int ty = sy + dyv;
-      // valid q: 0 <= ((xs + q) >> lvl) + dxv < w2l  <=>  qa <= q < qb
-      const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
-      const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
-      int qa = max(0, lo - xs), qb = min(8, hi - xs);
-      if (ty < 0 || ty >= h2l) qb = 0;
-      if (qa > 0 || qb < 8) {
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (q < qa || q >= qb) v.v[q] = (_Float16)0.f;
-      }
-      *reinterpret_cast<Half8v *>(&stage[r * 64 + sub * 8]) = v;
-      jx += 8;
-      dxm += 8;
-      if (jx >= nx) {  // next plane-row
-        jx -= nx;
-        jy++;
-        dym = (dym + 1 == h2l) ? 0 : dym + 1;
-        dxm = (bx0 + jx) % w2l;
-        dxm += (dxm < 0) ? w2l : 0;
-      } else {
-        while (dxm >= w2l) dxm -= w2l;
-      }
-    }
-    __syncthreads();  // single wave: just the LDS write -> read ordering
-    // lanes that touch nothing read row 0 (their weights are zero and their outputs are forced to zero)
-    const int rx = touches ? ox - bx0 : 0, ry = touches ? oy - by0 : 0;
-    const _Float16 *tp = stage + (ry * nx + rx) * 64 + lane;
-    const int rstride = nx * 64;
-#pragma unroll
-    for (int j = 0; j < WN; j++) {
-#pragma unroll
-      for (int i = 0; i < WN; i++) win[j][i] = tp[j * rstride + i * 64];
-    }
-  } else {
-    // incoherent flow (or ragged width): gather straight from the sheared volume
-#pragma unroll
-    for (int j = 0; j < WN; j++) {
-      const int ty = iy0 + j;
-      const bool rok = touches && (ty >= 0) && (ty < h2l);
-      int dym = (oy + j) % h2l;
-      dym += (dym < 0) ? h2l : 0;
-#pragma unroll
-      for (int i = 0; i < WN; i++) {
-        const int tx = ix0 + i;
-        const bool ok = rok && (tx >= 0) && (tx < w2l);
-        int dxm = (ox + i) % w2l;
-        dxm += (dxm < 0) ? w2l : 0;
-        win[j][i] = ok ? vol[((size_t)dym * w2l + dxm) * HW1 + x1] : (_Float16)0.f;
-      }
-    }
-  }
-  if (!active) return;
-
   // scalar_t(dx * dy): f32 product rounded to half (see corr_lookup.hip).
   float w00 = (1.0f - dx) * (1.0f - dy), w01 = (1.0f - dx) * dy, w10 = dx * (1.0f - dy), w11 = dx * dy;
   if (!touches) w00 = w01 = w10 = w11 = 0.f;  // nothing in bounds (incl. NaN / inf coords): exact zeros
@@ -195,6 +133,126 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
   // IEEE half operation (the float product is exact; a float sum rounded to half cannot double-round because
   // 24 >= 2*11 + 2), so native v_mul_f16 / v_add_f16 are bit-identical.  No fusion: -ffp-contract=off.
   _Float16 *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + (size_t)y1 * w1 + x1;
+
+  if (!any) {  // the whole wave is out of bounds
+    if (active) {
+#pragma unroll
+      for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
+    }
+    return;
+  }
+
+  const bool stream = (nx <= SH_NX) && (ny <= SH_NY) && ((w1 & 7) == 0) && (xt * 64 + 64 <= w1);
+  if (stream) {
+    // staging slots: lane + 64 t -> plane-row jx = slot >> 3, 16-byte piece sub = slot & 7 (fixed for all steps)
+    int dxm[2], qa[2], qb[2], ldsoff[2];
+    unsigned goff[2];
+    bool act[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int slot = lane + 64 * t;
+      const int jx = slot >> 3, sub = slot & 7;
+      act[t] = jx < nx;
+      const int dxv = bx0 + jx;
+      int m = dxv % w2l;
+      m += (m < 0) ? w2l : 0;
+      dxm[t] = m;
+      const int xs = xt * 64 + sub * 8;  // first x1 of this piece
+      // valid q: 0 <= ((xs + q) >> lvl) + dxv < w2l  <=>  qa <= q < qb
+      const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
+      const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
+      qa[t] = max(0, lo - xs);
+      qb[t] = min(8, hi - xs);
+      goff[t] = (unsigned)m * (unsigned)HW1 + (unsigned)xs;
+      ldsoff[t] = jx * 64 + sub * 8;
+    }
+    int dym = by0 % h2l;
+    dym += (dym < 0) ? h2l : 0;
+    const unsigned rowstride = (unsigned)w2l * (unsigned)HW1;  // elements between consecutive dy (< 2^32 per edge)
+
+    Half8v regs[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+      if (act[t]) regs[t] = *reinterpret_cast<const Half8v *>(vol + ((unsigned)dym * rowstride + goff[t]));
+
+    const int rx = touches ? ox - bx0 : 0, ry = touches ? oy - by0 : 0;
+    const _Float16 *tp = stage + rx * 64 + lane;
+    _Float16 prev[WN];
+#pragma unroll
+    for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
+
+    for (int jy = 0; jy < ny; jy++) {
+      const int ty = sy + by0 + jy;
+      const bool rowok = (ty >= 0) && (ty < h2l);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        if (act[t]) {
+          Half8v v = regs[t];
+          const int a_ = rowok ? qa[t] : 8, b_ = rowok ? qb[t] : 0;
+          if (a_ > 0 || b_ < 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (q < a_ || q >= b_) v.v[q] = (_Float16)0.f;
+          }
+          *reinterpret_cast<Half8v *>(&stage[ldsoff[t]]) = v;
+        }
+      }
+      dym = (dym + 1 == h2l) ? 0 : dym + 1;
+#ifndef SH_ABLATE_LOADS
+      if (jy + 1 < ny) {  // next plane-row's lines fly while this one is consumed
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+          if (act[t]) regs[t] = *reinterpret_cast<const Half8v *>(vol + ((unsigned)dym * rowstride + goff[t]));
+      }
+#endif
+      __syncthreads();  // one wave: orders the LDS row write before the tap reads
+      const int j = jy - ry;
+      if (j >= 0 && j < WN) {
+        _Float16 cur[WN];
+#pragma unroll
+        for (int i = 0; i < WN; i++) cur[i] = tp[i * 64];
+        if (j >= 1 && active) {
+          _Float16 *ob = o + (size_t)(j - 1) * HW1;
+#pragma unroll
+          for (int a = 0; a < RD; a++) {
+            // tap(a,b)*w00, tap(a,b+1)*w01, tap(a+1,b)*w10, tap(a+1,b+1)*w11 (correlation_kernels.cu:55-65)
+            _Float16 acc = prev[a] * h00;
+            acc = acc + cur[a] * h01;
+            acc = acc + prev[a + 1] * h10;
+            acc = acc + cur[a + 1] * h11;
+#ifdef SH_ABLATE_STORES  // ablation builds only (scratch/): keep the value live, store one channel
+            if (a == 0 && j == 1) ob[0] = acc; else asm volatile("" ::"v"(acc));
+#else
+            ob[(size_t)(a * RD) * HW1] = touches ? acc : (_Float16)0.f;
+#endif
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WN; i++) prev[i] = cur[i];
+      }
+      __syncthreads();  // tap reads done before the next row overwrites the LDS line buffer
+    }
+    return;
+  }
+
+  // incoherent flow (or ragged width): gather straight from the sheared volume
+  _Float16 win[WN][WN];
+#pragma unroll
+  for (int j = 0; j < WN; j++) {
+    const int ty = iy0 + j;
+    const bool rok = touches && (ty >= 0) && (ty < h2l);
+    int dym = (oy + j) % h2l;
+    dym += (dym < 0) ? h2l : 0;
+#pragma unroll
+    for (int i = 0; i < WN; i++) {
+      const int tx = ix0 + i;
+      const bool ok = rok && (tx >= 0) && (tx < w2l);
+      int dxm = (ox + i) % w2l;
+      dxm += (dxm < 0) ? w2l : 0;
+      win[j][i] = ok ? vol[((size_t)dym * w2l + dxm) * HW1 + x1] : (_Float16)0.f;
+    }
+  }
+  if (!active) return;
 #pragma unroll
   for (int a = 0; a < RD; a++) {
 #pragma unroll
