@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window", default="25_96", choices=["25_96", "32_122", "64_512"],
+                    help="synthetic window (default = BASELINE.json configs[1]; the others are for profiling)")
     args = ap.parse_args()
 
     from dbaf_amd import synthetic as syn
@@ -70,7 +72,7 @@ def main():
     _lib.load()
 
     # ---- workload: 25 KF / 96 edges / 64x64 (synthetic) --------------------------------
-    W = syn.window_25_96(args.seed)
+    W = {"25_96": syn.window_25_96, "32_122": syn.window_32_122, "64_512": syn.window_64_512}[args.window](args.seed)
     h, w, HW, N = W.h, W.w, W.h * W.w, W.N
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     poses0, disps0 = t(W.poses), t(W.disps)
@@ -138,6 +140,8 @@ def main():
         ms_per_step = 1e3 * dt / max(args.steps, 1)
         value = args.steps / dt
         alg_bytes = lookup_algorithmic_bytes(n_loc, HW)
+        if args.window != "25_96":
+            args.no_cpu_baseline = True
         achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
         out = {
             "metric": "DBA iterations/sec (25-KF, 96-edge, 512x512) [dba_update/s]",
@@ -152,9 +156,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
-            "config": {"workload": "TUM-VI-shape 512x512 -> 64x64 maps, 25-KF window, 96 edges, "
-                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step",
-                       "keyframes": 25, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world},
+            "config": {"workload": "synthetic TUM-VI-shape 512x512 -> %dx%d maps, %d-KF window, %d edges, "
+                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step" % (h, w, W.num_kf, N),
+                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world},
             "roofline": {
                 "kernel": "corr_lookup_sheared_kernel<3> (fused 4-level r=3 lookup, f16, %d edges on rank 0)" % n_loc,
                 "bound": "hbm",
@@ -167,6 +171,13 @@ def main():
                 "avg_launch_ms": round(lookup_ms, 5) if lookup_ms == lookup_ms else None,
             },
         }
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_lookup.json")
+        if os.path.exists(pmc) and world == 1 and args.window == "25_96":
+            # HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
+            # (FETCH_SIZE/WRITE_SIZE with the gfx950 corrections, see profiles/README.md); not re-measured here
+            with open(pmc) as fh:
+                out["roofline"]["traffic"] = int(json.load(fh)["traffic_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_lookup.json"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, corr, fmaps, ii, jj)
         print(json.dumps(out))

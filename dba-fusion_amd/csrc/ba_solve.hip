@@ -13,8 +13,9 @@
 //      sqrt sequences on the critical path);
 //   P  panel: one row per lane solves X L11^T = A21; the augmented row (the rhs) rides along, which is the
 //      forward substitution L y = b for free;
-//   U  trailing update A22 -= X X^T in 4x4 register tiles, skipping tiles whose panel rows are exactly
-//      zero (the reduced camera matrix of a sliding window is block-banded, so most tiles are skipped).
+//   U  trailing update A22 -= X X^T on the f64 matrix cores (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave
+//      at a time), skipping tiles whose panel rows are exactly zero (the reduced camera matrix of a sliding
+//      window is block-banded, so most tiles are skipped).
 // The backward substitution L^T x = y runs block-wise with the 12x12 triangle solved across lanes.
 #include "ba_kernels.h"
 
@@ -39,6 +40,8 @@ constexpr int NB = 12;
 constexpr int SOLVE_THREADS = 512;  // 2 waves/SIMD: 256 VGPRs, enough to hoist a whole 4x4 tile's operands
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
+
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int LANE>
 __device__ __forceinline__ double readlane_f64(double v) {
@@ -180,53 +183,44 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
     if (tid < nb) rdiag[kb + tid] = invd[tid];
     __syncthreads();
     PROF(2);
-    // ---- U: A22 -= X X^T in 4x4 tiles over rows r0..n, columns r0..n-1
+    // ---- U: A22 -= X X^T on the f64 matrix cores: 16x16 tiles over rows r0..n, columns r0..n-1, one
+    // v_mfma_f64_16x16x4_f64 per 4 panel columns (A = -X rows, B = X rows; C/D row = (lane>>4) + 4 reg,
+    // col = lane & 15).  Tiles whose panel rows or columns are exactly zero are skipped.
     {
-      const int Tn = (n1 - r0 + 3) >> 2;  // row tiles
+      const int Tn = (n1 - r0 + 15) >> 4;  // row tiles (the last one may hang over the rhs row)
       const int ntiles = Tn * (Tn + 1) / 2;
-      for (int e = tid; e < ntiles; e += nt) {
+      const int nw = nt >> 6;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int e = wave; e < ntiles; e += nw) {
         int ti = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (ti * (ti + 1) / 2 > e) ti--;
         while ((ti + 1) * (ti + 2) / 2 <= e) ti++;
         const int tj = e - ti * (ti + 1) / 2;
-        const int i0 = r0 + 4 * ti, j0 = r0 + 4 * tj;
-        int fi = 0, fj = 0;
-        int bi[4], bj[4];
+        const int i0 = r0 + 16 * ti, j0 = r0 + 16 * tj;
+        // per-lane operand rows (clamped; rows past the rhs row contribute zeros)
+        const int ia = i0 + li, jb = j0 + li;
+        const bool va = ia <= n, vb = jb <= n;
+        const int fa = va ? rowflag[ia] : 0, fb = vb ? rowflag[jb] : 0;
+        if (!(__any(fa) && __any(fb))) continue;  // wave-uniform
+        const int ba = tri(min(ia, n), kb), bb = tri(min(jb, n), kb);
+        d4 acc;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int i = min(i0 + q, n), j = min(j0 + q, n);
-          fi |= rowflag[i];
-          fj |= rowflag[j];
-          bi[q] = tri(i, kb);
-          bj[q] = tri(j, kb);
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + lk + 4 * r, j = j0 + li;
+          acc[r] = (i <= n && j < n && j <= i) ? A[tri(i, j)] : 0.0;
         }
-        if (!(fi && fj)) continue;
-        // all 8 x 12 operands are fetched before the first FMA (16 independent chains of 12)
-        double xi[4][NB], xj[4][NB];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int c0 = 0; c0 < NB; c0 += 4) {
+          const int c = c0 + lk;
+          const double xa = (va && c < nb) ? -A[ba + c] : 0.0;
+          const double xb = (vb && c < nb) ? A[bb + c] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, acc, 0, 0, 0);
+        }
 #pragma unroll
-          for (int c = 0; c < NB; c++) {
-            xi[q][c] = (c < nb) ? A[bi[q] + c] : 0.0;
-            xj[q][c] = (c < nb) ? A[bj[q] + c] : 0.0;
-          }
-        double acc[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            double t = 0.0;
-#pragma unroll
-            for (int c = 0; c < NB; c++) t = fma(xi[p][c], xj[q][c], t);
-            acc[p][q] = t;
-          }
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int i = i0 + p, j = j0 + q;
-            if (i <= n && j < n && j <= i) A[tri(i, j)] -= acc[p][q];
-          }
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + lk + 4 * r, j = j0 + li;
+          if (i <= n && j < n && j <= i) A[tri(i, j)] = acc[r];
+        }
       }
     }
     __syncthreads();

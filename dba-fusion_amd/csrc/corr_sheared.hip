@@ -117,9 +117,26 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
   const int sx = min(x1, w1 - 1) >> lvl, sy = y1 >> lvl;
   const int ox = ix0 - sx, oy = iy0 - sy;  // window origin relative to the shear
 
+  // Lanes whose window origin lies within +-4 of a reference lane's stream together (union <= 16 lines
+  // wide); the others ("outliers": flow discontinuities, pixels thrown far away) gather their taps one by
+  // one afterwards, so a single incoherent pixel does not push the whole wave onto the slow path.
+  const unsigned long long tmask = __ballot(touches);
+  int refx = 0, refy = 0;
+  if (tmask) {
+    const int first = __ffsll((long long)tmask) - 1, last = 63 - __clzll((long long)tmask);
+    const int fxo = __shfl(ox, first, 64), fyo = __shfl(oy, first, 64);
+    const int lxo = __shfl(ox, last, 64), lyo = __shfl(oy, last, 64);
+    const bool nearf = touches && (abs(ox - fxo) <= 4) && (abs(oy - fyo) <= 4);
+    const bool nearl = touches && (abs(ox - lxo) <= 4) && (abs(oy - lyo) <= 4);
+    const bool usef = __popcll(__ballot(nearf)) >= __popcll(__ballot(nearl));
+    refx = usef ? fxo : lxo;
+    refy = usef ? fyo : lyo;
+  }
+  const bool inlier = touches && (abs(ox - refx) <= 4) && (abs(oy - refy) <= 4);
+  const bool outlier = touches && !inlier;
   const int big = 1 << 28;
-  const int bx0 = wave_min_i32(touches ? ox : big), bx1 = wave_max_i32(touches ? ox : -big);
-  const int by0 = wave_min_i32(touches ? oy : big), by1 = wave_max_i32(touches ? oy : -big);
+  const int bx0 = wave_min_i32(inlier ? ox : big), bx1 = wave_max_i32(inlier ? ox : -big);
+  const int by0 = wave_min_i32(inlier ? oy : big), by1 = wave_max_i32(inlier ? oy : -big);
   const bool any = bx1 >= bx0;
   const int nx = any ? (bx1 - bx0 + WN) : 0, ny = any ? (by1 - by0 + WN) : 0;
   const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1;
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
   // 24 >= 2*11 + 2), so native v_mul_f16 / v_add_f16 are bit-identical.  No fusion: -ffp-contract=off.
   _Float16 *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + (size_t)y1 * w1 + x1;
 
-  if (!any) {  // the whole wave is out of bounds
+  if (!tmask) {  // the whole wave is out of bounds
     if (active) {
 #pragma unroll
       for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
     for (int t = 0; t < 2; t++)
       if (act[t]) regs[t] = *reinterpret_cast<const Half8v *>(vol + ((unsigned)dym * rowstride + goff[t]));
 
-    const int rx = touches ? ox - bx0 : 0, ry = touches ? oy - by0 : 0;
+    const int rx = inlier ? ox - bx0 : 0, ry = inlier ? oy - by0 : 0;
     const _Float16 *tp = stage + rx * 64 + lane;
     _Float16 prev[WN];
 #pragma unroll
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
         _Float16 cur[WN];
 #pragma unroll
         for (int i = 0; i < WN; i++) cur[i] = tp[i * 64];
-        if (j >= 1 && active) {
+        if (j >= 1 && active && !outlier) {
           _Float16 *ob = o + (size_t)(j - 1) * HW1;
 #pragma unroll
           for (int a = 0; a < RD; a++) {
@@ -232,10 +249,11 @@ __global__ __launch_bounds__(64) void corr_lookup_sheared_kernel(ShLevels L, con
       }
       __syncthreads();  // tap reads done before the next row overwrites the LDS line buffer
     }
-    return;
+    if (!outlier) return;
   }
 
-  // incoherent flow (or ragged width): gather straight from the sheared volume
+  // outliers of a streaming wave, or every lane of a wave that could not stream (ragged width):
+  // gather straight from the sheared volume
   _Float16 win[WN][WN];
 #pragma unroll
   for (int j = 0; j < WN; j++) {

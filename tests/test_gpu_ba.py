@@ -32,6 +32,8 @@ WINDOWS = {
     "kitti_shape_8kf": lambda: syn.make_window(*syn.graph_banded(8, 2), 8, 28, 107, seed=13,
                                                intr=(69.0, 69.5, 53.2, 14.1)),
     "25kf_96edges_64x64": lambda: syn.window_25_96(0),
+    "kitti360_32kf_122edges_28x107": lambda: syn.window_32_122(0),
+    "64kf_512edges_64x64": lambda: syn.window_64_512(0),  # n = 378: solver runs from the global scratch
 }
 
 
@@ -50,6 +52,24 @@ def test_ba_matches_oracle(name):
     print(name, "vs fp64 arbiter:", check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
                                                 ref32_disps=clamp(r32["disps"])))
     np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
+
+
+def test_ba_full_size_properties_64kf():
+    """BASELINE.json configs[3] size (64 KF / 512 edges / 64x64), size-independent properties:
+    (i) a noise-free window is a fixed point; (ii) Gauss-Newton contracts towards the ground truth;
+    (iii) the run is reproducible (f64 atomics only reorder sums at the 1e-16 level)."""
+    ii, jj = syn.graph_64_512()
+    W0 = syn.make_window(ii, jj, 64, 64, 64, seed=3, pose_noise=0.0, disp_noise=0.0, target_noise=0.0)
+    poses, disps, dx, dz = _run_gpu_ba(W0)
+    assert np.abs(dx).max() < 5e-5 and np.abs(poses - W0.poses).max() < 5e-5
+    W = syn.make_window(ii, jj, 64, 64, 64, seed=3, pose_noise=0.01, disp_noise=0.05, target_noise=0.0)
+    e0p = np.abs(W.poses - W.poses_gt)[:64].max()
+    e0d = np.abs(W.disps - W.disps_gt)[:64].mean()
+    p1, d1, _, _ = _run_gpu_ba(W, itrs=4)
+    p2, d2, _, _ = _run_gpu_ba(W, itrs=4)
+    assert np.abs(p1 - W.poses_gt)[:64].max() < 0.2 * e0p
+    assert np.abs(d1 - W.disps_gt)[:64].mean() < 0.2 * e0d
+    assert np.abs(p1 - p2).max() < 1e-6 and np.abs(d1 - d2).max() < 1e-4
 
 
 def test_ba_single_iteration_and_dz():
