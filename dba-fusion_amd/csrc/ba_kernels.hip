@@ -387,9 +387,13 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
       }
 
       float acc = 0.f;
+#ifndef LIN_ABLATE_REDUCE  // ablation builds only (scratch/)
       HjiLoop<PPL, 0, 0>::run(L, acc);
       HjjLoop<PPL, 0, 0>::run(L, acc);
       VjLoop<PPL, 0>::run(L, acc);
+#else
+      acc = L[0].Ju[0] + L[0].Jv[7];
+#endif
       W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
     }
   }

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdba_hip.so")
+LIB_PATH = os.environ.get("DBA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdba_hip.so")
 
 DBA_F32, DBA_F16, DBA_F64 = 0, 1, 2
 _ERR = {-1: "DBA_ERR_ARG", -2: "DBA_ERR_WORKSPACE", -3: "DBA_ERR_HIP", -4: "DBA_ERR_UNSUPPORTED"}

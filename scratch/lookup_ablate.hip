@@ -6,10 +6,11 @@
 #include <cstdlib>
 #include "../dba-fusion_amd/csrc/corr_sheared.hip"
 namespace dba { void set_last_error(const char*, hipError_t) {} }
+__global__ void fill_rand(unsigned short* p, size_t n) { size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; size_t st = (size_t)gridDim.x * 256; for (; i < n; i += st) { unsigned x = (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 13); x ^= x << 13; x ^= x >> 17; x ^= x << 5; p[i] = (unsigned short)((x & 0x83ff) | 0x3800); } }
 int main() {
   const int n = 96, h = 64, w = 64, HW = h * w;
   const void* vols[4];
-  for (int l = 0; l < 4; l++) { size_t bytes = (size_t)n * HW * (h >> l) * (w >> l) * 2; void* p; hipMalloc(&p, bytes); hipMemset(p, 0, bytes); vols[l] = p; }
+  for (int l = 0; l < 4; l++) { size_t bytes = (size_t)n * HW * (h >> l) * (w >> l) * 2; void* p; hipMalloc(&p, bytes); hipMemset(p, 0, bytes); if (getenv("RANDFILL")) hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, 0, (unsigned short*)p, bytes / 2); vols[l] = p; }
   std::vector<float> c((size_t)n * HW * 2);
   srand(1);
   for (int e = 0; e < n; e++) {
