@@ -50,6 +50,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const size_t o_fslot = take(sizeof(int) * (size_t)B);
   const size_t o_eoff = take(sizeof(int) * (size_t)(Mmax + 1));
   const size_t o_elist = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  const size_t o_erank = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
   L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
@@ -79,6 +80,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->T.frame_slot = reinterpret_cast<int *>(base + o_fslot);
     plan->T.eoff = reinterpret_cast<int *>(base + o_eoff);
     plan->T.elist = reinterpret_cast<int *>(base + o_elist);
+    plan->T.elist_rank = reinterpret_cast<int *>(base + o_erank);
     plan->T.Mmax = Mmax;
     plan->T.B = B;
     plan->W.E = reinterpret_cast<float *>(base + L.E);

@@ -16,6 +16,7 @@ struct BaTables {
   int *frame_slot;  // [B]      slot of frame f, -1 if absent
   int *eoff;        // [Mmax+1] CSR offsets of the out-edges of slot m
   int *elist;       // [N]      edge ids, ascending within a slot
+  int *elist_rank;  // [N]      scratch of the prepare kernel
   int Mmax, B;
 };
 

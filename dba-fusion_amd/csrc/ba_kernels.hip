@@ -35,6 +35,7 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   const int P = t1 - t0;
 
   for (int f = tid; f < B; f += nt) flag[f] = 0;
+  for (int n = tid; n < N; n += nt) T.elist_rank[n] = 0;
   __syncthreads();
   for (int p = tid; p < P; p += nt) {
     const int f = t0 + p;
@@ -97,13 +98,29 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     T.eoff[T.Mmax] = run;
   }
   __syncthreads();
-  // ascending-n fill: position = #earlier edges with the same source frame
+  // ascending-n fill: position = #earlier edges with the same source frame (source frames staged in LDS,
+  // in chunks, so the O(N^2) comparison never goes back to global memory)
+  int *sii = scan;  // 1024 ints, free after the scan
+  for (int base = 0; base < N; base += 1024) {
+    __syncthreads();
+    if (base + tid < N) sii[tid] = (int)ii[base + tid];
+    __syncthreads();
+    const int lim = min(1024, N - base);
+    for (int n = tid; n < N; n += nt) {
+      if (n <= base) continue;
+      const int f = (int)ii[n];
+      if (!(f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax)) continue;
+      int rank = 0;
+      const int qend = min(lim, n - base);
+      for (int q = 0; q < qend; q++) rank += (sii[q] == f);
+      atomicAdd(&T.elist_rank[n], rank);
+    }
+  }
+  __syncthreads();
   for (int n = tid; n < N; n += nt) {
     const int f = (int)ii[n];
     if (!(f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax)) continue;
-    int rank = 0;
-    for (int q = 0; q < n; q++) rank += ((int)ii[q] == f);
-    T.elist[cnt[flag[f] - 1] + rank] = n;
+    T.elist[cnt[flag[f] - 1] + T.elist_rank[n]] = n;
   }
 }
 
@@ -459,7 +476,15 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
     if (frame_owned && !frame_owned[src]) return;
     const float *hp = W.HpartE + (size_t)n * W.nparts * HPE_STRIDE + l;
     double s = 0.0;
-    for (int part = 0; part < W.nparts; part++) s += (double)hp[(size_t)part * HPE_STRIDE];
+    int part = 0;
+    for (; part + 8 <= W.nparts; part += 8) {  // eight independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
+#pragma unroll
+      for (int q = 0; q < 8; q++) s += (double)v[q];
+    }
+    for (; part < W.nparts; part++) s += (double)hp[(size_t)part * HPE_STRIDE];
     const int i = src - t0, j = (int)jj[n] - t0;
     const bool iv = (i >= 0 && i < P), jv = (j >= 0 && j < P);
     if (l < 36) {  // Hji[a][b] and its transpose Hij[b][a]
@@ -493,7 +518,15 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
   if (i < 0 || i >= P) return;  // fixed pose: its block is dropped (:1191)
   const float *hp = W.HpartF + (size_t)m * W.nparts * HPF_STRIDE + l;
   double s = 0.0;
-  for (int part = 0; part < W.nparts; part++) s += (double)hp[(size_t)part * HPF_STRIDE];
+  int part = 0;
+  for (; part + 8 <= W.nparts; part += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPF_STRIDE];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += (double)v[q];
+  }
+  for (; part < W.nparts; part++) s += (double)hp[(size_t)part * HPF_STRIDE];
   if (l < 21) {
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= l) a++;

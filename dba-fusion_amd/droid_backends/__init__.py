@@ -84,9 +84,9 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     t0, t1 = int(t0), int(t1)
     P = t1 - t0
     ws, nbytes = _ws(N, B, ht, wd, t0, t1, poses.device)
-    dx = torch.zeros(P, 6, dtype=torch.float32, device=poses.device)
+    dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by dba_ba
     Mmax = min(B, P + N)
-    dz_full = torch.zeros(Mmax, ht * wd, dtype=torch.float32, device=poses.device)
+    dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
     rc = _lib.load().dba_ba(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
                             _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1,
                             int(iterations), float(lm), float(ep), int(bool(motion_only)), _ptr(dx),
