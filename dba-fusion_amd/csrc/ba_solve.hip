@@ -56,7 +56,9 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
   const double hd = -0.5 * d;
   y = y * fma(hd, y * y, 1.5);
+#ifndef SOLVE_ONE_NEWTON
   y = y * fma(hd, y * y, 1.5);
+#endif
   return y;
 }
 
@@ -187,21 +189,30 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
     // v_mfma_f64_16x16x4_f64 per 4 panel columns (A = -X rows, B = X rows; C/D row = (lane>>4) + 4 reg,
     // col = lane & 15).  Tiles whose panel rows or columns are exactly zero are skipped.
     {
-      const int Tn = (n1 - r0 + 15) >> 4;  // row tiles (the last one may hang over the rhs row)
-      const int ntiles = Tn * (Tn + 1) / 2;
+      const int Tn = (n1 - r0 + 15) >> 4;  // row tiles (the last one may hang over the rhs row); <= 32 here
       const int nw = nt >> 6;
       const int li = lane & 15, lk = lane >> 4;
-      for (int e = wave; e < ntiles; e += nw) {
-        int ti = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (ti * (ti + 1) / 2 > e) ti--;
-        while ((ti + 1) * (ti + 2) / 2 <= e) ti++;
-        const int tj = e - ti * (ti + 1) / 2;
+      // which row tiles have a non-zero panel row?  (wave-uniform bit mask from ballots over the row flags)
+      unsigned tmask = 0;
+      for (int base = 0; base < Tn * 16; base += 64) {
+        const int i = r0 + base + lane;
+        const unsigned long long b = __ballot(i <= n && rowflag[i] != 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          if ((b >> (16 * g)) & 0xffffull) tmask |= 1u << ((base >> 4) + g);
+      }
+      PROF(4);
+      // enumerate the active lower-triangular tile pairs (ti >= tj, both active); wave w takes every nw-th
+      int pair = 0;
+      for (unsigned mi = tmask; mi; mi &= mi - 1) {
+        const int ti = __builtin_ctz(mi);
+        for (unsigned mj = tmask & ((2u << ti) - 1u); mj; mj &= mj - 1) {
+          const int tj = __builtin_ctz(mj);
+          if ((pair++ % nw) != wave) continue;
         const int i0 = r0 + 16 * ti, j0 = r0 + 16 * tj;
         // per-lane operand rows (clamped; rows past the rhs row contribute zeros)
         const int ia = i0 + li, jb = j0 + li;
         const bool va = ia <= n, vb = jb <= n;
-        const int fa = va ? rowflag[ia] : 0, fb = vb ? rowflag[jb] : 0;
-        if (!(__any(fa) && __any(fb))) continue;  // wave-uniform
         const int ba = tri(min(ia, n), kb), bb = tri(min(jb, n), kb);
         d4 acc;
 #pragma unroll
@@ -221,7 +232,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
           const int i = i0 + lk + 4 * r, j = j0 + li;
           if (i <= n && j < n && j <= i) A[tri(i, j)] = acc[r];
         }
+        }
       }
+      PROF(5);
     }
     __syncthreads();
     PROF(3);

@@ -45,8 +45,12 @@ class CorrBlock:
             raise RuntimeError("CorrBlock: sheared layout needs radius 3 and equal feature-map sizes")
         self.layout = layout
         self.h2, self.w2 = int(h2), int(w2)
-        ref = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
-        self.corr_pyramid = CorrBlock.shear_pyramid(ref) if layout == "sheared" else ref
+        if layout == "sheared":
+            fused = CorrBlock.build_sheared_fused(fmap1, fmap2, num_levels)
+            self.corr_pyramid = fused if fused is not None else CorrBlock.shear_pyramid(
+                CorrBlock.build_pyramid(fmap1, fmap2, num_levels))
+        else:
+            self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
 
     @staticmethod
     def build_pyramid(fmap1, fmap2, num_levels=4):
@@ -66,6 +70,27 @@ class CorrBlock:
         ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() for lv in levels])
         _lib.check(lib.dba_corr_volume_build(_ptr(f1), _ptr(f2), ptrs, n, dim, h1, w1, h2, w2, num_levels,
                                              _ptr(scratch), sbytes, _stream()), "dba_corr_volume_build")
+        return levels
+
+    @staticmethod
+    def build_sheared_fused(fmap1, fmap2, num_levels=4):
+        """one-pass MFMA build of the sheared pyramid (64-wide maps); None if the shape is not supported"""
+        batch, num, dim, h1, w1 = fmap1.shape
+        _, _, _, h2, w2 = fmap2.shape
+        lib = _lib.load()
+        if not lib.dba_corr_volume_build_sheared_supported(dim, h1, w1, h2, w2, num_levels):
+            return None
+        n = batch * num
+        f1 = fmap1.reshape(n, dim, h1, w1).to(torch.float16).contiguous()
+        f2 = fmap2.reshape(n, dim, h2, w2).to(torch.float16).contiguous()
+        levels = [torch.empty(n, h2 >> l, w2 >> l, h1, w1, dtype=torch.float16, device=f1.device)
+                  for l in range(num_levels)]
+        sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, h2, w2)
+        scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)
+        ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() for lv in levels])
+        _lib.check(lib.dba_corr_volume_build_sheared(_ptr(f1), _ptr(f2), ptrs, n, dim, h1, w1, h2, w2, num_levels,
+                                                     _ptr(scratch), sbytes, _stream()),
+                   "dba_corr_volume_build_sheared")
         return levels
 
     @staticmethod

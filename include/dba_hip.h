@@ -157,6 +157,15 @@ int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device
  * dbaf/modules/corr.py:31-36, but the taps that neighbouring source pixels read become contiguous, so a
  * wave fetches full 128-byte lines (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup
  * result is bit-identical to corr_index_forward on the reference layout.  f16 only, radius 3. */
+/* Fused build of the sheared pyramid straight from the feature maps (csrc/corr_build_fused.hip): MFMA GEMM,
+ * 2x2 pooling of the rounded levels and the flow-aligned store in one pass; every output byte is written once.
+ * Supported when dba_corr_volume_build_sheared_supported(...) returns 1 (h1 == h2, w1 == w2 == 64, h2 % 8 == 0,
+ * C % 16 == 0, 4 levels); sheared_levels[l] is [n, h2>>l, w2>>l, h1, w1] f16.  scratch as for
+ * dba_corr_volume_build. */
+int dba_corr_volume_build_sheared_supported(int C, int h1, int w1, int h2, int w2, int num_levels);
+int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *const *sheared_levels, int n, int C,
+                                  int h1, int w1, int h2, int w2, int num_levels, void *scratch,
+                                  size_t scratch_bytes, dba_stream_t stream);
 int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int h1, int w1, int h2l, int w2l,
                          int lvl, dba_stream_t stream);
 int dba_corr_lookup_pyramid_sheared(const void *const *volumes /* host array of L device ptrs */,

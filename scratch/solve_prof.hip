@@ -16,7 +16,7 @@ int main() {
   hipMemset(prof, 0, 8*16);
     for (int it = 0; it < 3; it++) { hipMemset(prof, 0, 8*16); dba::launch_ba_solve(dH, db, n, 1e-4, 0.1, dx, meta, nullptr, 0, prof); hipDeviceSynchronize(); }
   long long hp[16]; hipMemcpy(hp, prof, 8*16, hipMemcpyDeviceToHost);
-  const char* names[] = {"load","diag","panel","update","-","-","bwd_tri","bwd_upd","final"};
+  const char* names[] = {"load","diag","panel","upd_barrier","upd_mask","upd_tiles","bwd_tri","bwd_upd","final"};
   long long tot = 0; for (int i = 0; i < 9; i++) tot += hp[i];
   for (int i = 0; i < 9; i++) printf("%-8s %8lld ticks (%.1f%%)\n", names[i], hp[i], 100.0*hp[i]/tot);
   printf("total %lld ticks (100MHz const clock => %.1f us)\n", tot, tot/100.0);

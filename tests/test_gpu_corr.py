@@ -113,6 +113,23 @@ def test_lookup_non_finite_coords_do_not_fault(layout):
     assert np.array_equal(out[0][:, mask].view(np.uint16), good[0][:, mask].view(np.uint16))
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64), (3, 32, 24, 64), (1, 16, 8, 64)])
+def test_fused_sheared_build_equals_unfused_pipeline(shape):
+    """one-pass MFMA build (GEMM + pooling + shear) == GEMM kernel + 3 pooling passes + shear passes, bit for bit"""
+    from dbaf_amd.corr import CorrBlock
+    n, C, h, w = shape
+    rng = np.random.default_rng(12)
+    t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    fused = CorrBlock.build_sheared_fused(t1, t2, 4)
+    assert fused is not None
+    unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
+    for lvl in range(4):
+        a, b = fused[lvl].cpu().numpy(), unfused[lvl].cpu().numpy()
+        assert a.shape == b.shape
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (lvl, (a != b).mean())
+
+
 def test_sheared_volume_is_a_permutation_of_the_reference_volume():
     from dbaf_amd.corr import CorrBlock
     rng = np.random.default_rng(6)
