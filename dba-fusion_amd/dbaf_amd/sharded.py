@@ -7,7 +7,7 @@ The reference is single-GPU (no NCCL anywhere); this is new design for the MI355
     Gauss-Newton iteration (83 KB at P = 24) over RCCL/xGMI -- latency-bound, not bandwidth-bound;
   * every rank then solves the identical system redundantly (identical bits in -> identical dx out; RCCL
     delivers the same reduced buffer to all ranks), retracts all poses, back-substitutes the depths of the
-    frames it owns, and the per-frame depth updates are exchanged with one more small all-reduce
+    frames it owns; the per-frame depth updates are exchanged once per call with one more small all-reduce
     (a sum in which exactly one rank contributes a non-zero per element, hence exact).
 The stage executor is pluggable so the partition / exchange logic is testable on CPU with the gloo backend
 (tests/test_sharded_cpu.py drives it with a CPU stand-in); the product executor is `HipStages` (C ABI).
@@ -80,6 +80,7 @@ class ShardedWindow:
                            self.t0, self.t1, alpha)
         kmin, kmax = int(self.kx_global[0]), int(self.kx_global[-1]) + 1
         own_rows = d["owned"][kmin:kmax].to(torch.bool)
+        before = disps[kmin:kmax].clone()
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
             hb = stages.get_system(ctx)                     # float64 [n6*n6 + n6], this rank's partial sums
@@ -87,14 +88,16 @@ class ShardedWindow:
                 dist.all_reduce(hb)                         # RCCL sum over xGMI (gloo in the CPU tests)
             stages.set_system(ctx, hb)
             stages.solve(ctx, lm, ep)
-            before = disps[kmin:kmax].clone()
             stages.update(ctx, update_disps=not motion_only)
-            if not motion_only:
-                delta = disps[kmin:kmax] - before
-                delta[~own_rows] = 0                        # only the owner's update of a frame counts
-                if dist is not None and self.world > 1:
-                    dist.all_reduce(delta)
-                disps[kmin:kmax] = before + delta
+        # Between iterations a rank only reads the depths of the frames it owns (the source frames of its own
+        # edges), so the replicas are made coherent ONCE per call: owner-masked deltas, summed over ranks
+        # (exactly one non-zero contributor per element, hence exact).
+        if not motion_only:
+            delta = disps[kmin:kmax] - before
+            delta[~own_rows] = 0
+            if dist is not None and self.world > 1:
+                dist.all_reduce(delta)
+            disps[kmin:kmax] = before + delta
         assert hb.numel() == n6 * n6 + n6
         return stages.finish(ctx)
 

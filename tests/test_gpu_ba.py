@@ -148,6 +148,58 @@ def test_bacore_hessian_and_retract():
     del core
 
 
+def _compare_with_oracle(W, itrs=2, **kw):
+    orc = _oracle()
+    args = (W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, itrs,
+            W.lm, W.ep, False, 0.05)
+    r32, r64 = orc.ba(*args, np.float32), orc.ba(*args, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W, itrs=itrs)
+    assert dz.shape == r64["dz"].shape
+    return check_state(poses, disps, r64["poses"], r64["disps"], W.disps, ref32_disps=r32["disps"], **kw)
+
+
+def test_ba_duplicate_edges_and_edgeless_window_frame():
+    """collisions: the same (i, j) twice (the reference sums both, SparseBlock::update_lhs :1186-1200);
+    a frame inside [t0, t1) with no edge at all keeps its pose (zero block + damping) and its depths."""
+    ii = np.array([0, 1, 1, 2, 2, 1, 0, 2, 4, 2], np.int64)
+    jj = np.array([1, 0, 2, 1, 1, 2, 2, 0, 2, 4], np.int64)  # (2,1) and (1,2) twice; frame 3 has no edge
+    W = syn.make_window(ii, jj, 5, 16, 24, seed=81, intr=(9.0, 9.3, 11.6, 7.9))
+    assert 3 in W.kx and 3 not in ii and 3 not in jj
+    print(_compare_with_oracle(W))
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    np.testing.assert_allclose(poses[3], W.poses[3], atol=1e-6)  # untouched by any residual
+    assert np.array_equal(disps[3], W.disps[3])
+
+
+def test_ba_source_frames_outside_the_window_and_later_t0():
+    """t0 = 3: frames 0..2 are fixed (their pose blocks are dropped, :1191) but their depths still move"""
+    W = syn.make_window(*syn.graph_banded(7, 2), 7, 16, 16, seed=82, intr=(6.0, 6.0, 7.7, 8.1), t0=3)
+    assert W.t0 == 3 and W.M == 7
+    print(_compare_with_oracle(W))
+    poses, disps, _, _ = _run_gpu_ba(W)
+    assert np.array_equal(poses[:3], W.poses[:3]) and not np.array_equal(disps[1], W.disps[1])
+
+
+def test_ba_without_edges_is_a_noop():
+    W = syn.make_window(np.zeros(0, np.int64), np.zeros(0, np.int64), 4, 8, 16, seed=83, intr=(4.0, 4.0, 7.5, 3.5))
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    assert np.array_equal(dx, np.zeros_like(dx))
+    np.testing.assert_allclose(poses, W.poses, atol=1e-7)
+    assert np.array_equal(disps, W.disps)
+
+
+def test_ba_eta_broadcast_row():
+    """eta given as a single [1, h, w] row (view(-1, HW) broadcast in the reference, :1476)"""
+    orc = _oracle()
+    W = syn.window_tiny_a(84)
+    W.eta = W.eta[:1].copy()
+    r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+                 W.lm, W.ep, False, 0.05, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    assert dz.shape == (W.M, W.h * W.w)
+    check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
+
+
 def test_ba_rejects_cpu_and_noncontiguous():
     import droid_backends
     W = syn.window_tiny_a(71)
