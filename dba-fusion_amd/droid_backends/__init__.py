@@ -326,5 +326,18 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
-    """droid.cpp:266-278 (training only; dead in the DBA-Fusion runtime).  Not built yet."""
-    raise NotImplementedError("altcorr_backward: training-only op, not part of the MI355X hot path yet")
+    """droid.cpp:266-278 (training only; dead in the DBA-Fusion runtime).  Returns
+    [fmap1_grad, fmap2_grad, coords_grad]; coords_grad is all zeros like the reference's (never written)."""
+    _check(fmap1, "fmap1", torch.float32)
+    _check(fmap2, "fmap2", torch.float32)
+    _check(coords, "coords", torch.float32)
+    _check(corr_grad, "corr_grad", torch.float32)
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    g1 = torch.zeros(B, H1, W1, C, dtype=torch.float32, device=fmap1.device)
+    g2 = torch.zeros(B, H2, W2, C, dtype=torch.float32, device=fmap1.device)
+    gc = torch.zeros(B, S, H1, W1, 2, dtype=torch.float32, device=fmap1.device)
+    _lib.check(_lib.load().dba_altcorr_backward(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr_grad), _ptr(g1),
+                                                _ptr(g2), int(B), int(S), int(H1), int(W1), int(H2), int(W2),
+                                                int(C), int(radius), _stream()), "dba_altcorr_backward")
+    return [g1, g2, gc]

@@ -192,6 +192,14 @@ int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *lev
 int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr, int B,
                         int S, int H1, int W1, int H2, int W2, int C, int radius, dba_stream_t stream);
 
+/* altcorr_backward (src/droid.cpp:266-278, src/altcorr_kernel.cu:152-286,321-356; training only):
+ * gradients wrt the feature maps; fmap1_grad [B,H1,W1,C], fmap2_grad [B,H2,W2,C] must be zero-initialised
+ * by the caller (fmap2_grad is accumulated with float atomics like the reference); the reference's
+ * coords_grad is allocated and never written (stays zero), so it has no entry point here. */
+int dba_altcorr_backward(const float *fmap1, const float *fmap2, const float *coords, const float *corr_grad,
+                         float *fmap1_grad, float *fmap2_grad, int B, int S, int H1, int W1, int H2, int W2,
+                         int C, int radius, dba_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Geometry.
  * ---------------------------------------------------------------------------------------- */

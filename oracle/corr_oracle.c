@@ -216,3 +216,47 @@ void oracle_altcorr_forward_f32(const float *fmap1, const float *fmap2, const fl
               }
           }
 }
+
+/* ---- altcorr_backward_kernel, altcorr_kernel.cu:152-286 (float; launcher :321-356) ---------------
+ * fmap1_grad [B][H1][W1][C], fmap2_grad [B][H2][W2][C] (zero-initialised here like the launcher does);
+ * coords_grad is allocated but never written by the reference (stays zero). */
+void oracle_altcorr_backward_f32(const float *fmap1, const float *fmap2, const float *coords,
+                                 const float *corr_grad, float *fmap1_grad, float *fmap2_grad, int B, int S,
+                                 int H1, int W1, int H2, int W2, int C, int r) {
+  const int rd = 2 * r + 1;
+  const size_t HW1 = (size_t)H1 * W1;
+  memset(fmap1_grad, 0, sizeof(float) * (size_t)B * HW1 * C);
+  memset(fmap2_grad, 0, sizeof(float) * (size_t)B * H2 * W2 * C);
+  for (int b = 0; b < B; b++)
+    for (int h1 = 0; h1 < H1; h1++)
+      for (int w1 = 0; w1 < W1; w1++)
+        for (int c = 0; c < C; c += 32) {
+          const float *f1 = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c;
+          float f1g[32];
+          for (int k = 0; k < 32; k++) f1g[k] = 0.0f;
+          for (int s = 0; s < S; s++) {
+            const float *cp = coords + ((((size_t)b * S + s) * H1 + h1) * W1 + w1) * 2;
+            const float x2 = cp[0], y2 = cp[1];
+            const float dx = x2 - floorf(x2), dy = y2 - floorf(y2);
+            const float *gp = corr_grad + (((size_t)b * S + s) * rd * rd) * HW1 + (size_t)h1 * W1 + w1;
+            for (int iy = 0; iy < rd + 1; iy++)
+              for (int ix = 0; ix < rd + 1; ix++) {
+                const int h2 = (int)floorf(y2) - r + iy, w2 = (int)floorf(x2) - r + ix;
+                float g = 0.0f;
+                if (iy > 0 && ix > 0) g += gp[(size_t)((iy - 1) + rd * (ix - 1)) * HW1] * dy * dx;
+                if (iy > 0 && ix < rd) g += gp[(size_t)((iy - 1) + rd * ix) * HW1] * dy * (1 - dx);
+                if (iy < rd && ix > 0) g += gp[(size_t)(iy + rd * (ix - 1)) * HW1] * (1 - dy) * dx;
+                if (iy < rd && ix < rd) g += gp[(size_t)(iy + rd * ix) * HW1] * (1 - dy) * (1 - dx);
+                if (!within_bounds(h2, w2, H2, W2)) continue; /* f2 = 0: no f1 grad; no atomicAdd */
+                const float *f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C + c;
+                float *f2g = fmap2_grad + (((size_t)b * H2 + h2) * W2 + w2) * C + c;
+                for (int k = 0; k < 32 && c + k < C; k++) {
+                  f1g[k] += g * f2[k];
+                  f2g[k] += g * f1[k];
+                }
+              }
+          }
+          float *o = fmap1_grad + (((size_t)b * H1 + h1) * W1 + w1) * C + c;
+          for (int k = 0; k < 32 && c + k < C; k++) o[k] += f1g[k];
+        }
+}

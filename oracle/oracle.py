@@ -324,3 +324,18 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
                                      ctypes.c_int(S), ctypes.c_int(H1), ctypes.c_int(W1), ctypes.c_int(H2),
                                      ctypes.c_int(W2), ctypes.c_int(C), ctypes.c_int(radius))
     return out
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """altcorr_backward_kernel (altcorr_kernel.cu:152-286), float32 -> (fmap1_grad, fmap2_grad)."""
+    fmap1, fmap2, coords = _c(fmap1, np.float32), _c(fmap2, np.float32), _c(coords, np.float32)
+    corr_grad = _c(corr_grad, np.float32)
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    g1 = np.zeros_like(fmap1)
+    g2 = np.zeros_like(fmap2)
+    lib().oracle_altcorr_backward_f32(_p(fmap1), _p(fmap2), _p(coords), _p(corr_grad), _p(g1), _p(g2),
+                                      ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(H1), ctypes.c_int(W1),
+                                      ctypes.c_int(H2), ctypes.c_int(W2), ctypes.c_int(C), ctypes.c_int(radius))
+    return g1, g2

@@ -214,3 +214,21 @@ def test_corr_index_backward_matches_oracle():
     vol = torch.zeros(n, h1, w1, h2, w2, device="cuda")
     out, = droid_backends.corr_index_backward(vol, torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda(), r)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_altcorr_backward_matches_oracle():
+    import droid_backends
+    orc = _oracle()
+    rng = np.random.default_rng(11)
+    B, S, H1, W1, H2, W2, C, r = 2, 2, 6, 7, 5, 6, 48, 3
+    f1 = rng.standard_normal((B, H1, W1, C)).astype(np.float32)
+    f2 = rng.standard_normal((B, H2, W2, C)).astype(np.float32)
+    coords = np.stack([rng.uniform(-2, W2 + 1, size=(B, S, H1, W1)), rng.uniform(-2, H2 + 1, size=(B, S, H1, W1))],
+                      -1).astype(np.float32)
+    cg = rng.standard_normal((B, S, 49, H1, W1)).astype(np.float32)
+    r1, r2 = orc.altcorr_backward(f1, f2, coords, cg, r)
+    g1, g2, gc = droid_backends.altcorr_backward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
+                                                 torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda(), r)
+    np.testing.assert_allclose(g1.cpu().numpy(), r1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-4)
+    assert float(gc.abs().max()) == 0.0
