@@ -200,16 +200,40 @@ __device__ __forceinline__ void linearize_pixel(float u, float v, float disp, fl
 // Hii and vi only involve the source pose, so they are summed over the frame's out-edges in registers
 // and folded across the wave once per frame instead of once per edge.
 
-// reduce value #L across the wave and deposit it in lane L of acc
+// Cross-lane sums by LDS transpose: every lane drops value #L into column `lane` of row L of a per-wave
+// [64][RED_PITCH] float tile (consecutive lanes -> consecutive banks); afterwards lane L adds up row L with 16
+// ds_read_b128 (pitch 68 floats: 16-byte aligned rows, conflict-free for the four 16-lane read groups).
+// 63 ds_write_b32 + 16 ds_read_b128 + 63 v_add per edge instead of 63 x (6 DPP adds + readlane + select).
+constexpr int RED_PITCH = 68;
+
 template <int L>
-__device__ __forceinline__ void reduce_deposit(float val, float &acc) {
-  const float red = wave_sum_to_lane63(val);
-  acc = deposit_lane63<L>(acc, red, lane_id());
+__device__ __forceinline__ void reduce_deposit(float val, float *red_lane) {
+  red_lane[L * RED_PITCH] = val;
+}
+
+__device__ __forceinline__ float reduce_row(const float *red_wave, int lane) {
+  const float4 *row = reinterpret_cast<const float4 *>(red_wave + lane * RED_PITCH);
+  float4 s = row[0];
+#pragma unroll
+  for (int q = 1; q < 16; q++) {
+    const float4 v = row[q];
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  return (s.x + s.y) + (s.z + s.w);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {  // one wave: its LDS writes are complete before it reads them
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
 }
 
 template <int PPL, int A, int B_>
 struct HjiLoop {  // A in [0,6) indexes Jj, B_ in [0,6) indexes Ji
-  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
     float val = 0.f;
 #pragma unroll
     for (int q = 0; q < PPL; q++)
@@ -224,7 +248,7 @@ struct HjiLoop {  // A in [0,6) indexes Jj, B_ in [0,6) indexes Ji
 
 template <int PPL, int A, int B_>
 struct HjjLoop {
-  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
     float val = 0.f;
 #pragma unroll
     for (int q = 0; q < PPL; q++)
@@ -239,7 +263,7 @@ struct HjjLoop {
 
 template <int PPL, int A>
 struct VjLoop {
-  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float &acc) {
+  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
     float val = 0.f;
 #pragma unroll
     for (int q = 0; q < PPL; q++) val += L[q].wu * L[q].ru * L[q].Ju[6 + A] + L[q].wv * L[q].rv * L[q].Jv[6 + A];
@@ -250,7 +274,7 @@ struct VjLoop {
 
 template <int I>
 struct FrameReduce {  // 27 per-frame sums held in fsum[]
-  __device__ __forceinline__ static void run(const float (&fsum)[27], float &acc) {
+  __device__ __forceinline__ static void run(const float (&fsum)[27], float *acc) {
     reduce_deposit<I>(fsum[I], acc);
     if constexpr (I < 26) FrameReduce<I + 1>::run(fsum, acc);
   }
@@ -315,6 +339,9 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
   // while the current edge is being reduced.
   __shared__ float s_pose[64][12];  // tij[3], R[9]
   __shared__ int s_edge[64][2];     // edge id, target frame
+  __shared__ __attribute__((aligned(16))) float s_red[4][64 * RED_PITCH];  // per-wave transpose tiles
+  float *red_wave = s_red[threadIdx.x >> 6];
+  float *red_lane = red_wave + lane;
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
   for (int batch = e0; batch < e1; batch += 64) {
     const int cnt = min(64, e1 - batch);
@@ -403,11 +430,14 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
           fsum[21 + a] += L[q].wu * L[q].ru * L[q].Ju[a] + L[q].wv * L[q].rv * L[q].Jv[a];
       }
 
-      float acc = 0.f;
+      float acc;
 #ifndef LIN_ABLATE_REDUCE  // ablation builds only (scratch/)
-      HjiLoop<PPL, 0, 0>::run(L, acc);
-      HjjLoop<PPL, 0, 0>::run(L, acc);
-      VjLoop<PPL, 0>::run(L, acc);
+      HjiLoop<PPL, 0, 0>::run(L, red_lane);
+      HjjLoop<PPL, 0, 0>::run(L, red_lane);
+      VjLoop<PPL, 0>::run(L, red_lane);
+      wave_lds_fence();
+      acc = reduce_row(red_wave, lane);  // lane 63 adds up an unused row: harmless, never read back
+      wave_lds_fence();
 #else
       acc = L[0].Ju[0] + L[0].Jv[7];
 #endif
@@ -415,8 +445,9 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
     }
   }
   {
-    float acc = 0.f;
-    FrameReduce<0>::run(fsum, acc);
+    FrameReduce<0>::run(fsum, red_lane);
+    wave_lds_fence();
+    const float acc = reduce_row(red_wave, lane);
     if (lane < HPF_STRIDE) W.HpartF[((size_t)m * nparts + wave_global) * HPF_STRIDE + lane] = acc;
   }
 
