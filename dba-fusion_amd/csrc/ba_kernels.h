@@ -67,6 +67,9 @@ __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
 int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof = nullptr);
 bool ba_solve_fits_lds(int n);
+bool ba_solve_tile_supported(int n);
+int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
+                         hipStream_t stream);
 size_t ba_solve_scratch_doubles(int n);
 constexpr int SOLVE_MAX_LDS_BYTES = 160 * 1024;
 

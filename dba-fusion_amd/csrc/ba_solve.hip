@@ -19,6 +19,8 @@
 // The backward substitution L^T x = y runs block-wise with the 12x12 triangle solved across lanes.
 #include "ba_kernels.h"
 
+#include <cstdlib>
+
 namespace dba {
 
 #ifdef PROFILE_SOLVE
@@ -295,6 +297,9 @@ size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof) {
   if (n <= 0) return DBA_OK;
+  // window-sized systems take the register-tile LDL^T (ba_solve_tile.hip); DBA_SOLVE_GENERAL=1 forces this file's path
+  static const bool force_general = [] { const char *e = getenv("DBA_SOLVE_GENERAL"); return e && e[0] == '1'; }();
+  if (!prof && !force_general && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);
   const size_t small = solve_small_bytes(n), packed = solve_packed_bytes(n);
   if (packed + small <= (size_t)SOLVE_MAX_LDS_BYTES) {
     static bool attr_set = false;

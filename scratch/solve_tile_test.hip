@@ -1,0 +1,57 @@
+// scratch: correctness + timing of the tile LDL^T solver vs host Cholesky
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+#define PROFILE_SOLVE 1
+namespace dba { long long *g_tile_prof; }
+#include "../dba-fusion_amd/csrc/ba_solve.hip"
+#include "../dba-fusion_amd/csrc/ba_solve_tile.hip"
+namespace dba { void set_last_error(const char*, hipError_t) {} }
+static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
+  for (int j = 0; j < n; j++) {
+    double d = A[j*n+j]; for (int k = 0; k < j; k++) d -= A[j*n+k]*A[j*n+k];
+    if (!(d > 0)) return false; d = std::sqrt(d); A[j*n+j] = d;
+    for (int i = j+1; i < n; i++) { double s = A[i*n+j]; for (int k = 0; k < j; k++) s -= A[i*n+k]*A[j*n+k]; A[i*n+j] = s/d; }
+  }
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i*n+k]*b[k]; b[i] = s/A[i*n+i]; }
+  for (int i = n-1; i >= 0; i--) { double s = b[i]; for (int k = i+1; k < n; k++) s -= A[k*n+i]*b[k]; b[i] = s/A[i*n+i]; }
+  x = b; return true;
+}
+int run(int n, int band, bool spd, bool timeit) {
+  std::vector<double> H(n*n, 0.0), b(n);
+  srand(n*7+band);
+  for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) { double v = (i-j < band) ? ((rand()%2001)-1000)/1000.0/(1+i-j) : 0.0; H[i*n+j] = v; H[j*n+i] = v; } H[i*n+i] = spd ? 6.0 + (rand()%100)/50.0 : ((i == n/2) ? -1.0 : 6.0); b[i] = std::sin(i*1.3); }
+  const double lm = 1e-4, ep = 0.1;
+  std::vector<double> Hd = H; for (int i = 0; i < n; i++) Hd[i*n+i] += ep + lm*Hd[i*n+i];
+  std::vector<double> xr; bool ok = host_solve(Hd, b, n, xr);
+  double *dH, *db; float* dx; int* meta;
+  hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64);
+  hipMemcpy(dH, H.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
+  if (!dba::ba_solve_tile_supported(n)) { printf("n=%d unsupported\n", n); return 0; }
+  dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0);
+  hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("n=%d launch error %s\n", n, hipGetErrorString(e)); return 1; }
+  std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
+  double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
+  printf("n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
+  if (timeit) { long long hp[4]; hipMemcpy(hp, dba::g_tile_prof, 32, hipMemcpyDeviceToHost); printf("   ticks(10ns): load %lld factor %lld pinv %lld backsub %lld\n", hp[0],hp[1],hp[2],hp[3]); }
+  hipMemset(dba::g_tile_prof, 0, 128);
+  if (timeit) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; mode++) {
+      hipEventRecord(e0);
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr); }
+      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("   %s: %.2f us per solve\n", mode == 0 ? "tile " : "block", ms*1000/200);
+    }
+  }
+  return 0;
+}
+int main() {
+  hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
+  run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
+  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, false); run(174, 40, true, true); run(174, 174, true, false);
+  run(30, 30, false, false); run(150, 13, true, false); run(2, 2, true, false);
+}

@@ -210,3 +210,17 @@ def test_ba_rejects_cpu_and_noncontiguous():
     with pytest.raises(RuntimeError):
         droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"].transpose(2, 3),
                           d["weight"], d["eta"], d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+
+
+def test_ba_general_size_solver_path_matches_too():
+    """Window-sized systems take the register-tile LDL^T (csrc/ba_solve_tile.hip); the general-size blocked
+    Cholesky (csrc/ba_solve.hip) stays reachable with DBA_SOLVE_GENERAL=1 and must pass the same parity cases."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DBA_SOLVE_GENERAL="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_ba.py"),
+                        "-k", "matches_oracle or cholesky_failure"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
