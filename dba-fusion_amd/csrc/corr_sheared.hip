@@ -20,6 +20,8 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace dba {
 
 constexpr int SH_MAX_LEVELS = 8;
@@ -59,20 +61,36 @@ __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restr
 }
 
 // ---- lookup ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+// wave-wide / 8-lane-group integer min and max on the DPP network (fused into v_min/v_max: one VALU op per
+// step, no LDS traffic, no address arithmetic)
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ int dpp_minmax(int x) {
+  const int moved = __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);  // lanes without a source keep x
+  return IS_MIN ? min(x, moved) : max(x, moved);
 }
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_minmax(int x) {
+  x = dpp_minmax<0x111, 0xf, IS_MIN>(x);  // row_shr:1
+  x = dpp_minmax<0x112, 0xf, IS_MIN>(x);  // row_shr:2
+  x = dpp_minmax<0x114, 0xf, IS_MIN>(x);  // row_shr:4
+  x = dpp_minmax<0x118, 0xf, IS_MIN>(x);  // row_shr:8
+  x = dpp_minmax<0x142, 0xa, IS_MIN>(x);  // row_bcast:15
+  x = dpp_minmax<0x143, 0xc, IS_MIN>(x);  // row_bcast:31
+  return __builtin_amdgcn_readlane(x, 63);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ int group8_minmax(int x) {  // result in all 8 lanes of the group
+  x = dpp_minmax<0xB1, 0xf, IS_MIN>(x);   // quad_perm [1,0,3,2]
+  x = dpp_minmax<0x4E, 0xf, IS_MIN>(x);   // quad_perm [2,3,0,1]
+  x = dpp_minmax<0x141, 0xf, IS_MIN>(x);  // row_half_mirror: the other quad of the group
+  return x;
 }
 
 struct __attribute__((aligned(16))) Half8v {
   _Float16 v[8];
 };
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // Lookup kernel.  A workgroup is SH_WAVES independent waves; a wave = 64 consecutive x1 of one source row, one
 // pyramid level.
@@ -84,6 +102,14 @@ struct __attribute__((aligned(16))) Half8v {
 // registers, and emits the 7 outputs (a, b = j-1).  LDS per wave is 2 KB, so occupancy is bounded by registers
 // (8 waves/SIMD), not by staging space.
 //
+// The kernel is bound by VALU issue (a wave64 op holds a 16-lane SIMD for 4 cycles), so the inner step is
+// written for instruction count: the blend runs on channel PAIRS with packed f16 ops (v_pk_mul_f16 /
+// v_pk_add_f16 round each half exactly like the scalar ops), taps arrive from LDS already packed
+// (d16 / d16_hi loads) and the odd-aligned pairs come from one v_alignbit each, the two tap-row register sets
+// alternate roles instead of being copied, stores go through a scalar base per channel column with one
+// per-lane offset, staging loads use a scalar row base that advances on the scalar unit, and all cross-lane
+// set-up runs on DPP.
+//
 // Lanes whose window origin is further than SH_BAND from the wave's reference ("outliers": flow
 // discontinuities, pixels thrown far away, and every lane of a ragged tile) are not allowed to widen the
 // streamed region; they are appended to a workgroup-wide list and gathered afterwards with all 64 lanes of
@@ -91,8 +117,19 @@ struct __attribute__((aligned(16))) Half8v {
 constexpr int SH_NX = 16;     // plane-rows per step held in LDS (union width in x: 8 + spread <= 16)
 constexpr int SH_NY = 72;     // longest union in y walked by the streaming path
 constexpr int SH_BAND = 4;    // |origin - reference| <= SH_BAND streams
-constexpr int SH_WAVES = 8;   // waves (source rows) per workgroup
+#ifndef SH_WAVES_CFG
+#define SH_WAVES_CFG 8
+#endif
+#ifndef SH_DEPTH_CFG
+#define SH_DEPTH_CFG 2
+#endif
+#ifndef SH_OCC_CFG
+#define SH_OCC_CFG 8
+#endif
+constexpr int SH_WAVES = SH_WAVES_CFG;   // waves (source rows) per workgroup
 constexpr int SH_BLOCK = SH_WAVES * 64;
+constexpr int SH_DEPTH = SH_DEPTH_CFG;   // plane-rows in flight per wave (registers: 8 VGPRs per row)
+constexpr int SH_OCC = SH_OCC_CFG;       // waves per SIMD the register budget is set for
 
 struct ShPixel {  // per-pixel lookup state, identical arithmetic in the streaming and the gather phase
   int ix0, iy0, ox, oy;
@@ -128,7 +165,8 @@ __device__ __forceinline__ ShPixel sh_pixel(float2 c, int lvl, int x1, int y1, i
 
 // c10::Half `a * b` / `a + b` compute in float and round to half; for two halves that is exactly the IEEE half
 // operation (the float product is exact; a float sum rounded to half cannot double-round because
-// 24 >= 2*11 + 2), so native v_mul_f16 / v_add_f16 are bit-identical.  No fusion: -ffp-contract=off.
+// 24 >= 2*11 + 2), so native v_mul_f16 / v_add_f16 (and their packed forms) are bit-identical.  No fusion:
+// -ffp-contract=off.
 // Order: tap(a,b)*w00, tap(a,b+1)*w01, tap(a+1,b)*w10, tap(a+1,b+1)*w11 (correlation_kernels.cu:55-65).
 __device__ __forceinline__ _Float16 sh_blend(_Float16 p0, _Float16 c0, _Float16 p1, _Float16 c1, const ShPixel &p) {
   _Float16 acc = p0 * p.h00;
@@ -138,8 +176,29 @@ __device__ __forceinline__ _Float16 sh_blend(_Float16 p0, _Float16 c0, _Float16 
   return acc;
 }
 
+// one tap-row of a lane, as channel pairs: e[k] = (tap 2k, tap 2k+1), o[k] = (tap 2k+1, tap 2k+2)
+struct ShTaps {
+  h2v e[4], o[4];
+};
+
+__device__ __forceinline__ void sh_read_taps(const _Float16 *tp, ShTaps &T) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    h2v v;
+    v.x = tp[(2 * k) * 64];
+    v.y = tp[(2 * k + 1) * 64];
+    T.e[k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned lo = __builtin_bit_cast(unsigned, T.e[k]);
+    const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, T.e[k < 3 ? k + 1 : 3]) : 0u;
+    T.o[k] = __builtin_bit_cast(h2v, __builtin_amdgcn_alignbit(hi, lo, 16));
+  }
+}
+
 template <int R>
-__global__ __launch_bounds__(SH_BLOCK, 8) void corr_lookup_sheared_kernel(ShLevels L,
+__global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(ShLevels L,
                                                                           const float2 *__restrict__ coords,
                                                                           _Float16 *__restrict__ out, int n,
                                                                           int h1, int w1, int h2, int w2,
@@ -149,7 +208,8 @@ __global__ __launch_bounds__(SH_BLOCK, 8) void corr_lookup_sheared_kernel(ShLeve
   __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
   __shared__ int olist[SH_BLOCK];
   __shared__ int ocount;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   _Float16 *stage = stage_all[wave];
   const int xtiles = (w1 + 63) / 64;
   const int lvl = blockIdx.y;
@@ -172,15 +232,16 @@ __global__ __launch_bounds__(SH_BLOCK, 8) void corr_lookup_sheared_kernel(ShLeve
     const ShPixel P = sh_pixel<R>(coords[(size_t)ey * w1 + x1c], lvl, x1c, y1, h2l, w2l, active);
     const bool touches = P.touches;
     const int ox = P.ox, oy = P.oy, sy = y1 >> lvl;
-    _Float16 *o = olvl + (size_t)e * estride + (size_t)y1 * w1 + x1;
+    _Float16 *obase = olvl + (size_t)e * estride;     // uniform
+    const unsigned pix = (unsigned)(y1 * w1 + x1);   // this lane's pixel inside a channel plane
 
     const bool can_stream = ((w1 & 7) == 0) && (xt * 64 + 64 <= w1);
     const unsigned long long tmask = __ballot(touches);
     int refx = 0, refy = 0;
     if (tmask) {
       const int first = __ffsll((long long)tmask) - 1, last = 63 - __clzll((long long)tmask);
-      const int fxo = __shfl(ox, first, 64), fyo = __shfl(oy, first, 64);
-      const int lxo = __shfl(ox, last, 64), lyo = __shfl(oy, last, 64);
+      const int fxo = __builtin_amdgcn_readlane(ox, first), fyo = __builtin_amdgcn_readlane(oy, first);
+      const int lxo = __builtin_amdgcn_readlane(ox, last), lyo = __builtin_amdgcn_readlane(oy, last);
       const bool nearf = touches && (abs(ox - fxo) <= SH_BAND) && (abs(oy - fyo) <= SH_BAND);
       const bool nearl = touches && (abs(ox - lxo) <= SH_BAND) && (abs(oy - lyo) <= SH_BAND);
       const bool usef = __popcll(__ballot(nearf)) >= __popcll(__ballot(nearl));
@@ -192,122 +253,171 @@ __global__ __launch_bounds__(SH_BLOCK, 8) void corr_lookup_sheared_kernel(ShLeve
     if (outlier) olist[atomicAdd(&ocount, 1)] = ey * w1 + x1;  // <= 64 per wave: the list cannot overflow
 
     const int big = 1 << 28;
-    const int bx0 = wave_min_i32(inlier ? ox : big), bx1 = wave_max_i32(inlier ? ox : -big);
-    const int by0 = wave_min_i32(inlier ? oy : big), by1 = wave_max_i32(inlier ? oy : -big);
-    const bool any = bx1 >= bx0;
+    const bool any = __ballot(inlier) != 0ull;
 
     if (!any) {
       // nothing streams in this wave: lanes that touch nothing are exact zeros, outliers are written later
       if (active && !outlier) {
+        _Float16 *o = obase + pix;
 #pragma unroll
         for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
       }
     } else {
+      const int bx0 = wave_minmax<true>(inlier ? ox : big), bx1 = wave_minmax<false>(inlier ? ox : -big);
+      const int by0 = wave_minmax<true>(inlier ? oy : big), by1 = wave_minmax<false>(inlier ? oy : -big);
       const int nx = bx1 - bx0 + WN, ny = min(by1 - by0 + WN, SH_NY);  // nx <= 16, ny <= 16 by construction
-      const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1;
-      // per 8-lane group (= one 16-byte piece of a line): the range of window origins inside the group; a
-      // piece of line dx / plane-row dy is fetched only if some lane of its group reads it
-      int gx0 = inlier ? ox : big, gx1 = inlier ? ox : -big, gy0 = inlier ? oy : big, gy1 = inlier ? oy : -big;
-#pragma unroll
-      for (int off = 1; off <= 4; off <<= 1) {
-        gx0 = min(gx0, __shfl_xor(gx0, off, 64));
-        gx1 = max(gx1, __shfl_xor(gx1, off, 64));
-        gy0 = min(gy0, __shfl_xor(gy0, off, 64));
-        gy1 = max(gy1, __shfl_xor(gy1, off, 64));
-      }
-      // staging slots: lane + 64 t -> plane-row jx = slot >> 3, 16-byte piece sub = slot & 7 (fixed for all steps)
-      int qa[2], qb[2], ldsoff[2], jy_lo[2], jy_hi[2];
-      unsigned goff[2];
-      bool act[2];
+      // window origin of this lane inside the union (0 for lanes that stream nothing: they read row 0 with zero
+      // weights and emit exact zeros -- except outliers, whose outputs are left to the gather phase)
+      const int rx = inlier ? ox - bx0 : 0, ry = inlier ? oy - by0 : 0;
+      // per 8-lane group (= one 16-byte piece of a line): the range of window origins inside the group, packed
+      // into one word so that a single cross-lane permute hands it to the lanes that fetch the group's pieces
+      const int gx0 = group8_minmax<true>(inlier ? rx : 15), gx1 = group8_minmax<false>(inlier ? rx : -1);
+      const int gy0 = group8_minmax<true>(inlier ? ry : 15), gy1 = group8_minmax<false>(inlier ? ry : -1);
+      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
+      const int sub = lane & 7;  // 16-byte piece (fixed for both staging slots of a lane)
+      const int pg = __builtin_amdgcn_ds_bpermute(sub * 32, packed);  // from lane 8 * sub
+      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
+      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
+      const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
+
+      // staging slots: lane + 64 t -> plane-row jx = (lane >> 3) + 8 t of the union, piece sub
+      const int xs = xt * 64 + sub * 8;  // first x1 of this piece
+      unsigned goff[2], jlo[2], jlen[2];
+      int ldsoff[2];
+      u4v keep[2];
+      bool edge_any = false;
 #pragma unroll
       for (int t = 0; t < 2; t++) {
-        const int slot = lane + 64 * t;
-        const int jx = slot >> 3, sub = slot & 7;
+        const int jx = (lane >> 3) + 8 * t;
         const int dxv = bx0 + jx;
-        const int px0 = __shfl(gx0, sub * 8, 64), px1 = __shfl(gx1, sub * 8, 64);
-        const int py0 = __shfl(gy0, sub * 8, 64), py1 = __shfl(gy1, sub * 8, 64);
-        act[t] = (jx < nx) && (dxv >= px0) && (dxv < px1 + WN);
-        jy_lo[t] = py0 - by0;       // plane-rows [jy_lo, jy_hi) are read by this piece's lanes
-        jy_hi[t] = py1 - by0 + WN;
-        int m = dxv % w2l;
-        m += (m < 0) ? w2l : 0;
-        const int xs = xt * 64 + sub * 8;  // first x1 of this piece
+        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN);  // jx < nx follows
+        jlo[t] = (unsigned)py0;                 // plane-rows [py0, py1 + WN) are read by this piece's lanes
+        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
+        int m;
+        if (pow2) m = dxv & (w2l - 1);
+        else { m = dxv % w2l; m += (m < 0) ? w2l : 0; }
         // valid q: 0 <= ((xs + q) >> lvl) + dxv < w2l  <=>  qa <= q < qb
         const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
         const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
-        qa[t] = max(0, lo - xs);
-        qb[t] = min(8, hi - xs);
-        goff[t] = (unsigned)m * (unsigned)HW1 + (unsigned)xs;
+        const int qa = max(0, lo - xs), qb = min(8, hi - xs);
+        // 16-bit keep mask per half of the piece
+        u4v k;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const unsigned l_ = (2 * d >= qa && 2 * d < qb) ? 0x0000ffffu : 0u;
+          const unsigned h_ = (2 * d + 1 >= qa && 2 * d + 1 < qb) ? 0xffff0000u : 0u;
+          k[d] = l_ | h_;
+        }
+        keep[t] = k;
+        edge_any |= act && (qa > 0 || qb < 8);
+        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + (unsigned)xs);  // bytes inside one plane-row dy
         ldsoff[t] = jx * 64 + sub * 8;
       }
-      int dym = by0 % h2l;
-      dym += (dym < 0) ? h2l : 0;
-      const unsigned rowstride = (unsigned)w2l * (unsigned)HW1;  // elements between consecutive dy (< 2^32)
+      const bool masked = __ballot(edge_any) != 0ull;  // some piece of this wave straddles the image border
+      int dym;
+      if (pow2) dym = by0 & (h2l - 1);
+      else { dym = by0 % h2l; dym += (dym < 0) ? h2l : 0; }
+      dym = __builtin_amdgcn_readfirstlane(dym);
+      const size_t rowstride = (size_t)w2l * HW1;  // elements between consecutive dy
+      const unsigned rowbytes = (unsigned)(2 * rowstride);
 
-      Half8v regs[2];
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-        if (act[t] && jy_lo[t] <= 0) regs[t] = *reinterpret_cast<const Half8v *>(vol + ((unsigned)dym * rowstride + goff[t]));
+      // Buffer resources (raw, bounds-checked): a lane that must not load / store presents an out-of-range offset,
+      // which the memory pipeline drops (loads return zeros).  No branches and no exec changes around the memory
+      // instructions, so every step issues the same instruction sequence and the waits on the loads that were
+      // issued SH_DEPTH steps earlier are exact counts instead of "everything outstanding".
+      constexpr unsigned OOR = 0x80000000u;
+      const _Float16 *vedge = L.vol[lvl] + (size_t)e * h2l * rowstride;  // uniform: this edge, this level
+      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(vedge + (size_t)y1 * w1), 0, (int)((unsigned)h2l * rowbytes - 2u * (unsigned)(y1 * w1)), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rout =
+          __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
 
-      // lanes that stream nothing read row 0 with zero weights: they emit exact zeros (their window is out of
-      // bounds) -- except outliers, whose outputs are left to the gather phase
-      const int rx = inlier ? ox - bx0 : 0, ry = inlier ? oy - by0 : 0;
+      // packed weights and per-lane emission state
+      h2v W00, W01, W10, W11;
+      W00.x = W00.y = P.h00;
+      W01.x = W01.y = P.h01;
+      W10.x = W10.y = P.h10;
+      W11.x = W11.y = P.h11;
+      const bool writes = active && !outlier;
       const _Float16 *tp = stage + rx * 64 + lane;
-      _Float16 prev[WN];
-#pragma unroll
-      for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
 
-      for (int jy = 0; jy < ny; jy++) {
-        const int ty = sy + by0 + jy;
-        const bool rowok = (ty >= 0) && (ty < h2l);
+      auto request = [&](int row, int dy, u4v (&dst)[2]) {  // pieces of plane-row `row` of the union (dy = its plane)
+        const int ty = sy + by0 + row;  // uniform
+        const bool rowok = (row < ny) && (ty >= 0) && (ty < h2l);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-          if (act[t] && jy >= jy_lo[t] && jy < jy_hi[t]) {
-            Half8v v = regs[t];
-            const int a_ = rowok ? qa[t] : 8, b_ = rowok ? qb[t] : 0;
-            if (a_ > 0 || b_ < 8) {
-#pragma unroll
-              for (int q = 0; q < 8; q++)
-                if (q < a_ || q >= b_) v.v[q] = (_Float16)0.f;
-            }
-            *reinterpret_cast<Half8v *>(&stage[ldsoff[t]]) = v;
-          }
+          const bool need = rowok && (((unsigned)row - jlo[t]) < jlen[t]);  // row in [jlo, jlo + jlen)
+          dst[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, need ? goff[t] : OOR, (unsigned)dy * rowbytes, 0);
         }
-        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+      };
+
+      // ring of SH_DEPTH plane-rows in flight: regs[r] is receiving the pieces of row jy with jy % D == r
+      u4v regs[SH_DEPTH][2];
+      int dnext = dym;  // plane (mod h2l) of the next row to request
+#pragma unroll
+      for (int r = 0; r < SH_DEPTH; r++) {
+        request(r, dnext, regs[r]);
+        dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
+      }
+
+      // one plane-row: stage it, request the row SH_DEPTH ahead, read this lane's taps into `cur`, blend with `prev`
+      auto step = [&](int jy, const ShTaps &prev, ShTaps &cur, auto ring) {
+        constexpr int r = decltype(ring)::value;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          u4v v = regs[r][t];
+          if (masked) v &= keep[t];
+          *reinterpret_cast<u4v *>(&stage[ldsoff[t]]) = v;  // rows / pieces nobody needs arrive as zeros
+        }
 #ifndef SH_ABLATE_LOADS
-        if (jy + 1 < ny) {  // next plane-row's lines fly while this one is consumed
-#pragma unroll
-          for (int t = 0; t < 2; t++)
-            if (act[t] && jy + 1 >= jy_lo[t] && jy + 1 < jy_hi[t])
-              regs[t] = *reinterpret_cast<const Half8v *>(vol + ((unsigned)dym * rowstride + goff[t]));
-        }
+        request(jy + SH_DEPTH, dnext, regs[r]);
 #endif
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS row is written before its lanes read it
+        dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
+        // LDS operations of one wave execute in program order: no wait between the row's writes and the tap reads
         __builtin_amdgcn_wave_barrier();
         const int j = jy - ry;
-        if (j >= 0 && j < WN) {
-          _Float16 cur[WN];
+        const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
+        sh_read_taps(tp, cur);
+        const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
 #pragma unroll
-          for (int i = 0; i < WN; i++) cur[i] = tp[i * 64];
-          if (j >= 1 && active && !outlier) {
-            _Float16 *ob = o + (size_t)(j - 1) * HW1;
-#pragma unroll
-            for (int a = 0; a < RD; a++) {
-              const _Float16 acc = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
+        for (int k = 0; k < 4; k++) {
+          h2v acc = prev.e[k] * W00;
+          acc = acc + cur.e[k] * W01;
+          acc = acc + prev.o[k] * W10;
+          acc = acc + cur.o[k] * W11;
+          if (!touches) acc = (h2v)((_Float16)0.f);
+          const unsigned bits = __builtin_bit_cast(unsigned, acc);
+          const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;  // bytes to channel column a = 2k (uniform)
 #ifdef SH_ABLATE_STORES  // ablation builds only (scratch/): keep the value live, store one channel
-              if (a == 0 && j == 1) ob[0] = acc; else asm volatile("" ::"v"(acc));
+          if (k == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0); else asm volatile("" ::"v"(bits));
 #else
-              ob[(size_t)(a * RD) * HW1] = touches ? acc : (_Float16)0.f;
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0);
+          if (k < 3)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, 0);
 #endif
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < WN; i++) prev[i] = cur[i];
         }
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // tap reads done before the next row overwrites the LDS lines
-        __builtin_amdgcn_wave_barrier();
+      };
+
+      ShTaps A, B;
+#pragma unroll
+      for (int k = 0; k < 4; k++) A.e[k] = A.o[k] = B.e[k] = B.o[k] = (h2v)((_Float16)0.f);
+      // unrolled over lcm(2, SH_DEPTH) rows: the two tap-row register sets alternate roles and the ring slot of a
+      // row is a compile-time index.  Rows past ny are requested out of range and emit nothing.
+      constexpr int UNR = (SH_DEPTH % 2 == 0) ? SH_DEPTH : 2 * SH_DEPTH;
+      for (int jy = 0; jy < ny; jy += UNR) {
+        auto body = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          if constexpr (u % 2 == 0) step(jy + u, B, A, std::integral_constant<int, u % SH_DEPTH>{});
+          else step(jy + u, A, B, std::integral_constant<int, u % SH_DEPTH>{});
+        };
+        body(std::integral_constant<int, 0>{});
+        if constexpr (UNR > 1) body(std::integral_constant<int, 1>{});
+        if constexpr (UNR > 2) body(std::integral_constant<int, 2>{});
+        if constexpr (UNR > 3) body(std::integral_constant<int, 3>{});
+        if constexpr (UNR > 4) body(std::integral_constant<int, 4>{});
+        if constexpr (UNR > 5) body(std::integral_constant<int, 5>{});
+        static_assert(UNR <= 6, "SH_DEPTH up to 4");
       }
     }
   }
