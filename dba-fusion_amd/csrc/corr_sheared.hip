@@ -206,6 +206,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "the streaming lookup is written for radius 3");
   __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
+  __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];  // tap rows of lanes that touch nothing
   __shared__ int olist[SH_BLOCK];
   __shared__ int ocount;
   const int lane = threadIdx.x & 63;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   _Float16 *olvl = out + (size_t)lvl * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
   const size_t estride = (size_t)num_levels * RD * RD * HW1;
   if (threadIdx.x == 0) ocount = 0;
+  for (int i = threadIdx.x; i < WN * 64; i += SH_BLOCK) zero_taps[i] = (_Float16)0.f;
   __syncthreads();
 
   if (rowvalid) {
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       W10.x = W10.y = P.h10;
       W11.x = W11.y = P.h11;
       const bool writes = active && !outlier;
-      const _Float16 *tp = stage + rx * 64 + lane;
+      // lanes that touch nothing blend zero taps with zero weights: exact zeros without a select per channel pair
+      const _Float16 *tp = touches ? stage + rx * 64 + lane : zero_taps + lane;
 
       auto request = [&](int row, int dy, u4v (&dst)[2]) {  // pieces of plane-row `row` of the union (dy = its plane)
         const int ty = sy + by0 + row;  // uniform
@@ -385,12 +388,13 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
           acc = acc + cur.e[k] * W01;
           acc = acc + prev.o[k] * W10;
           acc = acc + cur.o[k] * W11;
-          if (!touches) acc = (h2v)((_Float16)0.f);
           const unsigned bits = __builtin_bit_cast(unsigned, acc);
           const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;  // bytes to channel column a = 2k (uniform)
 #ifdef SH_ABLATE_STORES  // ablation builds only (scratch/): keep the value live, store one channel
           if (k == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0); else asm volatile("" ::"v"(bits));
 #else
+          // (the high half goes through an explicit shift: handing the builtin `acc.y` directly makes this compiler
+          // store the LOW half of the packed register)
           __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0);
           if (k < 3)
             __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, 0);
