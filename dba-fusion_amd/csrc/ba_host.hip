@@ -169,14 +169,14 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int ablocks = (N + 3) / 4 + (plan.T.Mmax + 7) / 8;
-  if (ablocks > 0 && plan.P > 0) {
+  if (plan.P <= 0) return DBA_OK;
+  if (!motion_only) {  // Schur products and the pose-block assembly share one launch (both only add into H, b)
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
+                       (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
+    DBA_LAUNCH_CHECK();
+  } else if (ablocks > 0) {
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,
                        N, t0, plan.P, plan.T, plan.W);
-    DBA_LAUNCH_CHECK();
-  }
-  if (!motion_only && plan.P + N > 0 && plan.P > 0) {
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N, SCHUR_KP, SCHUR_CH), dim3(256), 0, (hipStream_t)stream,
-                       ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
     DBA_LAUNCH_CHECK();
   }
   return DBA_OK;
@@ -191,18 +191,25 @@ int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float e
                          plan.W.Lscratch, (hipStream_t)stream);
 }
 
-int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj,
-                  const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int update_poses,
-                  int update_disps, float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream) {
-  (void)ii;
+static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
+                            int ht, int wd, int t0, int t1, int update_poses, int update_disps, float *dz_out,
+                            float *dx_out, void *ws, size_t ws_bytes, dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1);
   hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, jj, frame_owned,
-                     plan.HW, t0, plan.P, update_poses, update_disps, dz_out, plan.T, plan.W);
+                     plan.HW, t0, plan.P, update_poses, update_disps, dz_out, dx_out, plan.T, plan.W);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
+}
+
+int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj,
+                  const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int update_poses,
+                  int update_disps, float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  (void)ii;
+  return ba_update_launch(poses, disps, jj, frame_owned, N, B, ht, wd, t0, t1, update_poses, update_disps, dz_out,
+                          nullptr, ws, ws_bytes, stream);
 }
 
 int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
@@ -225,15 +232,9 @@ int dba_ba(float *poses, float *disps, const float *intrinsics, const float *dis
     rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
     const bool last = (itr == iterations - 1);
-    rc = dba_ba_update(poses, disps, ii, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
-                       last ? dz_out : nullptr, ws, ws_bytes, stream);
+    rc = ba_update_launch(poses, disps, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
+                          last ? dz_out : nullptr, last ? dx_out : nullptr, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
-  }
-  if (dx_out && iterations > 0 && plan.P > 0) {
-    const int n = 6 * plan.P;
-    hipLaunchKernelGGL(ba_copy_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.dx,
-                       dx_out, n);
-    DBA_LAUNCH_CHECK();
   }
   return DBA_OK;
 }

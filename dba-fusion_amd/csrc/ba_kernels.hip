@@ -492,15 +492,15 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
 // pose-block assembly (SparseBlock::update_lhs / update_rhs, :1176-1218, :1457-1462): fold the per-wave
 // J^T W J partials and scatter them into H, b.  blocks [0, ceil(N/4)) take 4 edges each (64 lanes per
 // edge), blocks after that take 8 frame slots each (32 lanes per slot).
-__global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restrict__ ii,
-                                                          const int64_t *__restrict__ jj,
-                                                          const uint8_t *__restrict__ frame_owned, int N,
-                                                          int t0, int P, BaTables T, BaBuffers W) {
+__device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__restrict__ ii,
+                                                  const int64_t *__restrict__ jj,
+                                                  const uint8_t *__restrict__ frame_owned, int N, int t0, int P,
+                                                  const BaTables &T, const BaBuffers &W) {
   const int tid = threadIdx.x;
   const int n6 = 6 * P;
   const int edge_blocks = (N + 3) / 4;
-  if ((int)blockIdx.x < edge_blocks) {
-    const int n = 4 * blockIdx.x + (tid >> 6);
+  if (block < edge_blocks) {
+    const int n = 4 * block + (tid >> 6);
     const int l = tid & 63;
     if (n >= N || l >= 63) return;
     const int src = (int)ii[n];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
     return;
   }
   const int M = T.meta[0];
-  const int m = 8 * ((int)blockIdx.x - edge_blocks) + (tid >> 5);
+  const int m = 8 * (block - edge_blocks) + (tid >> 5);
   const int l = tid & 31;
   if (m >= M || l >= 27) return;
   const int frame = T.kx[m];
@@ -569,10 +569,19 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
   }
 }
 
+__global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restrict__ ii,
+                                                          const int64_t *__restrict__ jj,
+                                                          const uint8_t *__restrict__ frame_owned, int N,
+                                                          int t0, int P, BaTables T, BaBuffers W) {
+  ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, T, W);
+}
+
 // Schur complement (schur_block + EEt6x6_kernel + Ev6x1_kernel, :1046-1138, :1297-1391).
 // grid (P+N rows of E, SCHUR_KP partner slots, SCHUR_CH pixel chunks): workgroup (r1, ks, ch) forms
 // E[r1] diag(Q) E[r2]^T over its pixel chunk for the partners r2 = ks-th, (ks+KP)-th ... row of the same
 // source frame at or after r1 (partner 0 is r1 itself, which also yields the rhs term E Q w).
+// Workgroups with blockIdx.x >= P + N (y = z = 0) do the pose-block assembly instead: both parts only add
+// into H, b, so they share one launch (two launches less per call on a ~300 us step).
 __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict__ ii,
                                                        const int64_t *__restrict__ jj,
                                                        const uint8_t *__restrict__ frame_owned, int N, int HW,
@@ -580,6 +589,10 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
   __shared__ float red[4][44];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n6 = 6 * P;
+  if ((int)blockIdx.x >= P + N) {
+    if (blockIdx.y == 0 && blockIdx.z == 0) ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, T, W);
+    return;
+  }
   const int r1 = blockIdx.x;
   int frame, tgt1;
   if (r1 < P) {
@@ -717,11 +730,14 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
                                                         const int64_t *__restrict__ jj,
                                                         const uint8_t *__restrict__ frame_owned, int HW,
                                                         int t0, int P, int update_poses, int update_disps,
-                                                        float *__restrict__ dz_out, BaTables T,
-                                                        BaBuffers W) {
+                                                        float *__restrict__ dz_out,
+                                                        float *__restrict__ dx_out, BaTables T, BaBuffers W) {
   const int m = blockIdx.y;
   if (m == T.Mmax) {  // pose retraction: T_k <- Exp(dx_k) T_k for k in [t0, t1)
-    if (!update_poses || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    if (dx_out)  // the caller's copy of the last pose update
+      for (int i = threadIdx.x; i < 6 * P; i += blockDim.x) dx_out[i] = W.dx[i];
+    if (!update_poses) return;
     for (int p = threadIdx.x; p < P; p += blockDim.x) retract_pose(poses + 7 * (t0 + p), W.dx + 6 * p);
     return;
   }
