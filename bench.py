@@ -100,8 +100,10 @@ def main():
     poses, disps = poses0.clone(), disps0.clone()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
+    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 1)]
 
     def step(i):
+        ev_step[i].record()
         poses.copy_(poses0)
         disps.copy_(disps0)
         coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
@@ -124,6 +126,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    ev_step[args.warmup + args.steps].record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,6 +181,11 @@ def main():
             with open(pmc) as fh:
                 out["roofline"]["traffic"] = int(json.load(fh)["traffic_bytes_per_launch"])
             out["roofline"]["traffic_source"] = "profiles/r01_pmc_lookup.json"
+        # both units of work, and the spread of the per-step device times (events on the launch stream)
+        out["extra"] = {"gn_iter_per_s": round(2.0 * value, 3),
+                        "edge_lookups_per_s": round(N * value, 1),
+                        "step_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])],
+                        "lookup_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(look_us, [10, 50, 90])]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, corr, fmaps, ii, jj)
         print(json.dumps(out))
