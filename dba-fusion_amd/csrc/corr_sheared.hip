@@ -207,6 +207,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   static_assert(WN == 8, "the streaming lookup is written for radius 3");
   __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
   __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];  // tap rows of lanes that touch nothing
+  __shared__ u4v keep_all[SH_WAVES][2][64];  // per staging slot: 16-bit keep mask per half (image-border pieces)
   __shared__ int olist[SH_BLOCK];
   __shared__ int ocount;
   const int lane = threadIdx.x & 63;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       const int xs = xt * 64 + sub * 8;  // first x1 of this piece
       unsigned goff[2], jlo[2], jlen[2];
       int ldsoff[2];
-      u4v keep[2];
+      u4v *keep = &keep_all[wave][0][lane];  // [t * 64]: parked in LDS, 8 VGPRs less in the streaming loop
       bool edge_any = false;
 #pragma unroll
       for (int t = 0; t < 2; t++) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
           const unsigned h_ = (2 * d + 1 >= qa && 2 * d + 1 < qb) ? 0xffff0000u : 0u;
           k[d] = l_ | h_;
         }
-        keep[t] = k;
+        keep[t * 64] = k;
         edge_any |= act && (qa > 0 || qb < 8);
         goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + (unsigned)xs);  // bytes inside one plane-row dy
         ldsoff[t] = jx * 64 + sub * 8;
@@ -364,12 +365,13 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       }
 
       // one plane-row: stage it, request the row SH_DEPTH ahead, read this lane's taps into `cur`, blend with `prev`
-      auto step = [&](int jy, const ShTaps &prev, ShTaps &cur, auto ring) {
+      auto step = [&](int jy, const ShTaps &prev, ShTaps &cur, auto ring, auto emits) {
         constexpr int r = decltype(ring)::value;
+        constexpr bool EMITS = decltype(emits)::value;  // false for row 0: no lane has a previous tap-row yet
 #pragma unroll
         for (int t = 0; t < 2; t++) {
           u4v v = regs[r][t];
-          if (masked) v &= keep[t];
+          if (masked) v &= keep[t * 64];
           *reinterpret_cast<u4v *>(&stage[ldsoff[t]]) = v;  // rows / pieces nobody needs arrive as zeros
         }
 #ifndef SH_ABLATE_LOADS
@@ -378,27 +380,29 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
         dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
         // LDS operations of one wave execute in program order: no wait between the row's writes and the tap reads
         __builtin_amdgcn_wave_barrier();
-        const int j = jy - ry;
-        const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
         sh_read_taps(tp, cur);
-        const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
+        if constexpr (EMITS) {
+          const int j = jy - ry;
+          const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
+          const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          h2v acc = prev.e[k] * W00;
-          acc = acc + cur.e[k] * W01;
-          acc = acc + prev.o[k] * W10;
-          acc = acc + cur.o[k] * W11;
-          const unsigned bits = __builtin_bit_cast(unsigned, acc);
-          const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;  // bytes to channel column a = 2k (uniform)
+          for (int k = 0; k < 4; k++) {
+            h2v acc = prev.e[k] * W00;
+            acc = acc + cur.e[k] * W01;
+            acc = acc + prev.o[k] * W10;
+            acc = acc + cur.o[k] * W11;
+            const unsigned bits = __builtin_bit_cast(unsigned, acc);
+            const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;  // bytes to channel column a = 2k (uniform)
 #ifdef SH_ABLATE_STORES  // ablation builds only (scratch/): keep the value live, store one channel
-          if (k == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0); else asm volatile("" ::"v"(bits));
+            if (k == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0); else asm volatile("" ::"v"(bits));
 #else
-          // (the high half goes through an explicit shift: handing the builtin `acc.y` directly makes this compiler
-          // store the LOW half of the packed register)
-          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0);
-          if (k < 3)
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, 0);
+            // (the high half goes through an explicit shift: handing the builtin `acc.y` directly makes this compiler
+            // store the LOW half of the packed register)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, 0);
+            if (k < 3)
+              __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, 0);
 #endif
+          }
         }
         __builtin_amdgcn_wave_barrier();
       };
@@ -409,20 +413,22 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       // unrolled over lcm(2, SH_DEPTH) rows: the two tap-row register sets alternate roles and the ring slot of a
       // row is a compile-time index.  Rows past ny are requested out of range and emit nothing.
       constexpr int UNR = (SH_DEPTH % 2 == 0) ? SH_DEPTH : 2 * SH_DEPTH;
-      for (int jy = 0; jy < ny; jy += UNR) {
-        auto body = [&](auto uc) {
-          constexpr int u = decltype(uc)::value;
-          if constexpr (u % 2 == 0) step(jy + u, B, A, std::integral_constant<int, u % SH_DEPTH>{});
-          else step(jy + u, A, B, std::integral_constant<int, u % SH_DEPTH>{});
-        };
-        body(std::integral_constant<int, 0>{});
-        if constexpr (UNR > 1) body(std::integral_constant<int, 1>{});
-        if constexpr (UNR > 2) body(std::integral_constant<int, 2>{});
-        if constexpr (UNR > 3) body(std::integral_constant<int, 3>{});
-        if constexpr (UNR > 4) body(std::integral_constant<int, 4>{});
-        if constexpr (UNR > 5) body(std::integral_constant<int, 5>{});
+      auto body = [&](int jy, auto uc, auto emits) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u % 2 == 0) step(jy + u, B, A, std::integral_constant<int, u % SH_DEPTH>{}, emits);
+        else step(jy + u, A, B, std::integral_constant<int, u % SH_DEPTH>{}, emits);
+      };
+      auto group = [&](int jy, auto first_emits) {
+        body(jy, std::integral_constant<int, 0>{}, first_emits);
+        if constexpr (UNR > 1) body(jy, std::integral_constant<int, 1>{}, std::true_type{});
+        if constexpr (UNR > 2) body(jy, std::integral_constant<int, 2>{}, std::true_type{});
+        if constexpr (UNR > 3) body(jy, std::integral_constant<int, 3>{}, std::true_type{});
+        if constexpr (UNR > 4) body(jy, std::integral_constant<int, 4>{}, std::true_type{});
+        if constexpr (UNR > 5) body(jy, std::integral_constant<int, 5>{}, std::true_type{});
         static_assert(UNR <= 6, "SH_DEPTH up to 4");
-      }
+      };
+      group(0, std::false_type{});  // peeled: row 0 only loads taps (no lane has a previous tap-row yet); ny >= 8 > UNR
+      for (int jy = UNR; jy < ny; jy += UNR) group(jy, std::true_type{});
     }
   }
 
