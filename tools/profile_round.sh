@@ -11,7 +11,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 python $REPO/bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_pmc -o pmc_$(echo $set | cut -c1-5) -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_pmc -o pmc_$(echo $set | cut -c1-5) -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 done
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 python - <<PY
