@@ -182,6 +182,10 @@ def main():
                 out["roofline"]["traffic"] = int(json.load(fh)["traffic_bytes_per_launch"])
             out["roofline"]["traffic_source"] = "profiles/r01_pmc_lookup.json"
         # both units of work, and the spread of the per-step device times (events on the launch stream)
+        ks = range(args.warmup, args.warmup + args.steps)
+        step_us = np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3 if args.steps else np.zeros(1)
+        look_us = (np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in ks]) * 1e3
+                   if corr is not None and args.steps else np.zeros(1))
         out["extra"] = {"gn_iter_per_s": round(2.0 * value, 3),
                         "edge_lookups_per_s": round(N * value, 1),
                         "step_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])],
