@@ -414,8 +414,11 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #pragma unroll
         for (int c = 0; c < 6; c++) {
           Ei[q][c] += wJzu * L[q].Ju[c] + wJzv * L[q].Jv[c];
+#ifndef LIN_ABLATE_ESTORE
           if (active[q]) Eij[(size_t)c * HW] = wJzu * L[q].Ju[6 + c] + wJzv * L[q].Jv[6 + c];
+#endif
         }
+#ifndef LIN_ABLATE_FSUM
         // source-pose terms accumulate in registers across the frame's edges
         int idx = 0;
 #pragma unroll
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #pragma unroll
         for (int a = 0; a < 6; a++)
           fsum[21 + a] += L[q].wu * L[q].ru * L[q].Ju[a] + L[q].wv * L[q].rv * L[q].Jv[a];
+#endif
       }
 
       float acc;
