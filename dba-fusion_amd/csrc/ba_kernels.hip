@@ -280,7 +280,16 @@ struct FrameReduce {  // 27 per-frame sums held in fsum[]
   }
 };
 
-template <int PPL>
+// MF: the cross-lane sums of one edge (12 x 13 block [Hii Hij vi; Hji Hjj vj] = sum over the wave's 128 residual rows of
+// w J^T [J r]) run on the matrix cores: the wave stages its rows transposed in LDS and feeds 32
+// v_mfma_f32_16x16x4_f32 (A = w J^T, B = [J r]); both operands of a lane are the same staged value.  This replaces
+// 63 x (4 flops + one LDS deposit) + 27 x 4 flops per lane and the 17 KB transpose tile by 28 deposits and 8.5 KB.
+typedef float lin_f4 __attribute__((ext_vector_type(4)));
+constexpr int MFS_T = 32;                      // K steps of 4 residual rows
+constexpr int MFS_VALS = 4 * 16 * MFS_T;       // staged [k][i][t]
+constexpr int MFS_FLOATS = MFS_VALS + 4 * MFS_T;  // + weights [k][t]
+
+template <int PPL, bool MF>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const float *__restrict__ poses, const float *__restrict__ disps, const float *__restrict__ intrinsics,
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
@@ -339,9 +348,11 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
   // while the current edge is being reduced.
   __shared__ float s_pose[64][12];  // tij[3], R[9]
   __shared__ int s_edge[64][2];     // edge id, target frame
-  __shared__ __attribute__((aligned(16))) float s_red[4][64 * RED_PITCH];  // per-wave transpose tiles
+  constexpr int RED_FLOATS = MF ? MFS_FLOATS : 64 * RED_PITCH;
+  __shared__ __attribute__((aligned(16))) float s_red[4][RED_FLOATS];  // per-wave transpose tiles / MFMA staging
   float *red_wave = s_red[threadIdx.x >> 6];
   float *red_lane = red_wave + lane;
+  lin_f4 facc = {0.f, 0.f, 0.f, 0.f};  // MF: rows 0..5 of the block (frame sums), accumulated over the edges
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
   for (int batch = e0; batch < e1; batch += 64) {
     const int cnt = min(64, e1 - batch);
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #endif
         }
 #ifndef LIN_ABLATE_FSUM
+        if constexpr (!MF) {
         // source-pose terms accumulate in registers across the frame's edges
         int idx = 0;
 #pragma unroll
@@ -431,10 +443,63 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #pragma unroll
         for (int a = 0; a < 6; a++)
           fsum[21 + a] += L[q].wu * L[q].ru * L[q].Ju[a] + L[q].wv * L[q].rv * L[q].Jv[a];
+        }
 #endif
       }
 
       float acc;
+      if constexpr (MF) {
+        static_assert(!MF || PPL == 1, "the matrix-core reduction is written for one pixel per lane");
+        // stage: residual row kappa = 2 lane + c -> [k = kappa & 3][value i][t = kappa >> 2]
+        {
+          const int t_ = lane >> 1, k0 = 2 * (lane & 1);
+          float *su = red_wave + (k0 * 16) * MFS_T + t_, *sv = su + 16 * MFS_T;
+#pragma unroll
+          for (int i = 0; i < 12; i++) {
+            su[i * MFS_T] = L[0].Ju[i];
+            sv[i * MFS_T] = L[0].Jv[i];
+          }
+          su[12 * MFS_T] = L[0].ru;
+          sv[12 * MFS_T] = L[0].rv;
+          red_wave[MFS_VALS + k0 * MFS_T + t_] = L[0].wu;
+          red_wave[MFS_VALS + (k0 + 1) * MFS_T + t_] = L[0].wv;
+        }
+        wave_lds_fence();
+        lin_f4 c4 = {0.f, 0.f, 0.f, 0.f};
+        {
+          const lin_f4 *xs = reinterpret_cast<const lin_f4 *>(red_wave + ((lane >> 4) * 16 + (lane & 15)) * MFS_T);
+          const lin_f4 *ws = reinterpret_cast<const lin_f4 *>(red_wave + MFS_VALS + (lane >> 4) * MFS_T);
+#pragma unroll
+          for (int t4 = 0; t4 < MFS_T / 4; t4++) {
+            const lin_f4 x = xs[t4], w4 = ws[t4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e] * w4[e], x[e], c4, 0, 0, 0);
+          }
+        }
+        wave_lds_fence();
+        // D: register r <-> row 4 (lane >> 4) + r, column lane & 15.  Rows 6..11 are this edge's Hji | Hjj | vj;
+        // rows 0..5 (Hii | . | vi) add up over the frame's edges.  The 63 edge values go through LDS once more so
+        // that the partial leaves as one coalesced row, in the layout the assembly kernel reads.
+        {
+          const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 4 * g + r;
+            if (row < 6) facc[r] += c4[r];
+            const int a = row - 6;
+            int slot = -1;
+            if (a >= 0 && a < 6) {
+              if (col < 6) slot = a * 6 + col;
+              else if (col < 12) slot = (col - 6 <= a) ? 36 + a * (a + 1) / 2 + (col - 6) : -1;
+              else if (col == 12) slot = 57 + a;
+            }
+            if (slot >= 0) red_wave[slot] = c4[r];
+          }
+        }
+        wave_lds_fence();
+        acc = red_wave[lane];  // lane 63 reads a stale slot: never used
+        wave_lds_fence();
+      } else {
 #ifndef LIN_ABLATE_REDUCE  // ablation builds only (scratch/)
       HjiLoop<PPL, 0, 0>::run(L, red_lane);
       HjjLoop<PPL, 0, 0>::run(L, red_lane);
@@ -445,10 +510,25 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #else
       acc = L[0].Ju[0] + L[0].Jv[7];
 #endif
+      }
       W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
     }
   }
-  {
+  if constexpr (MF) {
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 4 * g + r;
+      int slot = -1;
+      if (row < 6) {
+        if (col <= row) slot = row * (row + 1) / 2 + col;
+        else if (col == 12) slot = 21 + row;
+      }
+      if (slot >= 0) red_wave[slot] = facc[r];
+    }
+    wave_lds_fence();
+    if (lane < HPF_STRIDE) W.HpartF[((size_t)m * nparts + wave_global) * HPF_STRIDE + lane] = red_wave[lane];
+  } else {
     FrameReduce<0>::run(fsum, red_lane);
     wave_lds_fence();
     const float acc = reduce_row(red_wave, lane);
@@ -476,13 +556,16 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
   }
 }
 
-template __global__ void ba_linearize_kernel<1>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<1, true>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
-template __global__ void ba_linearize_kernel<2>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<1, false>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
-template __global__ void ba_linearize_kernel<4>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<2, false>(const float *, const float *, const float *, const float *,
+                                                const float *, const float *, const float *, int, const int64_t *,
+                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+template __global__ void ba_linearize_kernel<4, false>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
 
