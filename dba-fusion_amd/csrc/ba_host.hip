@@ -31,7 +31,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     const long waves1 = (long)Mmax * ((HW + 63) / 64);
     if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4)) ppl = atoi(env);
     else if (waves1 >= 16 * 1024) ppl = 4;
-    else if (waves1 >= 3 * 1024) ppl = 2;  // measured: 25 KF/64x64 (1664 waves) best at 1, 64 KF (4096) at 2
+    else if (waves1 >= 8 * 1024) ppl = 2;  // measured: 25 KF/64x64 (1664 waves) and 64 KF (4096) best at 1 (matrix-core sums)
   }
   const int nchunks = (HW + 256 * ppl - 1) / (256 * ppl);
   const int nparts_max = ((HW + 255) / 256) * 4;  // workspace is sized for ppl = 1
