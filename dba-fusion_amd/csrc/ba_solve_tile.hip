@@ -127,6 +127,22 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
   const int sstart = valid ? max(first[I], first[min(K, T - 1)]) : 0x7fffffff;
   TPROF(0);
 
+  // The owner of a diagonal tile inverts the NEXT 2x2 pivot right after updating it (its dependent chain runs
+  // under the rest of the thread's FMAs) and publishes the inverse with the panel: the readers get P^-1 with one
+  // LDS read instead of each redoing the reciprocal, and the back-substitution finds it in place.
+  auto publish_pinv = [&](int sp, double pa, double pb, double pc) {
+    const double det = fma(-pb, pb, pa * pc);
+    const bool ok = pa > 0.0 && det > 0.0;
+    if (!ok) *fail = 1;  // a non-positive pivot: the verdict is collected after the substitution; keep things finite
+    const double idet = ok ? rcp_nr(det) : 0.0;
+    dbl2 lo;
+    lo.x = pc * idet;
+    lo.y = -pb * idet;
+    *(dbl2 *)(pinv + 4 * sp) = lo;
+    pinv[4 * sp + 2] = pa * idet;
+  };
+  if (valid && I == 0 && K == 0) publish_pinv(0, a[0][0], a[1][0], a[1][1]);
+
   // ---- factorisation: block LDL^T, 2x2 pivots, one barrier per column pair
   for (int Ks = 0; Ks < KT; Ks++) {
     auto step = [&](auto hc) {
@@ -146,18 +162,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
       __syncthreads();
       const bool active = Ks >= sstart && (K > Ks || (K == Ks && h == 0));
       if (active) {
-        const dbl2 pr0 = *(const dbl2 *)(P + 4 * h);      // (a, -)
-        const dbl2 pr1 = *(const dbl2 *)(P + 4 * h + 2);  // (b, c)
+        const dbl2 pv = *(const dbl2 *)(pinv + 4 * s);
+        const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
         dbl2 ri[4], rk[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) ri[r] = *(const dbl2 *)(P + 2 * (4 * (I - Ks) + r));
 #pragma unroll
         for (int c = 0; c < 4; c++) rk[c] = *(const dbl2 *)(P + 2 * (4 * (K - Ks) + c));
-        const double pa = pr0.x, pb = pr1.x, pc = pr1.y;
-        const double det = fma(-pb, pb, pa * pc);
-        // a non-positive pivot is reported by the back-substitution pass; keep the arithmetic finite here
-        const double idet = (pa > 0.0 && det > 0.0) ? rcp_nr(det) : 0.0;
-        const double p00 = pc * idet, p01 = -pb * idet, p11 = pa * idet;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const double u0 = fma(p01, rk[c].y, p00 * rk[c].x);
@@ -166,26 +177,18 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
           for (int r = 0; r < 4; r++) a[r][c] = fma(-ri[r].y, u1, fma(-ri[r].x, u0, a[r][c]));
         }
       }
+      // next pivot: columns j0 + 2, j0 + 3 = the other half of this tile column (h == 0) or the first half of the
+      // next one (h == 1); its owner publishes whether or not this step touched the tile (block-diagonal systems)
+      constexpr int hn = 1 - h;
+      const int Kn = (h == 0) ? Ks : Ks + 1;
+      if (valid && I == Kn && K == Kn && 2 * (s + 1) < n)
+        publish_pinv(s + 1, a[2 * hn][2 * hn], a[2 * hn + 1][2 * hn], a[2 * hn + 1][2 * hn + 1]);
     };
     step(std::integral_constant<int, 0>{});
     if (4 * Ks + 2 < n) step(std::integral_constant<int, 1>{});
   }
   __syncthreads();
   TPROF(1);
-
-  // ---- pivot inverses for the back-substitution (and the SPD verdict), then L^T-side substitution by wave 0
-  for (int s = tid; s < npairs; s += blockDim.x) {
-    const double *P = C + pair_off(s, T) + 4 * (s & 1);
-    const double pa = P[0], pb = P[2], pc = P[3];
-    const double det = fma(-pb, pb, pa * pc);
-    const bool ok = pa > 0.0 && det > 0.0;
-    if (!ok) *fail = 1;
-    const double idet = ok ? rcp_nr(det) : 0.0;
-    pinv[4 * s + 0] = pc * idet;
-    pinv[4 * s + 1] = -pb * idet;
-    pinv[4 * s + 2] = pa * idet;
-  }
-  __syncthreads();
   TPROF(2);
 
   if (wave == 0) {

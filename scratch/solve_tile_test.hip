@@ -53,6 +53,6 @@ int main() {
   hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
   run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
-  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false);
+  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
   run(30, 30, false, false); run(150, 13, true, false); run(2, 2, true, false);
 }

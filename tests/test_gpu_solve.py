@@ -1,0 +1,65 @@
+"""The damped reduced-system solve (csrc/ba_solve_tile.hip, csrc/ba_solve.hip) through the C ABI stage function
+dba_ba_solve, against a float64 Cholesky on the host: dense, block-banded, block-diagonal and non-SPD systems at
+window sizes on both sides of the register-tile kernel's limit (replaces droid_kernels.cu:200-218, :1248-1269)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dbaf_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(rng, P, band, spd=True):
+    n = 6 * P
+    A = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - band + 1), i + 1):
+            A[i, j] = A[j, i] = rng.uniform(-1, 1) / (1 + i - j)
+    A[np.diag_indices(n)] = 6.0 + rng.uniform(0, 2, n)
+    if not spd:
+        A[n // 2, n // 2] = -1.0
+    return A, np.sin(1.3 * np.arange(n))
+
+
+def _solve_on_device(H, b, P, lm, ep):
+    lib = _lib.load()
+    N, B, ht, wd, t0, t1 = 1, P + 2, 8, 8, 1, 1 + P
+    dims = (N, B, ht, wd, t0, t1)
+    nbytes = lib.dba_ba_workspace_bytes(*dims)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    lay = _lib.BaLayout()
+    _lib.check(lib.dba_ba_get_layout(*dims, ctypes.byref(lay)), "dba_ba_get_layout")
+    n = 6 * P
+    ws[lay.H:lay.H + 8 * n * n].view(torch.float64).copy_(torch.from_numpy(H.reshape(-1)).cuda())
+    ws[lay.b:lay.b + 8 * n].view(torch.float64).copy_(torch.from_numpy(b).cuda())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.dba_ba_solve(*dims, lm, ep, ctypes.c_void_p(ws.data_ptr()), nbytes, stream), "dba_ba_solve")
+    torch.cuda.synchronize()
+    dx = ws[lay.dx:lay.dx + 4 * n].view(torch.float32).cpu().numpy().copy()
+    failed = int(ws[lay.meta:lay.meta + 8].view(torch.int32)[1].item())
+    return dx, failed
+
+
+@pytest.mark.parametrize("P,band", [(1, 6), (2, 12), (3, 7), (23, 30), (24, 24), (24, 144), (24, 1), (24, 3), (28, 40),
+                                     (29, 174), (30, 36), (33, 50), (40, 60)])
+def test_solve_matches_host_cholesky(P, band):
+    rng = np.random.default_rng(100 * P + band)
+    H, b = _system(rng, P, band)
+    lm, ep = 1e-4, 0.1
+    Hd = H.copy()
+    Hd[np.diag_indices_from(Hd)] += ep + lm * np.diag(H)  # droid_kernels.cu:1252-1253
+    ref = np.linalg.solve(Hd, b)
+    dx, failed = _solve_on_device(H, b, P, lm, ep)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("P", [5, 24, 29, 33])
+def test_non_spd_system_gives_a_zero_update(P):
+    rng = np.random.default_rng(P)
+    H, b = _system(rng, P, 18, spd=False)
+    dx, failed = _solve_on_device(H, b, P, 1e-4, 0.1)
+    assert failed == 1 and np.all(dx == 0.0)
