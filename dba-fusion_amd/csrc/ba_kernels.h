@@ -6,8 +6,14 @@ namespace dba {
 
 constexpr int HPE_STRIDE = 64;  // floats per per-wave, per-edge partial (63 used: Hji, Hjj, vj)
 constexpr int HPF_STRIDE = 32;  // floats per per-wave, per-frame partial (27 used: Hii, vi)
-constexpr int SCHUR_KP = 8;     // partner slots of the Schur grid
-constexpr int SCHUR_CH = 2;     // pixel chunks of the Schur grid
+#ifndef SCHUR_KP_CFG
+#define SCHUR_KP_CFG 8
+#endif
+#ifndef SCHUR_CH_CFG
+#define SCHUR_CH_CFG 2
+#endif
+constexpr int SCHUR_KP = SCHUR_KP_CFG;     // partner slots of the Schur grid
+constexpr int SCHUR_CH = SCHUR_CH_CFG;     // pixel chunks of the Schur grid
 
 // device index tables (all int32, inside the workspace)
 struct BaTables {
