@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-events", action="store_true",
+                    help="also record one event per step (p10/p50/p90 of the step time; costs ~1 us per step)")
     ap.add_argument("--window", default="25_96", choices=["25_96", "32_122", "64_512"],
                     help="synthetic window (default = BASELINE.json configs[1]; the others are for profiling)")
     args = ap.parse_args()
@@ -103,7 +105,8 @@ def main():
     ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 1)]
 
     def step(i):
-        ev_step[i].record()
+        if args.step_events:
+            ev_step[i].record()
         poses.copy_(poses0)
         disps.copy_(disps0)
         coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
@@ -126,7 +129,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
-    ev_step[args.warmup + args.steps].record()
+    if args.step_events:
+        ev_step[args.warmup + args.steps].record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -183,12 +187,14 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r01_pmc_lookup.json"
         # both units of work, and the spread of the per-step device times (events on the launch stream)
         ks = range(args.warmup, args.warmup + args.steps)
-        step_us = np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3 if args.steps else np.zeros(1)
+        step_us = (np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3
+                   if args.steps and args.step_events else np.zeros(1))
         look_us = (np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in ks]) * 1e3
                    if corr is not None and args.steps else np.zeros(1))
         out["extra"] = {"gn_iter_per_s": round(2.0 * value, 3),
                         "edge_lookups_per_s": round(N * value, 1),
-                        "step_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])],
+                        "step_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])]
+                                                if args.step_events else None),
                         "lookup_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(look_us, [10, 50, 90])]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, corr, fmaps, ii, jj)

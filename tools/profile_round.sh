@@ -6,6 +6,7 @@ set -u
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc   # gpurun merges into an existing gpurun_out/: no stale traces
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 python $REPO/bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
@@ -13,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- pyt
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_pmc -o pmc_$(echo $set | cut -c1-5) -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 done
-cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+cp $(ls -t $(find $OUT/${TAG}_trace -name "*kernel_stats.csv") | head -1) $OUT/${TAG}_kernel_stats.csv
 python - <<PY
 import csv, glob, json, collections
 agg = collections.defaultdict(list)
