@@ -51,6 +51,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const size_t o_eoff = take(sizeof(int) * (size_t)(Mmax + 1));
   const size_t o_elist = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
   const size_t o_erank = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  const size_t o_fpose = take(sizeof(int) * (size_t)(P > 0 ? P : 1));
   L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
@@ -81,6 +82,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->T.eoff = reinterpret_cast<int *>(base + o_eoff);
     plan->T.elist = reinterpret_cast<int *>(base + o_elist);
     plan->T.elist_rank = reinterpret_cast<int *>(base + o_erank);
+    plan->T.fpose = reinterpret_cast<int *>(base + o_fpose);
     plan->T.Mmax = Mmax;
     plan->T.B = B;
     plan->W.E = reinterpret_cast<float *>(base + L.E);
@@ -185,13 +187,21 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   return DBA_OK;
 }
 
-int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
-                 dba_stream_t stream) {
+// graph_skyline: the caller guarantees that H only has the structure of THIS workspace's graph (edges + Schur fill),
+// so the solver may take the skyline from the prepare kernel's table instead of measuring it.  False for systems
+// that were summed over ranks or that came from the host (BACore.optimize: GTSAM priors can couple any two poses).
+static int ba_solve_stage(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
+                          dba_stream_t stream, bool graph_skyline) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  return launch_ba_solve(plan.W.H, plan.W.b, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
-                         plan.W.Lscratch, (hipStream_t)stream);
+  return launch_ba_solve(plan.W.H, plan.W.b, graph_skyline ? plan.T.fpose : nullptr, 6 * plan.P, (double)lm, (double)ep,
+                         plan.W.dx, plan.T.meta, plan.W.Lscratch, (hipStream_t)stream);
+}
+
+int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
+                 dba_stream_t stream) {
+  return ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false);
 }
 
 static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
@@ -232,7 +242,7 @@ int dba_ba(float *poses, float *disps, const float *intrinsics, const float *dis
     if (rc != DBA_OK) return rc;
     rc = dba_ba_reduce(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
-    rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
+    rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true);
     if (rc != DBA_OK) return rc;
     const bool last = (itr == iterations - 1);
     rc = ba_update_launch(poses, disps, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,

@@ -23,6 +23,7 @@ struct BaTables {
   int *eoff;        // [Mmax+1] CSR offsets of the out-edges of slot m
   int *elist;       // [N]      edge ids, ascending within a slot
   int *elist_rank;  // [N]      scratch of the prepare kernel
+  int *fpose;       // [P]      first pose (index - t0) the reduced system couples pose p with (edges + Schur fill)
   int Mmax, B;
 };
 
@@ -70,10 +71,15 @@ __global__ void ba_copy_dx_kernel(const double *src, float *dst, int n);
 __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
 
 // damped float64 Cholesky solve of H x = b, one workgroup
-int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
+// fpose: optional [n/6] skyline of the system at pose granularity (see BaTables); null = measure it from H
+int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof = nullptr);
 bool ba_solve_fits_lds(int n);
 bool ba_solve_tile_supported(int n);
+bool ba_solve_band_supported(int n);
+int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
+                         int *meta,
+                         hipStream_t stream);
 int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                          hipStream_t stream);
 size_t ba_solve_scratch_doubles(int n);

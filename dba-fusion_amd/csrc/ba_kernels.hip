@@ -122,6 +122,33 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     if (!(f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax)) continue;
     T.elist[cnt[flag[f] - 1] + T.elist_rank[n]] = n;
   }
+  // Skyline of the reduced camera system at pose granularity, for the solver: the poses in
+  // S_i = {targets of the edges leaving frame i} U {i} (window poses only) are mutually coupled (pose blocks and the
+  // Schur products E Q E^T of the frame), so fpose[a] = min over the sets containing a of min S_i.
+  __threadfence_block();
+  __syncthreads();
+  const int Mv = min(M, T.Mmax);
+  int *minS = cnt;  // the offsets are in T.eoff by now
+  for (int m = tid; m < Mv; m += nt) {
+    const int pp = T.kx[m] - t0;
+    minS[m] = (pp >= 0 && pp < P) ? pp : 0x7fffffff;
+  }
+  for (int pp = tid; pp < P; pp += nt) T.fpose[pp] = pp;
+  __threadfence_block();
+  __syncthreads();
+  for (int n = tid; n < N; n += nt) {
+    const int f = (int)ii[n], tg = (int)jj[n] - t0;
+    if (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax && tg >= 0 && tg < P) atomicMin(&minS[flag[f] - 1], tg);
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += nt) {
+    const int f = (int)ii[n], tg = (int)jj[n] - t0;
+    if (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax && tg >= 0 && tg < P) atomicMin(&T.fpose[tg], minS[flag[f] - 1]);
+  }
+  for (int m = tid; m < Mv; m += nt) {
+    const int pp = T.kx[m] - t0;
+    if (pp >= 0 && pp < P) atomicMin(&T.fpose[pp], minS[m]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -105,8 +105,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
                                                                  float *__restrict__ dx,
                                                                  int *__restrict__ meta,
                                                                  double *__restrict__ Lglobal,
-                                                                 long long *__restrict__ prof) {
+                                                                 long long *__restrict__ prof, int skip_if_solved) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // queued behind the skyline kernel (ba_solve_band.hip), which leaves meta[3] = 1 when it handled the system
+  if (skip_if_solved && meta[3] != 0) return;
   // layout: [A packed, n+1 rows (LDS mode only)] [rdiag: n] [D: NB*NB] [invd: NB] [rowflag: n+1 ints] [fail]
   const int n1 = n + 1;
   double *A;
@@ -294,12 +296,28 @@ bool ba_solve_fits_lds(int n) {
 
 size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 
-int launch_ba_solve(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
+int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof) {
   if (n <= 0) return DBA_OK;
-  // window-sized systems take the register-tile LDL^T (ba_solve_tile.hip); DBA_SOLVE_GENERAL=1 forces this file's path
-  static const bool force_general = [] { const char *e = getenv("DBA_SOLVE_GENERAL"); return e && e[0] == '1'; }();
-  if (!prof && !force_general && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);
+  // n <= 174 (29 poses): the register-tile kernel (ba_solve_tile.hip).  Above that, up to n = 384, the skyline kernel
+  // (ba_solve_band.hip) tries first; a system whose skyline does not fit one workgroup is left to this file's
+  // kernel, which is queued behind it and returns at once when meta[3] says the system is solved.
+  // DBA_SOLVE_KERNEL = tile | general | band forces a path (tests, comparisons).
+  static const int forced = [] {
+    const char *e = getenv("DBA_SOLVE_KERNEL");
+    if (e && e[0] == 't') return 1;
+    if (e && e[0] == 'g') return 2;
+    if (e && e[0] == 'b') return 3;
+    const char *g = getenv("DBA_SOLVE_GENERAL");
+    return (g && g[0] == '1') ? 2 : 0;
+  }();
+  int chained = 0;
+  if (!prof && forced <= 1 && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);
+  if (!prof && (forced == 0 || forced == 3) && ba_solve_band_supported(n)) {
+    const int rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, stream);
+    if (rc != DBA_OK || ba_solve_tile_supported(n)) return rc;  // n <= 174: the skyline kernel cannot bail out
+    chained = 1;
+  }
   const size_t small = solve_small_bytes(n), packed = solve_packed_bytes(n);
   if (packed + small <= (size_t)SOLVE_MAX_LDS_BYTES) {
     static bool attr_set = false;
@@ -309,11 +327,11 @@ int launch_ba_solve(const double *H, const double *b, int n, double lm, double e
       attr_set = true;
     }
     hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), packed + small, stream, H, b, n,
-                       lm, ep, dx, meta, Lscratch, prof);
+                       lm, ep, dx, meta, Lscratch, prof, chained);
   } else {
     if (!Lscratch) return DBA_ERR_WORKSPACE;
     hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), small, stream, H, b, n, lm, ep,
-                       dx, meta, Lscratch, prof);
+                       dx, meta, Lscratch, prof, chained);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

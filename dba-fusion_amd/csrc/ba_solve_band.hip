@@ -1,0 +1,414 @@
+// Damped solve of the reduced camera system, float64, one workgroup, register tiles allocated INSIDE THE SKYLINE.
+//
+// Replaces the host-side Eigen LLT / SimplicialLLT of the reference
+// (/root/reference/src/droid_kernels.cu:200-218 solveDenseD, :1248-1269 SparseBlock::solve).
+//
+// Same elimination as ba_solve_tile.hip (block LDL^T with 2x2 pivots, raw column pairs published to LDS once, one
+// barrier per pair, the owner of a diagonal tile publishes the next pivot inverse, one wave substitutes at the
+// end), but threads and LDS are handed out only where the matrix can ever be non-zero:
+//   * the skyline (first non-zero column tile of every 4-row tile) is measured on the device; fill-in cannot
+//     leave it.  The right-hand side rides along as a dense last row tile;
+//   * a thread owns one 4 x TW tile inside the skyline.  When twice the tile count fits the workgroup the tiles
+//     are 4 x 2 (half the dependent work per thread and step: 25-KF windows), otherwise 4 x 4;
+//   * a column pair's panel keeps only the rows that can be non-zero below it, so the panels of a 64-KF window
+//     (n = 378, half-bandwidth ~36) fit in LDS (133 KB) where the dense lower triangle (575 KB) does not.
+// A sliding-window system is block-banded, so n up to 384 runs here; a system whose skyline does not fit
+// (1024 tiles, 148 KB of panels) is left untouched, meta[3] stays 0 and the general kernel (ba_solve.hip) takes it.
+#include "ba_kernels.h"
+
+#include <type_traits>
+
+namespace dba {
+
+constexpr int BD_THREADS = 1024;
+constexpr int BD_MAX_N = 384;          // 6 column registers of 64 lanes in the substitution
+constexpr int BD_INTS = 1536;          // first[100] pre[100] hiK[100] poff[196] tinfo[1024] flags[16]
+constexpr int BD_PINV = 4 * (BD_MAX_N / 2);
+constexpr int BD_CAP = (SOLVE_MAX_LDS_BYTES - BD_INTS * 4 - BD_PINV * 8) / 8;  // doubles left for the panels
+
+typedef double bd2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double bd_rcp(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  return y;
+}
+
+__device__ __forceinline__ double bd_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ int bd_wave_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double *__restrict__ H,
+                                                                   const double *__restrict__ bvec,
+                                                                   const int *__restrict__ fpose, int n,
+                                                                   double lm, double ep, float *__restrict__ dx,
+                                                                   int *__restrict__ meta
+#ifdef PROFILE_SOLVE
+                                                                   , long long *__restrict__ prof
+#endif
+                                                                   ) {
+#ifdef PROFILE_SOLVE
+#define BPROF(slot) do { if (threadIdx.x == 0) { long long t_ = wall_clock64(); prof[slot] += t_ - tprev_; tprev_ = t_; } } while (0)
+  long long tprev_ = wall_clock64();
+#else
+#define BPROF(slot)
+#endif
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  int *first = (int *)smem;   // [T]    first non-zero column tile of a row tile (0 for the last, dense one)
+  int *pre = first + 100;     // [T+1]  tiles before row tile I in the allocation order
+  int *hiK = pre + 100;       // [KT]   last banded row tile below column tile K
+  int *poff = hiK + 100;      // [npairs+1] doubles before the panel of a column pair
+  int *tinfo = poff + 196;    // [1024] I | K << 8 | half << 16 | valid << 24
+  int *flags = tinfo + 1024;  // 0: fail, 1: tile width, 2: unsupported
+  double *pinv = smem + BD_INTS / 2;
+  double *C = pinv + BD_PINV;
+
+  const int T = (n + 1 + 3) >> 2, KT = (n + 3) >> 2, npairs = n >> 1, Tl = T - 1;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
+
+  // ---- skyline: every candidate tile of the lower triangle is looked at once
+  if (tid < T) first[tid] = (tid == Tl) ? 0 : min(tid, KT - 1);
+  if (tid < KT) hiK[tid] = tid;
+  if (tid < 16) flags[tid] = 0;
+  __syncthreads();
+  if (fpose) {  // skyline from the graph (ba_prepare_kernel): rows 4I .. 4I+3 belong to at most two poses
+    if (tid < Tl) {
+      const int P = n / 6;
+      const int p0 = (4 * tid) / 6, p1 = min((4 * tid + 3) / 6, P - 1);
+      const int fp = max(0, min(fpose[p0], fpose[p1]));
+      first[tid] = min(first[tid], (6 * fp) >> 2);
+    }
+  } else {      // measured: a wave reads four matrix rows of a tile row at a time, 64 columns per load
+    for (int I = wave; I < Tl; I += nt >> 6) {
+      const int ncol = min(4 * I + 4, n);
+      unsigned long long seen[6];
+#pragma unroll
+      for (int ch = 0; ch < 6; ch++) {
+        const int col = 64 * ch + lane;
+        bool nz = false;
+        if (64 * ch < ncol) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = 4 * I + r;  // (upper entries inside the diagonal tile mirror the lower ones)
+            const double v = (col < ncol && i < n) ? H[(size_t)max(i, col) * n + min(i, col)] : 0.0;
+            nz |= (v != 0.0);
+          }
+        }
+        seen[ch] = __ballot(nz);
+      }
+      int fc = ncol;
+#pragma unroll
+      for (int ch = 5; ch >= 0; ch--)
+        if (seen[ch]) fc = 64 * ch + (int)__builtin_ctzll(seen[ch]);
+      if (lane == 0) first[I] = min(first[I], fc >> 2);
+    }
+  }
+  __syncthreads();
+  BPROF(0);
+  // hiK[K] = last banded row tile whose skyline reaches column tile K
+  if (tid < Tl) {
+    for (int K = first[tid]; K <= min(tid, KT - 1); K++) atomicMax(&hiK[K], tid);
+  }
+  __syncthreads();
+  if (wave == 0) {  // allocation order: banded rows first, the dense last row at the end (T <= 128: two per lane)
+    int c[2], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int I = 2 * lane + q;
+      c[q] = (I < Tl) ? min(I, KT - 1) - first[I] + 1 : 0;
+      tot += c[q];
+    }
+    const int incl = bd_wave_scan(tot, lane);
+    int run = incl - tot;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int I = 2 * lane + q;
+      if (I < Tl) pre[I] = run;
+      run += c[q];
+    }
+    const int total = __shfl(incl, 63, 64) + KT;
+    if (lane == 0) {
+      pre[Tl] = total - KT;
+      pre[T] = total;
+      flags[1] = (2 * total <= nt) ? 2 : 4;
+      if (total > nt) flags[2] = 1;
+    }
+  } else if (wave == 1) {  // panels: rows 4K .. 4 hiK[K] + 3 of the banded part, then the 4 rows of the last tile (+2: skew)
+    int c[3], tot = 0;    // npairs <= 192: three per lane
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int sp = 3 * lane + q;
+      const int Kq = min(sp >> 1, KT - 1);
+      c[q] = (sp < npairs) ? 2 * (4 * (min(hiK[Kq], Tl - 1) - Kq + 1) + 4) + 2 : 0;
+      tot += c[q];
+    }
+    const int incl = bd_wave_scan(tot, lane);
+    int run = 2 + incl - tot;  // C[0..1] stay zero: the substitution reads them for coefficients outside the skyline
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int sp = 3 * lane + q;
+      if (sp < npairs) poff[sp] = run;
+      run += c[q];
+    }
+    const int total = 2 + __shfl(incl, 63, 64);
+    if (lane == 0) {
+      poff[npairs] = total;
+      if (total > BD_CAP) flags[2] = 1;
+    }
+  }
+  for (int e = tid; e < 1024; e += nt) tinfo[e] = 0;
+  __syncthreads();
+  if (flags[2]) {  // skyline too large for one workgroup: the general kernel takes the system
+    if (tid == 0) meta[3] = 0;
+    return;
+  }
+  const int TW = flags[1], halves = 4 / TW;
+  if (tid < Tl) {
+    const int kend = min(tid, KT - 1);
+    for (int K = first[tid]; K <= kend; K++)
+      for (int hh = 0; hh < halves; hh++)
+        tinfo[(pre[tid] + (K - first[tid])) * halves + hh] = tid | (K << 8) | (hh << 16) | (1 << 24);
+  } else if (tid >= 128 && tid < 128 + KT) {
+    const int K = tid - 128;
+    for (int hh = 0; hh < halves; hh++) tinfo[(pre[Tl] + K) * halves + hh] = Tl | (K << 8) | (hh << 16) | (1 << 24);
+  }
+  for (int e = tid; e < poff[npairs]; e += nt) C[e] = 0.0;
+  __syncthreads();
+
+  BPROF(1);
+  // ---- this thread's tile
+  const int info = tinfo[tid];
+  const bool valid = (info >> 24) & 1;
+  const int I = info & 0xff, K = (info >> 8) & 0xff, hh = (info >> 16) & 0xff;
+  const int c0 = (TW == 2) ? 2 * hh : 0;  // first column of the tile inside its 4-column tile
+  double a[4][4];
+  {
+    const double *src[4][4];
+    bool okm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int i = 4 * I + r, k = 4 * K + c0 + c;
+        okm[r][c] = valid && (c < TW) && k < n && i <= n;
+        const double *q = (i == n) ? bvec + k : H + (size_t)max(i, k) * n + min(i, k);  // mirrored upper half on the diagonal
+        src[r][c] = okm[r][c] ? q : H;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) a[r][c] = *src[r][c];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        double v = okm[r][c] ? a[r][c] : 0.0;
+        if (4 * I + r == 4 * K + c0 + c && 4 * I + r < n) v += ep + lm * v;  // damping (:1252-1253)
+        a[r][c] = v;
+      }
+  }
+  const int sstart = valid ? max(first[I], first[K]) : 0x7fffffff;  // (rows 4K.. of the column side live in row tile K)
+  if (wave != 0 && __ballot(valid) == 0ull) return;  // a finished wave no longer counts at the barriers
+  int *fail = flags;
+
+  auto publish_pinv = [&](int sp, double pa, double pb, double pc) {
+    const double det = fma(-pb, pb, pa * pc);
+    const bool ok = pa > 0.0 && det > 0.0;
+    if (!ok) *fail = 1;
+    const double idet = ok ? bd_rcp(det) : 0.0;
+    bd2 lo;
+    lo.x = pc * idet;
+    lo.y = -pb * idet;
+    *(bd2 *)(pinv + 4 * sp) = lo;
+    pinv[4 * sp + 2] = pa * idet;
+  };
+
+  BPROF(2);
+  // ---- factorisation (one instantiation per tile width; the choice is workgroup-uniform)
+  auto factor = [&](auto twc) {
+    constexpr int W = decltype(twc)::value;
+    if (valid && I == 0 && K == 0 && (W == 4 || hh == 0)) publish_pinv(0, a[0][0], a[1][0], a[1][1]);
+    // panel offset and the slot of the last row tile are read one step ahead (they sit on the chain otherwise)
+    int pcur = poff[0], pnxt = 0;
+    int last0 = 4 * (min(hiK[0], Tl - 1) - 0 + 1), lastn = 0;  // panel slot of the first row of the last row tile
+    for (int Ks = 0; Ks < KT; Ks++) {
+      auto step = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        const int s = 2 * Ks + h;
+        double *P = C + pcur;
+        const int si = (I == Tl) ? last0 : 4 * (I - Ks);  // panel slot of this tile's first row
+        if (valid && K == Ks && (W == 4 || hh == h)) {
+          constexpr int cc = (W == 4) ? 2 * h : 0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            bd2 v;
+            v.x = a[r][cc];
+            v.y = a[r][cc + 1];
+            *(bd2 *)(P + 2 * (si + r)) = v;
+          }
+        }
+        __syncthreads();
+        pnxt = poff[min(s + 1, npairs)];
+        if (h == 0) lastn = 4 * (min(hiK[min(Ks + 1, KT - 1)], Tl - 1) - (Ks + 1) + 1);
+        const bool later = (W == 4) ? (h == 0) : (hh == 1 && h == 0);  // columns right of the pair inside column tile Ks
+        const bool active = Ks >= sstart && (K > Ks || (K == Ks && later));
+        if (active) {
+          const bd2 pv = *(const bd2 *)(pinv + 4 * s);
+          const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
+          const int sk = ((K == Tl) ? last0 : 4 * (K - Ks)) + c0;  // panel slot of the tile's first column-side row
+          bd2 ri[4], rk[W];
+#pragma unroll
+          for (int r = 0; r < 4; r++) ri[r] = *(const bd2 *)(P + 2 * (si + r));
+#pragma unroll
+          for (int c = 0; c < W; c++) rk[c] = *(const bd2 *)(P + 2 * (sk + c));
+#pragma unroll
+          for (int c = 0; c < W; c++) {
+            const double u0 = fma(p01, rk[c].y, p00 * rk[c].x);
+            const double u1 = fma(p11, rk[c].y, p01 * rk[c].x);
+#pragma unroll
+            for (int r = 0; r < 4; r++) a[r][c] = fma(-ri[r].y, u1, fma(-ri[r].x, u0, a[r][c]));
+          }
+        }
+        // the owner of the next pivot publishes its inverse (whether or not this step touched the tile)
+        constexpr int hn = 1 - h;
+        const int Kn = (h == 0) ? Ks : Ks + 1;
+        if (valid && I == Kn && K == Kn && 2 * (s + 1) < n && (W == 4 || hh == hn)) {
+          constexpr int pc0 = (W == 4) ? 2 * hn : 0;
+          publish_pinv(s + 1, a[2 * hn][pc0], a[2 * hn + 1][pc0], a[2 * hn + 1][pc0 + 1]);
+        }
+        pcur = pnxt;
+      };
+      step(std::integral_constant<int, 0>{});
+      if (4 * Ks + 2 < n) step(std::integral_constant<int, 1>{});
+      last0 = lastn;
+    }
+  };
+  if (TW == 2) factor(std::integral_constant<int, 2>{});
+  else factor(std::integral_constant<int, 4>{});
+  __syncthreads();
+  BPROF(3);
+
+  // ---- L^T-side block substitution by wave 0: lane l holds t_j for the columns j = l + 64 r, r < 6
+  if (wave != 0) return;
+  constexpr int RMAX = BD_MAX_N / 64;
+  double t[RMAX], xo[RMAX];
+  int cb[RMAX], cl[RMAX];  // C(i, j) = C[cb + 2 i] for banded rows i, C[cl + 2 i] for rows of the last tile
+  const int Rn = (n + 63) >> 6;
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    const int j = lane + 64 * r;
+    const int jc = (j < n) ? j : 0;
+    const int Kc = jc >> 2;
+    cb[r] = poff[jc >> 1] - 8 * Kc + (jc & 1);
+    cl[r] = poff[jc >> 1] + 8 * (min(hiK[Kc], Tl - 1) - Kc + 1) - 8 * Tl + (jc & 1);
+    t[r] = (j < n) ? C[cl[r] + 2 * n] : 0.0;
+    xo[r] = 0.0;
+  }
+  auto sweep = [&](auto rc) {
+    constexpr int r0 = decltype(rc)::value;
+    const int shi = min(npairs, 32 * (r0 + 1)) - 1, slo = 32 * r0;
+    struct Ops { double l0[r0 + 1], l1[r0 + 1], p[3]; };
+    auto fetch = [&](int s, Ops &o) {
+      const int sc = max(s, 0), Is = sc >> 1;  // row tile of the pivot rows 2 sc, 2 sc + 1
+      const int jlo = 4 * first[Is];           // columns left of it that the rows can touch
+#pragma unroll
+      for (int r = 0; r <= r0; r++) {
+        const int j = lane + 64 * r;
+        const bool in = (j >= jlo) && (j < 2 * sc);
+        const int base = (Is == Tl) ? cl[r] : cb[r];
+        const double *q = C + (in ? base + 4 * sc : 0);  // outside the skyline: the zero pair at C[0]
+        o.l0[r] = q[0];
+        o.l1[r] = in ? q[2] : 0.0;
+      }
+      o.p[0] = pinv[4 * sc], o.p[1] = pinv[4 * sc + 1], o.p[2] = pinv[4 * sc + 2];
+    };
+    auto pin = [&](Ops &o) {  // keeps the prefetch where it was issued
+#pragma unroll
+      for (int r = 0; r <= r0; r++) asm volatile("" : "+v"(o.l0[r]), "+v"(o.l1[r]));
+      asm volatile("" : "+v"(o.p[0]), "+v"(o.p[1]), "+v"(o.p[2]));
+    };
+    auto solve_step = [&](int s, const Ops &o) {
+      const int l0 = (2 * s) & 63;
+      const double t0 = bd_readlane(t[r0], l0), t1 = bd_readlane(t[r0], l0 + 1);
+      const double x0 = fma(o.p[1], t1, o.p[0] * t0), x1 = fma(o.p[2], t1, o.p[1] * t0);
+#pragma unroll
+      for (int r = 0; r <= r0; r++) t[r] = fma(-o.l1[r], x1, fma(-o.l0[r], x0, t[r]));
+      xo[r0] = (lane == l0) ? x0 : ((lane == l0 + 1) ? x1 : xo[r0]);
+    };
+    // several steps per LDS round trip (four while the register budget allows it)
+    constexpr int CH = (r0 <= 2) ? 4 : 2;
+    for (int s = shi; s >= slo; s -= CH) {
+      Ops o[CH];
+#pragma unroll
+      for (int q = 0; q < CH; q++) fetch(s - q, o[q]);
+#pragma unroll
+      for (int q = 0; q < CH; q++) pin(o[q]);
+#pragma unroll
+      for (int q = 0; q < CH; q++)
+        if (s - q >= slo) solve_step(s - q, o[q]);
+    }
+  };
+  if (Rn > 5) sweep(std::integral_constant<int, 5>{});
+  if (Rn > 4) sweep(std::integral_constant<int, 4>{});
+  if (Rn > 3) sweep(std::integral_constant<int, 3>{});
+  if (Rn > 2) sweep(std::integral_constant<int, 2>{});
+  if (Rn > 1) sweep(std::integral_constant<int, 1>{});
+  sweep(std::integral_constant<int, 0>{});
+
+  // non-finite results count as failure too; failure => zero update (:1263-1266)
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < RMAX; r++)
+    if (lane + 64 * r < n && !isfinite(xo[r])) bad = true;
+  const int failed = (*fail != 0) || (__ballot(bad) != 0ull);
+#pragma unroll
+  for (int r = 0; r < RMAX; r++) {
+    const int j = lane + 64 * r;
+    if (j < n) dx[j] = failed ? 0.f : (float)xo[r];
+  }
+  BPROF(4);
+  if (lane == 0) {
+    meta[1] = failed;
+    meta[3] = 1;  // solved here: the general kernel queued behind this one returns at once
+  }
+}
+
+bool ba_solve_band_supported(int n) { return n > 0 && !(n & 1) && n <= BD_MAX_N; }
+
+int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
+                         int *meta, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+    attr_set = true;
+  }
+#ifdef PROFILE_SOLVE
+  extern long long *g_band_prof;
+  hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
+                     dx, meta, g_band_prof);
+#else
+  hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
+                     dx, meta);
+#endif
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+}  // namespace dba

@@ -9,6 +9,8 @@ namespace dba { long long *g_tile_prof; }
 #include "../dba-fusion_amd/csrc/ba_solve.hip"
 #include "../dba-fusion_amd/csrc/ba_solve_tile.hip"
 #include "ba_solve_mfma_experiment.hip"
+namespace dba { long long *g_band_prof; }
+#include "../dba-fusion_amd/csrc/ba_solve_band.hip"
 namespace dba { void set_last_error(const char*, hipError_t) {} }
 static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
   for (int j = 0; j < n; j++) {
@@ -30,29 +32,28 @@ int run(int n, int band, bool spd, bool timeit) {
   double *dH, *db; float* dx; int* meta;
   hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64);
   hipMemcpy(dH, H.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
-  if (!dba::ba_solve_mfma_supported(n)) { printf("n=%d unsupported by mfma\n", n); return 0; }
-  dba::launch_ba_solve_mfma(dH, db, n, lm, ep, dx, meta, 0);
+  dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, 0);
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("n=%d launch error %s\n", n, hipGetErrorString(e)); return 1; }
   std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
-  if (timeit) { long long hp[12]; hipMemcpy(hp, dba::g_mfma_prof, 96, hipMemcpyDeviceToHost); printf("   ticks(10ns): load %lld factor(rest) %lld backsub %lld | barrier %lld jobs %lld pinv %lld pk %lld apply %lld\n", hp[0],hp[1],hp[2],hp[4],hp[5],hp[6],hp[7],hp[8]); }
-  hipMemset(dba::g_mfma_prof, 0, 128);
+  if (timeit) { long long hp[12]; hipMemcpy(hp, dba::g_band_prof, 96, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld\n", hp[0],hp[1],hp[2],hp[3],hp[4]); }
+  hipMemset(dba::g_band_prof, 0, 128);
   if (timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 3; mode++) {
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_mfma(dH, db, n, lm, ep, dx, meta, 0); else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, 0); else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
-      printf("   %s: %.2f us per solve\n", mode == 0 ? "mfma " : mode == 2 ? "tile " : "block", ms*1000/200);
+      printf("   %s: %.2f us per solve\n", mode == 0 ? "band " : mode == 2 ? "tile " : "block", ms*1000/200);
     }
   }
   return 0;
 }
 int main() {
-  hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128);
+  hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 128); hipMemset(dba::g_band_prof, 0, 128);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
   run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
-  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
+  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(186, 36, true, true); run(240, 36, true, true); run(378, 36, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
   run(30, 30, false, false); run(150, 13, true, false); run(2, 2, true, false);
 }

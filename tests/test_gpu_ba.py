@@ -218,9 +218,11 @@ def test_ba_general_size_solver_path_matches_too():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DBA_SOLVE_GENERAL="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_ba.py"),
-                        "-k", "matches_oracle or cholesky_failure"], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for kernel in ("general", "band"):  # the skyline kernel (csrc/ba_solve_band.hip) serves 30..64-pose windows by default
+        env = dict(os.environ, DBA_SOLVE_KERNEL=kernel)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                            os.path.join(here, "test_gpu_ba.py"), os.path.join(here, "test_gpu_solve.py"),
+                            "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, kernel + r.stdout[-2000:] + r.stderr[-2000:]

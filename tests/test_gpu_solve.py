@@ -44,7 +44,7 @@ def _solve_on_device(H, b, P, lm, ep):
 
 
 @pytest.mark.parametrize("P,band", [(1, 6), (2, 12), (3, 7), (23, 30), (24, 24), (24, 144), (24, 1), (24, 3), (28, 40),
-                                     (29, 174), (30, 36), (33, 50), (40, 60)])
+                                     (29, 174), (30, 36), (33, 50), (40, 60), (63, 36), (63, 18), (64, 40), (63, 378), (50, 300), (45, 1), (64, 5)])
 def test_solve_matches_host_cholesky(P, band):
     rng = np.random.default_rng(100 * P + band)
     H, b = _system(rng, P, band)
@@ -57,7 +57,7 @@ def test_solve_matches_host_cholesky(P, band):
     np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("P", [5, 24, 29, 33])
+@pytest.mark.parametrize("P", [5, 24, 29, 33, 63])
 def test_non_spd_system_gives_a_zero_update(P):
     rng = np.random.default_rng(P)
     H, b = _system(rng, P, 18, spd=False)
