@@ -22,7 +22,10 @@ namespace dba {
 
 constexpr int BD_THREADS = 1024;
 constexpr int BD_MAX_N = 384;          // 6 column registers of 64 lanes in the substitution
-constexpr int BD_INTS = 1536;          // first[100] pre[100] hiK[100] poff[196] tinfo[1024] flags[16]
+constexpr int BD_TILES = 1536;         // tile slots: 1024 threads x 1 tile, or 512 threads x 3 tiles (BD_BIG_*)
+constexpr int BD_BIG_THREADS = 512;    // the many-tile variant: 256 VGPRs per thread
+constexpr int BD_BIG_SLOTS = 3;
+constexpr int BD_INTS = 2048;          // first[100] pre[100] hiK[100] poff[196] tinfo[1536] flags[16]
 constexpr int BD_PINV = 4 * (BD_MAX_N / 2);
 constexpr int BD_CAP = (SOLVE_MAX_LDS_BYTES - BD_INTS * 4 - BD_PINV * 8) / 8;  // doubles left for the panels
 
@@ -53,11 +56,16 @@ __device__ __forceinline__ int bd_wave_scan(int v, int lane) {
   return v;
 }
 
-__global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double *__restrict__ H,
-                                                                   const double *__restrict__ bvec,
-                                                                   const int *__restrict__ fpose, int n,
-                                                                   double lm, double ep, float *__restrict__ dx,
-                                                                   int *__restrict__ meta
+// THREADS x SLOTS tiles.  GP: the column-pair panels live in global memory (G, zero-filled here) for the
+// substitution and only the pair being eliminated is kept in LDS (double-buffered), for skylines whose panels exceed
+// LDS; such systems also need more than 1024 tiles, hence several tiles per thread and fewer, fatter threads.
+template <int THREADS, int SLOTS, bool GP>
+__global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__restrict__ H,
+                                                                const double *__restrict__ bvec,
+                                                                const int *__restrict__ fpose, int n,
+                                                                double lm, double ep, float *__restrict__ dx,
+                                                                int *__restrict__ meta, double *__restrict__ G,
+                                                                int gcap
 #ifdef PROFILE_SOLVE
                                                                    , long long *__restrict__ prof
 #endif
@@ -73,13 +81,14 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
   int *pre = first + 100;     // [T+1]  tiles before row tile I in the allocation order
   int *hiK = pre + 100;       // [KT]   last banded row tile below column tile K
   int *poff = hiK + 100;      // [npairs+1] doubles before the panel of a column pair
-  int *tinfo = poff + 196;    // [1024] I | K << 8 | half << 16 | valid << 24
-  int *flags = tinfo + 1024;  // 0: fail, 1: tile width, 2: unsupported
+  int *tinfo = poff + 196;    // [1536] I | K << 8 | half << 16 | valid << 24
+  int *flags = tinfo + BD_TILES;  // 0: fail, 1: tile width, 2: unsupported, 3: doubles of the largest panel
   double *pinv = smem + BD_INTS / 2;
   double *C = pinv + BD_PINV;
 
   const int T = (n + 1 + 3) >> 2, KT = (n + 3) >> 2, npairs = n >> 1, Tl = T - 1;
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (GP && meta[3] != 0) return;  // queued behind the one-tile-per-thread variant, which solved the system
   const int wave = tid >> 6, lane = tid & 63;
 
   // ---- skyline: every candidate tile of the lower triangle is looked at once
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
     if (lane == 0) {
       pre[Tl] = total - KT;
       pre[T] = total;
-      flags[1] = (2 * total <= nt) ? 2 : 4;
-      if (total > nt) flags[2] = 1;
+      flags[1] = (SLOTS == 1 && 2 * total <= nt) ? 2 : 4;
+      if (total > nt * SLOTS) flags[2] = 1;
     }
   } else if (wave == 1) {  // panels: rows 4K .. 4 hiK[K] + 3 of the banded part, then the 4 rows of the last tile (+2: skew)
     int c[3], tot = 0;    // npairs <= 192: three per lane
@@ -158,6 +167,9 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
       c[q] = (sp < npairs) ? 2 * (4 * (min(hiK[Kq], Tl - 1) - Kq + 1) + 4) + 2 : 0;
       tot += c[q];
     }
+    int big = max(c[0], max(c[1], c[2]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) big = max(big, __shfl_xor(big, off, 64));
     const int incl = bd_wave_scan(tot, lane);
     int run = 2 + incl - tot;  // C[0..1] stay zero: the substitution reads them for coefficients outside the skyline
 #pragma unroll
@@ -169,10 +181,11 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
     const int total = 2 + __shfl(incl, 63, 64);
     if (lane == 0) {
       poff[npairs] = total;
-      if (total > BD_CAP) flags[2] = 1;
+      flags[3] = big;
+      if (GP ? (total > gcap || 2 * big > BD_CAP) : (total > BD_CAP)) flags[2] = 1;
     }
   }
-  for (int e = tid; e < 1024; e += nt) tinfo[e] = 0;
+  for (int e = tid; e < BD_TILES; e += nt) tinfo[e] = 0;
   __syncthreads();
   if (flags[2]) {  // skyline too large for one workgroup: the general kernel takes the system
     if (tid == 0) meta[3] = 0;
@@ -188,44 +201,64 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
     const int K = tid - 128;
     for (int hh = 0; hh < halves; hh++) tinfo[(pre[Tl] + K) * halves + hh] = Tl | (K << 8) | (hh << 16) | (1 << 24);
   }
-  for (int e = tid; e < poff[npairs]; e += nt) C[e] = 0.0;
+  if (GP) {
+    for (int e = tid; e < poff[npairs]; e += nt) G[e] = 0.0;
+    __threadfence_block();
+  } else {
+    for (int e = tid; e < poff[npairs]; e += nt) C[e] = 0.0;
+  }
   __syncthreads();
 
   BPROF(1);
-  // ---- this thread's tile
-  const int info = tinfo[tid];
-  const bool valid = (info >> 24) & 1;
-  const int I = info & 0xff, K = (info >> 8) & 0xff, hh = (info >> 16) & 0xff;
-  const int c0 = (TW == 2) ? 2 * hh : 0;  // first column of the tile inside its 4-column tile
-  double a[4][4];
+  // ---- this thread's tiles (slot q: allocation index tid + q * THREADS)
+  bool valid[SLOTS];
+  int I[SLOTS], K[SLOTS], sstart[SLOTS];
+  double a[SLOTS][4][4];
+  const int hh = (tinfo[tid] >> 16) & 0xff;       // half tiles exist only with one slot
+  const int c0 = (TW == 2) ? 2 * hh : 0;          // first column of the tile inside its 4-column tile
+  bool anyvalid = false;
   {
-    const double *src[4][4];
-    bool okm[4][4];
+    const double *src[SLOTS][4][4];
+    bool okm[SLOTS][4][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int q = 0; q < SLOTS; q++) {
+      const int info = tinfo[tid + q * THREADS];
+      valid[q] = (info >> 24) & 1;
+      I[q] = info & 0xff, K[q] = (info >> 8) & 0xff;
+      anyvalid |= valid[q];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int i = 4 * I + r, k = 4 * K + c0 + c;
-        okm[r][c] = valid && (c < TW) && k < n && i <= n;
-        const double *q = (i == n) ? bvec + k : H + (size_t)max(i, k) * n + min(i, k);  // mirrored upper half on the diagonal
-        src[r][c] = okm[r][c] ? q : H;
-      }
+      for (int r = 0; r < 4; r++)
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+          const int i = 4 * I[q] + r, k = 4 * K[q] + c0 + c;
+          okm[q][r][c] = valid[q] && (c < TW) && k < n && i <= n;
+          const double *src_ = (i == n) ? bvec + k : H + (size_t)max(i, k) * n + min(i, k);  // mirrored upper half on the diagonal
+          src[q][r][c] = okm[q][r][c] ? src_ : H;
+        }
+    }
 #pragma unroll
-      for (int c = 0; c < 4; c++) a[r][c] = *src[r][c];
+    for (int q = 0; q < SLOTS; q++)
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        double v = okm[r][c] ? a[r][c] : 0.0;
-        if (4 * I + r == 4 * K + c0 + c && 4 * I + r < n) v += ep + lm * v;  // damping (:1252-1253)
-        a[r][c] = v;
-      }
+        for (int c = 0; c < 4; c++) a[q][r][c] = *src[q][r][c];
+#pragma unroll
+    for (int q = 0; q < SLOTS; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          double v = okm[q][r][c] ? a[q][r][c] : 0.0;
+          if (4 * I[q] + r == 4 * K[q] + c0 + c && 4 * I[q] + r < n) v += ep + lm * v;  // damping (:1252-1253)
+          a[q][r][c] = v;
+        }
+#pragma unroll
+    for (int q = 0; q < SLOTS; q++)  // (rows 4K.. of the column side live in row tile K)
+      sstart[q] = valid[q] ? max(first[I[q]], first[K[q]]) : 0x7fffffff;
   }
-  const int sstart = valid ? max(first[I], first[K]) : 0x7fffffff;  // (rows 4K.. of the column side live in row tile K)
-  if (wave != 0 && __ballot(valid) == 0ull) return;  // a finished wave no longer counts at the barriers
+  if (wave != 0 && __ballot(anyvalid) == 0ull) return;  // a finished wave no longer counts at the barriers
   int *fail = flags;
+  const int pmax = flags[3];  // GP: doubles per LDS panel buffer
 
   auto publish_pinv = [&](int sp, double pa, double pb, double pc) {
     const double det = fma(-pb, pb, pa * pc);
@@ -243,7 +276,9 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
   // ---- factorisation (one instantiation per tile width; the choice is workgroup-uniform)
   auto factor = [&](auto twc) {
     constexpr int W = decltype(twc)::value;
-    if (valid && I == 0 && K == 0 && (W == 4 || hh == 0)) publish_pinv(0, a[0][0], a[1][0], a[1][1]);
+#pragma unroll
+    for (int q = 0; q < SLOTS; q++)
+      if (valid[q] && I[q] == 0 && K[q] == 0 && (W == 4 || hh == 0)) publish_pinv(0, a[q][0][0], a[q][1][0], a[q][1][1]);
     // panel offset and the slot of the last row tile are read one step ahead (they sit on the chain otherwise)
     int pcur = poff[0], pnxt = 0;
     int last0 = 4 * (min(hiK[0], Tl - 1) - 0 + 1), lastn = 0;  // panel slot of the first row of the last row tile
@@ -251,46 +286,57 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
       auto step = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         const int s = 2 * Ks + h;
-        double *P = C + pcur;
-        const int si = (I == Tl) ? last0 : 4 * (I - Ks);  // panel slot of this tile's first row
-        if (valid && K == Ks && (W == 4 || hh == h)) {
-          constexpr int cc = (W == 4) ? 2 * h : 0;
+        double *P = GP ? C + (s & 1) * pmax : C + pcur;  // the pair being eliminated (LDS)
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            bd2 v;
-            v.x = a[r][cc];
-            v.y = a[r][cc + 1];
-            *(bd2 *)(P + 2 * (si + r)) = v;
+        for (int q = 0; q < SLOTS; q++) {
+          if (valid[q] && K[q] == Ks && (W == 4 || hh == h)) {
+            const int si = (I[q] == Tl) ? last0 : 4 * (I[q] - Ks);  // panel slot of this tile's first row
+            constexpr int cc = (W == 4) ? 2 * h : 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              bd2 v;
+              v.x = a[q][r][cc];
+              v.y = a[q][r][cc + 1];
+              *(bd2 *)(P + 2 * (si + r)) = v;
+              if (GP) *(bd2 *)(G + pcur + 2 * (si + r)) = v;  // kept for the substitution
+            }
           }
         }
         __syncthreads();
         pnxt = poff[min(s + 1, npairs)];
         if (h == 0) lastn = 4 * (min(hiK[min(Ks + 1, KT - 1)], Tl - 1) - (Ks + 1) + 1);
         const bool later = (W == 4) ? (h == 0) : (hh == 1 && h == 0);  // columns right of the pair inside column tile Ks
-        const bool active = Ks >= sstart && (K > Ks || (K == Ks && later));
-        if (active) {
-          const bd2 pv = *(const bd2 *)(pinv + 4 * s);
-          const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
-          const int sk = ((K == Tl) ? last0 : 4 * (K - Ks)) + c0;  // panel slot of the tile's first column-side row
-          bd2 ri[4], rk[W];
+        const bd2 pv = *(const bd2 *)(pinv + 4 * s);
+        const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
 #pragma unroll
-          for (int r = 0; r < 4; r++) ri[r] = *(const bd2 *)(P + 2 * (si + r));
+        for (int q = 0; q < SLOTS; q++) {
+          const bool active = Ks >= sstart[q] && (K[q] > Ks || (K[q] == Ks && later));
+          if (active) {
+            const int si = (I[q] == Tl) ? last0 : 4 * (I[q] - Ks);
+            const int sk = ((K[q] == Tl) ? last0 : 4 * (K[q] - Ks)) + c0;  // panel slot of the tile's first column-side row
+            bd2 ri[4], rk[W];
 #pragma unroll
-          for (int c = 0; c < W; c++) rk[c] = *(const bd2 *)(P + 2 * (sk + c));
+            for (int r = 0; r < 4; r++) ri[r] = *(const bd2 *)(P + 2 * (si + r));
 #pragma unroll
-          for (int c = 0; c < W; c++) {
-            const double u0 = fma(p01, rk[c].y, p00 * rk[c].x);
-            const double u1 = fma(p11, rk[c].y, p01 * rk[c].x);
+            for (int c = 0; c < W; c++) rk[c] = *(const bd2 *)(P + 2 * (sk + c));
 #pragma unroll
-            for (int r = 0; r < 4; r++) a[r][c] = fma(-ri[r].y, u1, fma(-ri[r].x, u0, a[r][c]));
+            for (int c = 0; c < W; c++) {
+              const double u0 = fma(p01, rk[c].y, p00 * rk[c].x);
+              const double u1 = fma(p11, rk[c].y, p01 * rk[c].x);
+#pragma unroll
+              for (int r = 0; r < 4; r++) a[q][r][c] = fma(-ri[r].y, u1, fma(-ri[r].x, u0, a[q][r][c]));
+            }
           }
         }
         // the owner of the next pivot publishes its inverse (whether or not this step touched the tile)
         constexpr int hn = 1 - h;
         const int Kn = (h == 0) ? Ks : Ks + 1;
-        if (valid && I == Kn && K == Kn && 2 * (s + 1) < n && (W == 4 || hh == hn)) {
-          constexpr int pc0 = (W == 4) ? 2 * hn : 0;
-          publish_pinv(s + 1, a[2 * hn][pc0], a[2 * hn + 1][pc0], a[2 * hn + 1][pc0 + 1]);
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++) {
+          if (valid[q] && I[q] == Kn && K[q] == Kn && 2 * (s + 1) < n && (W == 4 || hh == hn)) {
+            constexpr int pc0 = (W == 4) ? 2 * hn : 0;
+            publish_pinv(s + 1, a[q][2 * hn][pc0], a[q][2 * hn + 1][pc0], a[q][2 * hn + 1][pc0 + 1]);
+          }
         }
         pcur = pnxt;
       };
@@ -299,13 +345,15 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
       last0 = lastn;
     }
   };
-  if (TW == 2) factor(std::integral_constant<int, 2>{});
+  if (SLOTS == 1 && TW == 2) factor(std::integral_constant<int, 2>{});
   else factor(std::integral_constant<int, 4>{});
+  if (GP) __threadfence_block();
   __syncthreads();
   BPROF(3);
 
   // ---- L^T-side block substitution by wave 0: lane l holds t_j for the columns j = l + 64 r, r < 6
   if (wave != 0) return;
+  const double *Cs = GP ? G : C;  // all published panels
   constexpr int RMAX = BD_MAX_N / 64;
   double t[RMAX], xo[RMAX];
   int cb[RMAX], cl[RMAX];  // C(i, j) = C[cb + 2 i] for banded rows i, C[cl + 2 i] for rows of the last tile
@@ -317,7 +365,7 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
     const int Kc = jc >> 2;
     cb[r] = poff[jc >> 1] - 8 * Kc + (jc & 1);
     cl[r] = poff[jc >> 1] + 8 * (min(hiK[Kc], Tl - 1) - Kc + 1) - 8 * Tl + (jc & 1);
-    t[r] = (j < n) ? C[cl[r] + 2 * n] : 0.0;
+    t[r] = (j < n) ? Cs[cl[r] + 2 * n] : 0.0;
     xo[r] = 0.0;
   }
   auto sweep = [&](auto rc) {
@@ -332,7 +380,7 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
         const int j = lane + 64 * r;
         const bool in = (j >= jlo) && (j < 2 * sc);
         const int base = (Is == Tl) ? cl[r] : cb[r];
-        const double *q = C + (in ? base + 4 * sc : 0);  // outside the skyline: the zero pair at C[0]
+        const double *q = Cs + (in ? base + 4 * sc : 0);  // outside the skyline: the zero pair at the start
         o.l0[r] = q[0];
         o.l1[r] = in ? q[2] : 0.0;
       }
@@ -352,7 +400,7 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
       xo[r0] = (lane == l0) ? x0 : ((lane == l0 + 1) ? x1 : xo[r0]);
     };
     // several steps per LDS round trip (four while the register budget allows it)
-    constexpr int CH = (r0 <= 2) ? 4 : 2;
+    constexpr int CH = GP ? 4 : ((r0 <= 2) ? 4 : 2);
     for (int s = shi; s >= slo; s -= CH) {
       Ops o[CH];
 #pragma unroll
@@ -391,22 +439,35 @@ __global__ __launch_bounds__(BD_THREADS) void ba_solve_band_kernel(const double 
 
 bool ba_solve_band_supported(int n) { return n > 0 && !(n & 1) && n <= BD_MAX_N; }
 
+#ifdef PROFILE_SOLVE
+#define BD_PROF_ARG , g_band_prof
+extern long long *g_band_prof;
+#else
+#define BD_PROF_ARG
+#endif
+
+// big = false: 1024 threads, one tile each, panels in LDS.  big = true: 512 threads, up to three tiles each, panels in
+// `scratch` (scratch_doubles >= the packed lower triangle).  Either variant leaves meta[3] = 0 when the skyline
+// does not fit it.
 int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
-                         int *meta, hipStream_t stream) {
+                         int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_THREADS, 1, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_set = true;
   }
-#ifdef PROFILE_SOLVE
-  extern long long *g_band_prof;
-  hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
-                     dx, meta, g_band_prof);
-#else
-  hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
-                     dx, meta);
-#endif
+  if (!big) {
+    hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
+                       H, b, fpose, n, lm, ep, dx, meta, (double *)nullptr, 0 BD_PROF_ARG);
+  } else {
+    if (!scratch) return DBA_ERR_WORKSPACE;
+    const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
+    hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
+                       SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap BD_PROF_ARG);
+  }
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

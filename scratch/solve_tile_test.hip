@@ -22,7 +22,9 @@ static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std:
   for (int i = n-1; i >= 0; i--) { double s = b[i]; for (int k = i+1; k < n; k++) s -= A[k*n+i]*b[k]; b[i] = s/A[i*n+i]; }
   x = b; return true;
 }
+static double *gscratch;
 int run(int n, int band, bool spd, bool timeit) {
+  if (!gscratch) hipMalloc(&gscratch, 8 << 20);
   std::vector<double> H(n*n, 0.0), b(n);
   srand(n*7+band);
   for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) { double v = (i-j < band) ? ((rand()%2001)-1000)/1000.0/(1+i-j) : 0.0; H[i*n+j] = v; H[j*n+i] = v; } H[i*n+i] = spd ? 6.0 + (rand()%100)/50.0 : ((i == n/2) ? -1.0 : 6.0); b[i] = std::sin(i*1.3); }
@@ -32,7 +34,7 @@ int run(int n, int band, bool spd, bool timeit) {
   double *dH, *db; float* dx; int* meta;
   hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64);
   hipMemcpy(dH, H.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
-  dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, 0);
+  { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); }
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("n=%d launch error %s\n", n, hipGetErrorString(e)); return 1; }
   std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
@@ -43,7 +45,7 @@ int run(int n, int band, bool spd, bool timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 3; mode++) {
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, 0); else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); } else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "band " : mode == 2 ? "tile " : "block", ms*1000/200);
     }
@@ -54,6 +56,6 @@ int main() {
   hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 128); hipMemset(dba::g_band_prof, 0, 128);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
   run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
-  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(186, 36, true, true); run(240, 36, true, true); run(378, 36, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
+  run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(186, 36, true, true); run(240, 36, true, true); run(378, 36, true, true); run(378, 56, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
   run(30, 30, false, false); run(150, 13, true, false); run(2, 2, true, false);
 }
