@@ -226,3 +226,48 @@ def test_ba_general_size_solver_path_matches_too():
                             "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd"], env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, kernel + r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _random_graph(rng, num_kf, n_edges, t0, long_range):
+    """random covisibility graph: mostly near-neighbour edges, a few long-range ones (loop closures inside the
+    window), sources on both sides of t0, duplicates allowed"""
+    ii, jj = [], []
+    for _ in range(n_edges):
+        i = int(rng.integers(0, num_kf))
+        if rng.uniform() < long_range:
+            j = int(rng.integers(0, num_kf))
+        else:
+            j = int(np.clip(i + rng.integers(-3, 4), 0, num_kf - 1))
+        if i == j:
+            j = (i + 1) % num_kf
+        ii.append(i)
+        jj.append(j)
+    return np.array(ii, np.int64), np.array(jj, np.int64)
+
+
+@pytest.mark.parametrize("seed,num_kf,n_edges,t0,long_range", [
+    (0, 6, 14, 1, 0.3), (1, 12, 40, 2, 0.0), (2, 20, 70, 1, 0.1), (3, 31, 110, 1, 0.0), (4, 34, 120, 3, 0.05),
+    (5, 40, 150, 1, 0.0), (6, 46, 170, 1, 0.02), (7, 27, 90, 5, 0.5), (8, 64, 200, 1, 0.0), (9, 33, 100, 1, 1.0),
+])
+def test_ba_random_graphs_match_oracle(seed, num_kf, n_edges, t0, long_range):
+    """irregular graphs exercise every solver path (register tiles up to 29 poses, the skyline variants above, the
+    general kernel for wide skylines) and the pose-level skyline table of the prepare kernel: a skyline that missed
+    a coupling would show up as a wrong pose update here"""
+    orc = _oracle()
+    rng = np.random.default_rng(1000 + seed)
+    ii, jj = _random_graph(rng, num_kf, n_edges, t0, long_range)
+    W = syn.make_window(ii, jj, num_kf, h=8, w=12, seed=seed, t0=t0, target_noise=0.2)
+    args = (W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+            W.lm, W.ep, False, 0.05)
+    r32 = orc.ba(*args, np.float32)
+    r64 = orc.ba(*args, np.float64)
+    poses, disps, dx, dz = _run_gpu_ba(W)
+    clamp = lambda a: np.maximum(a, 0.001)  # noqa: E731
+    if np.abs(r64["dx"]).max() == 0.0:  # the damped system was not positive definite: zero update on both sides
+        assert np.abs(dx).max() == 0.0
+        return
+    # tiny maps make the systems poorly conditioned: the fp32-built system is solved in fp64 on both sides, so the
+    # pose update is compared with the fp32-faithful oracle's (same inputs to the solve) and the state with the arbiter
+    np.testing.assert_allclose(dx, r32["dx"], rtol=2e-2, atol=2e-4)
+    print(check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
+                      ref32_disps=clamp(r32["disps"]), t_tol=2e-4, r_tol=2e-4, d_rtol=2e-3, frac=0.95))
