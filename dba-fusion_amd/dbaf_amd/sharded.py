@@ -81,12 +81,18 @@ class ShardedWindow:
         kmin, kmax = int(self.kx_global[0]), int(self.kx_global[-1]) + 1
         own_rows = d["owned"][kmin:kmax].to(torch.bool)
         before = disps[kmin:kmax].clone()
+        inplace = getattr(stages, "system_view", None)
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
-            hb = stages.get_system(ctx)                     # float64 [n6*n6 + n6], this rank's partial sums
-            if dist is not None and self.world > 1:
-                dist.all_reduce(hb)                         # RCCL sum over xGMI (gloo in the CPU tests)
-            stages.set_system(ctx, hb)
+            hb = inplace(ctx) if inplace is not None else None
+            if hb is not None:                              # float64 view of [H | pad | b] inside the workspace
+                if dist is not None and self.world > 1:
+                    dist.all_reduce(hb)                     # RCCL sum over xGMI, in place: no staging copies
+            else:
+                hb = stages.get_system(ctx)                 # float64 [n6*n6 + n6], this rank's partial sums
+                if dist is not None and self.world > 1:
+                    dist.all_reduce(hb)                     # (gloo in the CPU tests)
+                stages.set_system(ctx, hb)
             stages.solve(ctx, lm, ep)
             stages.update(ctx, update_disps=not motion_only)
         # Between iterations a rank only reads the depths of the frames it owns (the source frames of its own
@@ -98,7 +104,7 @@ class ShardedWindow:
             if dist is not None and self.world > 1:
                 dist.all_reduce(delta)
             disps[kmin:kmax] = before + delta
-        assert hb.numel() == n6 * n6 + n6
+        assert hb.numel() >= n6 * n6 + n6
         return stages.finish(ctx)
 
 
@@ -123,6 +129,11 @@ class HipStages:
         n = 6 * (int(t1) - int(t0))
         ctx["H"] = ws[lay.H:lay.H + 8 * n * n].view(torch.float64)
         ctx["b"] = ws[lay.b:lay.b + 8 * n].view(torch.float64)
+        # H and b are neighbours in the workspace: one in-place all-reduce covers both (the alignment gap is zeroed
+        # once so that it sums to zero)
+        if lay.b >= lay.H + 8 * n * n and (lay.b - lay.H) % 8 == 0 and lay.b - (lay.H + 8 * n * n) <= 4096:
+            ws[lay.H + 8 * n * n:lay.b].zero_()
+            ctx["hb"] = ws[lay.H:lay.b + 8 * n].view(torch.float64)
         return ctx
 
     @staticmethod
@@ -141,6 +152,9 @@ class HipStages:
                    "dba_ba_linearize")
         _lib.check(lib.dba_ba_reduce(p(c["ii"]), p(c["jj"]), p(c["owned"]), *c["dims"], int(bool(motion_only)),
                                      p(c["ws"]), c["nbytes"], self._s()), "dba_ba_reduce")
+
+    def system_view(self, c):
+        return c["hb"] if "hb" in c else None
 
     def get_system(self, c):
         return torch.cat([c["H"], c["b"]])
