@@ -36,19 +36,21 @@ struct __attribute__((aligned(16))) H8 {
 
 constexpr int FW = 64;         // w1 == w2
 constexpr int FT_ROWS = 8;     // target rows per tile
-constexpr int T_PITCH = FT_ROWS * FW + 8;  // halves per source pixel in the LDS tile (+8: bank spread)
+constexpr int T_PITCH = FT_ROWS * FW + 4;  // halves per source pixel in the LDS tile (+4: the 32 lanes of an 8-byte
+                                           // accumulator write land in 32 different bank pairs)
 
 __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
   // ATen avg_pool2d on half: float accumulate, one rounding
   return (_Float16)(((float)a + (float)b + (float)c + (float)d) / 4.0f);
 }
 
-__global__ __launch_bounds__(512) void corr_build_fused_kernel(const _Float16 *__restrict__ A,
+__global__ __launch_bounds__(512, 4) void corr_build_fused_kernel(const _Float16 *__restrict__ A,
                                                                const _Float16 *__restrict__ Bm, FusedLevels L,
                                                                int C, int h) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  // 66 KB per workgroup, two workgroups per CU: the pooled levels reuse the level-0 tile once it is dead
   _Float16 *T = smem;                         // [64][T_PITCH]           level 0, rounded
-  _Float16 *P1 = T + 64 * T_PITCH;            // [64][4][32]             level 1, rounded, unsheared
+  _Float16 *P1 = T;                           // [64][4][32]             level 1, rounded, unsheared (after T)
   _Float16 *P2 = P1 + 64 * 4 * 32;            // [64][2][16]
   _Float16 *P3 = P2 + 64 * 2 * 16;            // [64][1][8]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -79,18 +81,23 @@ __global__ __launch_bounds__(512) void corr_build_fused_kernel(const _Float16 *_
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);  // targets x sources
   }
-  // D layout: col = lane & 31 (target tx within the 32-block), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // D layout: col = lane & 31 (source x1 within the 32-block), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (target tx):
+  // four consecutive targets of one source per register quad -> one 8-byte LDS write
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int x1 = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int tx = j * 32 + l31;
-        T[x1 * T_PITCH + wave * FW + tx] = (_Float16)acc[i][j][r];
+      for (int rq = 0; rq < 4; rq++) {
+        const int x1 = i * 32 + l31;
+        const int tx = j * 32 + 8 * rq + 4 * (lane >> 5);
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[i][j][4 * rq + e];
+        *reinterpret_cast<half4 *>(T + x1 * T_PITCH + wave * FW + tx) = v;
       }
   __syncthreads();
 
@@ -114,11 +121,19 @@ __global__ __launch_bounds__(512) void corr_build_fused_kernel(const _Float16 *_
       *reinterpret_cast<H8 *>(dst + (size_t)dx * HW) = v;
     }
   }
-  // ---- level 1, unsheared into LDS: P1[x1][ty1][tx1] ------------------------------------------------------
-  for (int idx = tid; idx < 64 * 4 * 32; idx += 512) {
-    const int tx1 = idx & 31, ty1 = (idx >> 5) & 3, x1 = idx >> 7;
-    const _Float16 *s = T + x1 * T_PITCH + (2 * ty1) * FW + 2 * tx1;
-    P1[idx] = pool4(s[0], s[1], s[FW], s[FW + 1]);
+  // ---- level 1, unsheared: P1[x1][ty1][tx1], through registers because it takes the tile's place --------------
+  {
+    _Float16 p1v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int idx = tid + 512 * u;
+      const int tx1 = idx & 31, ty1 = (idx >> 5) & 3, x1 = idx >> 7;
+      const _Float16 *s = T + x1 * T_PITCH + (2 * ty1) * FW + 2 * tx1;
+      p1v[u] = pool4(s[0], s[1], s[FW], s[FW + 1]);
+    }
+    __syncthreads();  // every read of the level-0 tile is done (its sheared store above included)
+#pragma unroll
+    for (int u = 0; u < 16; u++) P1[tid + 512 * u] = p1v[u];
   }
   __syncthreads();
   // level 2 and the sheared store of level 1 only read P1
@@ -213,7 +228,7 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
                      static_cast<const _Float16 *>(fmap2), Bm, C, HW);
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
-  const size_t lds = sizeof(_Float16) * ((size_t)64 * T_PITCH + 64 * 4 * 32 + 64 * 2 * 16 + 64 * 8);
+  const size_t lds = sizeof(_Float16) * ((size_t)64 * T_PITCH);  // the pooled levels live inside the dead tile
   static bool attr_set = false;
   if (!attr_set) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel),
