@@ -271,3 +271,43 @@ def test_ba_random_graphs_match_oracle(seed, num_kf, n_edges, t0, long_range):
     np.testing.assert_allclose(dx, r32["dx"], rtol=2e-2, atol=2e-4)
     print(check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
                       ref32_disps=clamp(r32["disps"]), t_tol=2e-4, r_tol=2e-4, d_rtol=2e-3, frac=0.95))
+
+
+def test_ba_extend_exports_the_system_and_matches_ba_with_a_zero_prior():
+    """droid.cpp:140-178 (debug binding, unused by the runtime): with skip_solve the reduced system of the first
+    iteration is exported to the CPU float64 H, v and the state is untouched; otherwise the solve uses Ad + Adprior"""
+    import droid_backends
+    W = syn.window_tiny_a(21)
+    P = W.t1 - W.t0
+    d = to_dev(W)
+    H = torch.zeros(6 * P, 6 * P, dtype=torch.float64)
+    v = torch.zeros(6 * P, dtype=torch.float64)
+    A0 = torch.zeros(6 * P, 6 * P, dtype=torch.float64)
+    p0, z0 = d["poses"].clone(), d["disps"].clone()
+    droid_backends.ba_extend(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"],
+                             d["eta"], d["ii"], d["jj"], H, v, A0, W.t0, W.t1, 1, W.lm, W.ep, False, True)
+    assert torch.equal(d["poses"], p0) and torch.equal(d["disps"], z0)
+    Hn, vn = H.numpy(), v.numpy()
+    # (the Schur blocks are formed in fp32 as (E q) E^T, so H is symmetric to fp32 rounding only; the solvers read
+    # the lower triangle)
+    assert np.abs(Hn).max() > 0 and np.allclose(Hn, Hn.T, rtol=0, atol=1e-5 * np.abs(Hn).max())
+    Hn = np.tril(Hn) + np.tril(Hn, -1).T
+    # the exported system is the one ba() solves: dx = (H + damping)^-1 v
+    Hd = Hn.copy()
+    Hd[np.diag_indices_from(Hd)] += W.ep + W.lm * np.diag(Hn)
+    dx_ref = np.linalg.solve(Hd, vn).reshape(P, 6)
+    d2 = to_dev(W)
+    dx, _ = droid_backends.ba(d2["poses"], d2["disps"], d2["intrinsics"], d2["disps_sens"], d2["target"], d2["weight"],
+                              d2["eta"], d2["ii"], d2["jj"], W.t0, W.t1, 1, W.lm, W.ep, False)
+    np.testing.assert_allclose(dx.cpu().numpy(), dx_ref, rtol=1e-4, atol=1e-7)
+    # the prior REPLACES the corresponding part of a copy of Ad (droid_kernels.cu:1624-1632): an all-zero prior of full
+    # size leaves Ad alone, a prior equal to Ad itself doubles the system
+    for prior, factor in ((A0, 1.0), (torch.from_numpy(Hn.copy()), 2.0)):
+        d3 = to_dev(W)
+        dx3, dz3 = droid_backends.ba_extend(d3["poses"], d3["disps"], d3["intrinsics"], d3["disps_sens"], d3["target"],
+                                            d3["weight"], d3["eta"], d3["ii"], d3["jj"], H, v, prior, W.t0, W.t1, 1,
+                                            W.lm, W.ep, False, False)
+        Hf = factor * Hn
+        Hf[np.diag_indices_from(Hf)] += W.ep + W.lm * np.diag(Hf)
+        np.testing.assert_allclose(dx3.cpu().numpy(), np.linalg.solve(Hf, vn).reshape(P, 6), rtol=1e-4, atol=1e-7)
+        assert dz3 is not None and torch.isfinite(dz3).all()
