@@ -238,7 +238,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     _Float16 *obase = olvl + (size_t)e * estride;     // uniform
     const unsigned pix = (unsigned)(y1 * w1 + x1);   // this lane's pixel inside a channel plane
 
-    const bool can_stream = ((w1 & 7) == 0) && (xt * 64 + 64 <= w1);
+    // (the streaming path addresses one edge's level through a buffer resource: 31-bit byte range)
+    const bool can_stream = ((w1 & 7) == 0) && (xt * 64 + 64 <= w1) &&
+                            ((size_t)h2l * w2l * HW1 * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
     const unsigned long long tmask = __ballot(touches);
     int refx = 0, refy = 0;
     if (tmask) {
