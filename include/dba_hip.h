@@ -92,8 +92,11 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
                   int ht, int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes,
                   dba_stream_t stream);
 
-/* stage 3: damped dense Cholesky solve in float64 on the device
- * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx. */
+/* stage 3: damped dense solve in float64 on the device
+ * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx.  Register-tile block LDL^T up
+ * to 29 poses, skyline variants up to 64 poses, blocked Cholesky beyond / for wide skylines (csrc/ba_solve*.hip).
+ * This stage measures the skyline from H (the system may have been summed over ranks); dba_ba takes it from the
+ * prepare stage's graph tables. */
 int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws,
                  size_t ws_bytes, dba_stream_t stream);
 
