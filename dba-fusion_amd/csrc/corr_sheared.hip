@@ -116,7 +116,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 // a wave busy, instead of each wave paying a full gather pass for its one or two odd pixels.
 constexpr int SH_NX = 16;     // plane-rows per step held in LDS (union width in x: 8 + spread <= 16)
 constexpr int SH_NY = 72;     // longest union in y walked by the streaming path
-constexpr int SH_BAND = 4;    // |origin - reference| <= SH_BAND streams
+#ifndef SH_BAND_CFG
+#define SH_BAND_CFG 4
+#endif
+constexpr int SH_BAND = SH_BAND_CFG;    // |origin - reference| <= SH_BAND streams
 #ifndef SH_WAVES_CFG
 #define SH_WAVES_CFG 8
 #endif
