@@ -220,7 +220,15 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   const int lvl = blockIdx.y;
   const int h2l = h2 >> lvl, w2l = w2 >> lvl;
   const int HW1 = h1 * w1;
+#ifndef SH_NO_XCD_SWIZZLE
+  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of rows (whole edges), so that
+  // the 64 rows of a channel plane are written (and a plane's lines read) through ONE L2
+  const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+  const int lb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int rowid = (lb < nblk ? lb : nblk) * SH_WAVES + wave;
+#else
   const int rowid = blockIdx.x * SH_WAVES + wave;  // (e * h1 + y1) * xtiles + xt
+#endif
   const bool rowvalid = rowid < n * h1 * xtiles;
   _Float16 *olvl = out + (size_t)lvl * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
   const size_t estride = (size_t)num_levels * RD * RD * HW1;
