@@ -223,9 +223,10 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
 #ifndef SH_NO_XCD_SWIZZLE
   // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of rows (whole edges), so that
   // the 64 rows of a channel plane are written (and a plane's lines read) through ONE L2
-  const int nblk = gridDim.x, per = (nblk + 7) >> 3;
-  const int lb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int rowid = (lb < nblk ? lb : nblk) * SH_WAVES + wave;
+  // (XCD k receives the workgroups k, k + 8, ...: q + (k < r) of them for gridDim.x = 8 q + r; a bijection)
+  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
+  const int lb = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
+  const int rowid = lb * SH_WAVES + wave;
 #else
   const int rowid = blockIdx.x * SH_WAVES + wave;  // (e * h1 + y1) * xtiles + xt
 #endif

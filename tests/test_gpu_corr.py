@@ -232,3 +232,23 @@ def test_altcorr_backward_matches_oracle():
     np.testing.assert_allclose(g1.cpu().numpy(), r1, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-4)
     assert float(gc.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h", [(1, 8), (1, 24), (3, 8), (5, 24), (7, 40), (11, 8)])
+def test_sheared_lookup_with_workgroup_counts_that_are_not_multiples_of_8(n, h):
+    """the lookup re-maps workgroups to XCDs (csrc/corr_sheared.hip): every row must still be covered exactly once
+    for any grid size"""
+    from dbaf_amd.corr import CorrBlock
+    orc = _oracle()
+    rng = np.random.default_rng(n * 100 + h)
+    C, w = 16, 64
+    f1 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
+    f2 = rng.standard_normal((1, n, C, h, w)).astype(np.float16)
+    t1, t2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    cb = CorrBlock(t1, t2, num_levels=2, radius=3, layout="sheared")
+    pyr_ref = [p.cpu().numpy() for p in CorrBlock.build_pyramid(t1, t2, 2)]
+    coords = np.ascontiguousarray(_smooth_coords(rng, n, h, w))
+    out = cb(torch.from_numpy(coords)[None].cuda()).cpu().numpy()[0]
+    ref = orc.corr_lookup_pyramid(pyr_ref, coords, 3)
+    assert np.array_equal(out.view(np.uint16), ref.view(np.uint16))
