@@ -53,11 +53,21 @@ __device__ __host__ __forceinline__ int pair_off(int s, int T) {
   return 4 * (4 * T * m - 2 * m * (m - 1)) + ((s & 1) ? 2 * (4 * T - 4 * m) : 0) + 2 * s;
 }
 
-__global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const double *__restrict__ H,
+// Bottom-front row panels: n + 4 entries of two doubles, indexed by unknown (the right-hand side at n); the stride
+// is 2 mod 32 doubles so that the substitution's reads of consecutive pairs fall into different banks.
+__device__ __host__ __forceinline__ int bottom_stride(int n) {
+  const int raw = 2 * (n + 4);
+  return raw + ((34 - (raw & 31)) & 31);
+}
+
+// MAXT: launch bound.  Windows up to 25 optimised poses (n <= 150) need at most 768 threads, which leaves the
+// compiler 168 registers per lane instead of 128 (no spills of the per-thread step constants).
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__restrict__ H,
                                                                          const double *__restrict__ bvec,
                                                                          int n, double lm, double ep,
                                                                          float *__restrict__ dx,
-                                                                         int *__restrict__ meta
+                                                                         int *__restrict__ meta, int cb_doubles
 #ifdef PROFILE_SOLVE
                                                                          , long long *__restrict__ prof
 #endif
@@ -73,24 +83,33 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
   const int T = (n1 + 3) >> 2;          // row tiles
   const int KT = (n + 3) >> 2;          // column tiles
   const int npairs = n >> 1;
-  double *C = smem;                                   // raw panels, pair-major
+  const int PBS = bottom_stride(n);     // doubles per bottom-front panel
+  double *C = smem;                                   // raw panels of the top front, pair-major
   double *pinv = C + pair_off(npairs, T);           // 4 doubles per pair (p00, p01, p11, -)
   int *first = (int *)(pinv + 4 * npairs);            // skyline: first non-zero column tile of a row tile
-  int *fail = first + T;
+  int *colmax = first + T;                            // last row tile whose (monotone) skyline reaches a column tile
+  int *fail = colmax + T;                             // [0] failure, [1] c1
+  double *Cb = (double *)(fail + 4 + 2 * (T & 1));     // row panels of the bottom front (slot = step), 16-byte aligned
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
 
-  // ---- tile of this thread (row-major over the lower triangle of tiles)
-  int I = (int)((sqrtf(8.f * tid + 1.f) - 1.f) * 0.5f);
-  while ((I + 1) * (I + 2) / 2 <= tid) I++;
-  while (I * (I + 1) / 2 > tid) I--;
-  const int K = tid - I * (I + 1) / 2;
+  // ---- tile of this thread: COLUMN-major over the lower triangle of tiles, so the tiles still being updated at
+  // step Ks (columns >= Ks) are a suffix of the thread ids: the waves of the eliminated columns skip the step body
+  // and the live lanes stay packed
+  const int ntile = T * (T + 1) / 2;
+  const int rev = max(ntile - 1 - tid, 0);  // reversed, the order is row-major over a triangle of T - 1 - K
+  int Kr = (int)((sqrtf(8.f * rev + 1.f) - 1.f) * 0.5f);
+  while ((Kr + 1) * (Kr + 2) / 2 <= rev) Kr++;
+  while (Kr * (Kr + 1) / 2 > rev) Kr--;
+  const int K = T - 1 - Kr;
+  const int I = (tid < ntile) ? T - 1 - (rev - Kr * (Kr + 1) / 2) : T;
   const bool valid = I < T && 4 * K < n;
+  const bool rhs = (I == T - 1);  // the tile row that carries the right-hand side
 
-  if (tid < T) first[tid] = min(tid, KT - 1);
-  if (tid == 0) *fail = 0;
+  if (tid < T) first[tid] = min(tid, KT - 1), colmax[tid] = 0;
+  if (tid < 4) fail[tid] = 0;
 
-  // zero the panel store (padding rows are read as operands) while the tile loads are in flight
+  // zero the panel stores (padding rows are read as operands) while the tile loads are in flight
   double a[4][4];
   const double *src[4][4];
   bool okm[4][4];
@@ -109,7 +128,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
   for (int r = 0; r < 4; r++)
 #pragma unroll
     for (int c = 0; c < 4; c++) a[r][c] = *src[r][c];
-  for (int e = tid; e < pair_off(npairs, T); e += blockDim.x) C[e] = 0.0;
+  // two fronts need n % 4 == 0 (the right-hand side alone in its tile row) and room for the row panels
+  const int c1cap = ((n & 3) == 0) ? min((KT - 1) >> 1, cb_doubles / (2 * PBS)) : 0;
+  {
+    dbl2 z;
+    z.x = z.y = 0.0;
+    for (int e = tid; 2 * e < pair_off(npairs, T); e += blockDim.x) *(dbl2 *)(C + 2 * e) = z;
+    for (int e = tid; e < c1cap * PBS; e += blockDim.x) *(dbl2 *)(Cb + 2 * e) = z;
+  }
   bool nz = false;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -124,16 +150,76 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
   __syncthreads();
   if (valid && nz) atomicMin(&first[I], K);
   __syncthreads();
-  const int sstart = valid ? max(first[I], first[min(K, T - 1)]) : 0x7fffffff;
+
+  // ---- two fronts.  A banded system is eliminated from both ends at once: the top front takes the column pairs
+  // 0, 1, ... as before, the bottom front the pairs npairs-1, npairs-2, ... (a tile ROW's two halves, bottom up),
+  // one pair each per barrier, for the first c1 tile columns of either end; then the top front finishes the
+  // middle.  c1 is the largest count for which the fronts never touch the same tile: with f' the skyline made
+  // monotone (suffix minimum: bottom-up elimination fills a row to the left as far as any row below it reaches)
+  // and colmax[K] = last row tile with f' <= K, the top front at tile column c works in rows <= colmax[c], the
+  // bottom front at tile row KT-1-c in columns >= f'[KT-1-c].  Dense or arrow-shaped systems give c1 = 0.
+  if (wave == 0) {
+    int c1 = 0;  // (shadows nothing: the kernel-wide c1 is read back from LDS below)
+    if (c1cap >= 2) {
+      int fp = (lane < KT) ? first[lane] : 0x7fffffff;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(fp, off, 64);
+        if (lane + off < 64) fp = min(fp, o);
+      }
+      // colmax[K] = last row with f' <= K: scatter each row to its first column, then a running maximum
+      if (lane < KT) atomicMax(&colmax[fp], lane);
+      int cm = (lane < KT) ? colmax[lane] : 0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(cm, off, 64);
+        if (lane >= off) cm = max(cm, o);
+      }
+      const int fo = __shfl(fp, max(KT - 1 - lane, 0), 64);
+      const unsigned long long okb = __ballot(lane < c1cap && cm < fo);
+      c1 = (int)__builtin_ctzll(~okb);
+      if (c1 < 2) c1 = 0;
+      if (c1 > 0) {
+        if (lane < KT) first[lane] = fp, colmax[lane] = cm;
+        const int fb = __shfl(fp, KT - c1, 64);  // leftmost column the bottom front writes in the right-hand side row
+        if (lane == 0) first[T - 1] = min(first[T - 1], fb);
+      }
+    }
+    if (lane == 0) fail[1] = c1;
+  }
+  __syncthreads();
+#ifdef TILE_NO_TWIST
+  constexpr int c1 = 0;
+#else
+  const int c1 = __builtin_amdgcn_readfirstlane(fail[1]);  // wave-uniform: keeps the loop control on the scalar unit
+#endif
+  const int sstart = valid ? max(first[I], first[min(K, T - 1)]) : 0x3fffffff;
+  const int cmK = (c1 > 0 && valid) ? colmax[K] : -1;           // the bottom front reaches this tile from row cmK up
+  const bool frozen = c1 > 0 && !rhs && I >= KT - c1;          // rows the bottom front eliminates
+  const int nsteps = npairs - 2 * c1;                           // barriers: pairs of the top front
+  // Steps at which this tile is updated, as windows of the step counter s (one subtract + one unsigned compare per
+  // front and step; everything a step needs per thread is a constant from here on: the lone waves of the dependent
+  // chain pay ~5 cycles per instruction, so the step body is kept branch-free and short).
+  //   top front, pair s = tile column Ks = s >> 1, half h = s & 1:  Ks >= sstart and (K > Ks or (K == Ks and h == 0))
+  //   bottom front, pair sb = npairs - 1 - s = tile row Kb, half hb:  Kb <= cmK, (K < Kb or (K == Kb and hb == 1)),
+  //                 (I < Kb or (I == Kb and hb == 1) or right-hand side), s < 2 c1
+  int t_lo = 0x40000000, t_len = 0, b_lo = 0x40000000, b_len = 0;
+  if (valid && !frozen && sstart <= K) t_lo = 2 * sstart, t_len = 2 * K - 2 * sstart;
+  {
+    const int sb_lo = max(max(2 * K + 1, npairs - 2 * c1), rhs ? 0 : 2 * I + 1), sb_hi = 2 * cmK + 1;
+    if (valid && c1 > 0 && sb_lo <= sb_hi) b_lo = npairs - 1 - sb_hi, b_len = sb_hi - sb_lo;
+  }
+  const int offI = 64 * I, offK = 64 * K;  // bytes of 4 panel entries (two doubles each): operands by row / column index
+  int bad = 0;  // a non-positive pivot seen by this thread (collected after the loop; keeps the step branch-free)
   TPROF(0);
 
-  // The owner of a diagonal tile inverts the NEXT 2x2 pivot right after updating it (its dependent chain runs
-  // under the rest of the thread's FMAs) and publishes the inverse with the panel: the readers get P^-1 with one
-  // LDS read instead of each redoing the reciprocal, and the back-substitution finds it in place.
+  // The owner of a diagonal tile inverts the NEXT 2x2 pivot right after updating it and publishes the inverse with
+  // the panel: the readers get P^-1 with one LDS read instead of each redoing the reciprocal, and the
+  // back-substitution finds it in place.
   auto publish_pinv = [&](int sp, double pa, double pb, double pc) {
     const double det = fma(-pb, pb, pa * pc);
     const bool ok = pa > 0.0 && det > 0.0;
-    if (!ok) *fail = 1;  // a non-positive pivot: the verdict is collected after the substitution; keep things finite
+    bad |= !ok;  // the verdict is collected after the substitution; keep things finite
     const double idet = ok ? rcp_nr(det) : 0.0;
     dbl2 lo;
     lo.x = pc * idet;
@@ -141,80 +227,198 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
     *(dbl2 *)(pinv + 4 * sp) = lo;
     pinv[4 * sp + 2] = pa * idet;
   };
-  if (valid && I == 0 && K == 0) publish_pinv(0, a[0][0], a[1][0], a[1][1]);
+  // Panels are addressed in bytes from C: entry i of a panel sits at base + 16 i, so a tile's four row (column)
+  // operands are 64 contiguous bytes at base + offI (offK).  The bases only depend on the step and are carried as
+  // running scalars (the compiler does not strength-reduce them out of the specialised loops by itself):
+  //   top pair s:     tb(s) = 8 pair_off(s, T) - 64 (s >> 1),  tb(s + 1) - tb(s) = 64 (T - (s >> 1)) + 16 - 64 (s & 1)
+  //   bottom slot s:  bb(s) = (Cb - C) + 8 PBS s
+  char *const Cc = (char *)C;
+  const int bb0 = (int)((char *)Cb - Cc), pv0 = (int)((char *)pinv - Cc);
+  // column panel of the top front (pair sp, half hp of its tile column) at base tbn, from the tiles of that column
+  auto publish_top = [&](int tbn, int sp, auto hc) {
+    constexpr int hp = decltype(hc)::value;
+    dbl2 *const q = (dbl2 *)(Cc + tbn + offI);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      dbl2 v;
+      v.x = a[r][2 * hp];
+      v.y = a[r][2 * hp + 1];
+      q[r] = v;
+    }
+    if (I == K) publish_pinv(sp, a[2 * hp][2 * hp], a[2 * hp + 1][2 * hp], a[2 * hp + 1][2 * hp + 1]);
+  };
+  // row panel of the bottom front at base bbn: the pivot rows (half hp of their tile row) over all columns, indexed
+  // by column; the diagonal tile only contributes the columns left of the pivot (the rest stays zero) and the pivot
+  auto publish_bottom = [&](int bbn, int sp, auto hc) {
+    constexpr int hp = decltype(hc)::value;
+    dbl2 *const q = (dbl2 *)(Cc + bbn + offK);
+    if (I != K) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        dbl2 v;
+        v.x = a[2 * hp][c];
+        v.y = a[2 * hp + 1][c];
+        q[c] = v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2 * hp; c++) {
+        dbl2 v;
+        v.x = a[2 * hp][c];
+        v.y = a[2 * hp + 1][c];
+        q[c] = v;
+      }
+      publish_pinv(sp, a[2 * hp][2 * hp], a[2 * hp + 1][2 * hp], a[2 * hp + 1][2 * hp + 1]);
+    }
+  };
+  // ... and the right-hand side's two entries at index n
+  auto publish_bottom_rhs = [&](int bbn, auto hc) {
+    constexpr int hp = decltype(hc)::value;
+    dbl2 v;
+    v.x = a[0][2 * hp];
+    v.y = a[0][2 * hp + 1];
+    *(dbl2 *)(Cc + bbn + 16 * n) = v;
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  if (valid && K == 0 && !frozen) publish_top(0, 0, H0{});
+  if (c1 > 0 && valid && I == KT - 1) publish_bottom(bb0, npairs - 1, H1{});
+  if (c1 > 0 && valid && rhs && K == KT - 1) publish_bottom_rhs(bb0, H1{});
 
-  // ---- factorisation: block LDL^T, 2x2 pivots, one barrier per column pair
-  for (int Ks = 0; Ks < KT; Ks++) {
-    auto step = [&](auto hc) {
-      constexpr int h = decltype(hc)::value;
-      const int j0 = 4 * Ks + 2 * h;
-      const int s = j0 >> 1;
-      double *P = C + pair_off(s, T);  // row 4 Ks first
-      if (valid && K == Ks) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          dbl2 v;
-          v.x = a[r][2 * h];
-          v.y = a[r][2 * h + 1];
-          *(dbl2 *)(P + 2 * (4 * (I - Ks) + r)) = v;
-        }
-      }
-      __syncthreads();
-      const bool active = Ks >= sstart && (K > Ks || (K == Ks && h == 0));
-      if (active) {
-        const dbl2 pv = *(const dbl2 *)(pinv + 4 * s);
-        const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
-        dbl2 ri[4], rk[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) ri[r] = *(const dbl2 *)(P + 2 * (4 * (I - Ks) + r));
-#pragma unroll
-        for (int c = 0; c < 4; c++) rk[c] = *(const dbl2 *)(P + 2 * (4 * (K - Ks) + c));
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const double u0 = fma(p01, rk[c].y, p00 * rk[c].x);
-          const double u1 = fma(p11, rk[c].y, p01 * rk[c].x);
-#pragma unroll
-          for (int r = 0; r < 4; r++) a[r][c] = fma(-ri[r].y, u1, fma(-ri[r].x, u0, a[r][c]));
-        }
-      }
-      // next pivot: columns j0 + 2, j0 + 3 = the other half of this tile column (h == 0) or the first half of the
-      // next one (h == 1); its owner publishes whether or not this step touched the tile (block-diagonal systems)
-      constexpr int hn = 1 - h;
-      const int Kn = (h == 0) ? Ks : Ks + 1;
-      if (valid && I == Kn && K == Kn && 2 * (s + 1) < n)
-        publish_pinv(s + 1, a[2 * hn][2 * hn], a[2 * hn + 1][2 * hn], a[2 * hn + 1][2 * hn + 1]);
+  // ---- factorisation: block LDL^T, 2x2 pivots, one barrier per step.  A step first updates the elements the NEXT
+  // step's panels consist of (two columns for the top front, two rows for the bottom front) and publishes them
+  // (panel + inverted pivot) before touching the rest, so the LDS round trip of the hand-off runs under the
+  // remaining FMAs.  Panels are per pair: no write-after-read hazard.  Both fronts read their operands by global
+  // row / column index from the pair's panel, so one update body serves both.
+  // A lone wave issues about one instruction per 5-8 cycles, so a step costs what the busiest wave's step body is
+  // long: the body is specialised per WAVE.  MODE 0: top front only (also the middle and one-front systems),
+  // 1: bottom front only, 2: both (a wave whose tiles straddle the two regions).  (Tried: one straight-line region
+  // per step in which lanes that do not publish store into a dump block and every lane inverts its own pivot, so
+  // that the reciprocal chain can overlap the remaining updates - slower, every busy wave then pays for it.)
+  int tb = 0, bb = bb0;  // bases of the current step's panels
+  auto step = [&](int Ks, auto hc, auto mode) {
+    constexpr int h = decltype(hc)::value;
+    constexpr int MODE = decltype(mode)::value;
+    constexpr bool TOP = (MODE != 1), BOT = (MODE != 0);
+    constexpr int hn = 1 - h;
+    using HN = std::integral_constant<int, hn>;
+    const int s = 2 * Ks + h;
+    const int Kn = (h == 0) ? Ks : Ks + 1;
+    // bottom front (n % 4 == 0: npairs is even, so its half is the opposite one)
+    const int sb = npairs - 1 - s;
+    const int Kbn = (sb - 1) >> 1;
+    const int tbn = tb + 64 * (T - Ks) + 16 - 64 * h, bbn = bb + 8 * PBS;
+    __syncthreads();
+    const bool topA = TOP && (unsigned)(s - t_lo) <= (unsigned)t_len;
+    const bool botA = BOT && (unsigned)(s - b_lo) <= (unsigned)b_len;
+    dbl2 ri[4];
+    double u0[4], u1[4];
+    auto upd = [&](int r, int c) { a[r][c] = fma(-ri[r].y, u1[c], fma(-ri[r].x, u0[c], a[r][c])); };
+    // the tile in four quarters: the next top pivot's columns are (2 hn, 2 hn + 1), the next bottom pivot's rows
+    // (2 h, 2 h + 1).  quarter(rh, ch) = rows 2 rh.., columns 2 ch..
+    auto quarter = [&](int rh, int ch) {
+      upd(2 * rh, 2 * ch);
+      upd(2 * rh, 2 * ch + 1);
+      upd(2 * rh + 1, 2 * ch);
+      upd(2 * rh + 1, 2 * ch + 1);
     };
-    step(std::integral_constant<int, 0>{});
-    if (4 * Ks + 2 < n) step(std::integral_constant<int, 1>{});
+    if (topA | botA) {
+      const bool useb = BOT && (!TOP || botA);
+      const char *const base = Cc + (useb ? bb : tb);
+      const double *const pvp = (const double *)(Cc + pv0 + 32 * (useb ? sb : s));
+      const dbl2 pv = *(const dbl2 *)pvp;
+      const double p00 = pv.x, p01 = pv.y, p11 = pvp[2];
+      const dbl2 *const pi = (const dbl2 *)(base + offI), *const pk = (const dbl2 *)(base + offK);
+      dbl2 rk[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) ri[r] = pi[r];
+#pragma unroll
+      for (int c = 0; c < 4; c++) rk[c] = pk[c];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        u0[c] = fma(p01, rk[c].y, p00 * rk[c].x);
+        u1[c] = fma(p11, rk[c].y, p01 * rk[c].x);
+      }
+      // first what the next step's panels consist of (one static order per mode: a per-lane order would make the
+      // compiler address the tile through scratch)
+      if (TOP) quarter(h, hn), quarter(hn, hn);
+      if (BOT) quarter(h, h);
+      if (BOT && !TOP) quarter(h, hn);
+    }
+    // published whether or not this step touched the tile (block-diagonal systems); the bottom front's row panel
+    // only inside the skyline (the row's tiles sit in every column; the rest stays zero)
+    if (TOP) {
+      if (valid & (K == Kn) & !frozen & (s + 1 < nsteps)) publish_top(tbn, s + 1, HN{});
+    }
+    if (BOT) {
+      if (valid & (I == Kbn) & (Kbn <= cmK) & (s + 1 < 2 * c1)) publish_bottom(bbn, sb - 1, hc);
+    }
+    if (topA | botA) {
+      if (!BOT) quarter(h, h);
+      if (TOP) quarter(hn, h);
+      if (BOT && !TOP) quarter(hn, h), quarter(hn, hn);
+    }
+    // (the right-hand side's entries sit in row 0 of its tile, which is complete only now)
+    if (BOT) {
+      if (valid & rhs & (K == Kbn) & (s + 1 < 2 * c1)) publish_bottom_rhs(bbn, hc);
+    }
+    tb = tbn, bb = bbn;
+  };
+  {
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    // which fronts this wave's tiles ever serve while both are running (columns up to c1 publish top panels)
+    const bool my_top = valid && !frozen && (K <= c1 || t_lo < 2 * c1);
+    const bool my_bot = b_lo != 0x40000000;
+    const int wmode = (__ballot(my_bot) != 0ull) ? ((__ballot(my_top) != 0ull) ? 2 : 1) : 0;
+    int Ks = 0;
+    if (wmode == 2) {
+      for (; Ks < c1; Ks++) step(Ks, H0{}, M2{}), step(Ks, H1{}, M2{});
+    } else if (wmode == 1) {
+      for (; Ks < c1; Ks++) step(Ks, H0{}, M1{}), step(Ks, H1{}, M1{});
+    } else {
+      for (; Ks < c1; Ks++) step(Ks, H0{}, M0{}), step(Ks, H1{}, M0{});
+    }
+    for (; 2 * Ks < nsteps; Ks++) {
+      step(Ks, H0{}, M0{});
+      if (2 * Ks + 1 < nsteps) step(Ks, H1{}, M0{});
+    }
   }
+  if (bad) *fail = 1;
   __syncthreads();
   TPROF(1);
   TPROF(2);
 
+  // ---- substitution, one wave.  t_j = y_j - sum over the solved unknowns i of coef(i, j) x_i, where coef(i, j) is
+  // entry i of the panel of j's pair (a column panel for the top front / middle, a row panel for the bottom
+  // front): lane l keeps t_j for the columns j = l, l + 64, l + 128 and reads its panels by unknown index.  Order =
+  // reverse elimination: the middle downwards, then the top front's pairs downwards and the bottom front's upwards.
   if (wave == 0) {
-    // lane l holds t_j for the columns j = l, l + 64, l + 128; C(i, j) = raw panel value of row i in column j
-    auto Cij = [&](int i, int j) { return C[pair_off(j >> 1, T) + 2 * (i - 4 * (j >> 2)) + (j & 1)]; };
     double t[3];
-    int cbase[3];  // C(i, j) = C[cbase + 2 i] for this lane's column j (columns past n alias column 0; masked)
+    int cbase[3];  // coef(i, j) = C[cbase + 2 i] for this lane's column j (columns past n alias column 0; masked)
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const int j = lane + 64 * r;
       const int jc = (j < n) ? j : 0;
-      cbase[r] = pair_off(jc >> 1, T) - 8 * (jc >> 2) + (jc & 1);
-      t[r] = (j < n) ? Cij(n, j) : 0.0;
+      const int sj = jc >> 1;
+      cbase[r] = (sj >= npairs - 2 * c1) ? (int)(Cb - C) + (npairs - 1 - sj) * PBS + (jc & 1)
+                                         : pair_off(sj, T) - 8 * (jc >> 2) + (jc & 1);
+      t[r] = (j < n) ? C[cbase[r] + 2 * n] : 0.0;
     }
     double xo[3] = {0.0, 0.0, 0.0};  // solution entries of this lane's columns (kept off the dependent chain)
-    auto sweep = [&](auto rc) {
-      constexpr int r0 = decltype(rc)::value;
-      constexpr int R = r0 + 1;
-      const int shi = min(npairs, 32 * (r0 + 1)) - 1, slo = 32 * r0;
+    // pairs s_from, s_from + DIR, ..., s_to of column group r0; the t registers RLO..RHI receive the update
+    auto sweep = [&](auto rc, auto rlo, auto rhi, auto dir, int s_from, int s_to) {
+      constexpr int r0 = decltype(rc)::value, RLO = decltype(rlo)::value, RHI = decltype(rhi)::value;
+      constexpr int DIR = decltype(dir)::value;
+      constexpr int R = RHI - RLO + 1;
       struct Ops { double l0[R], l1[R], p[3]; };
-      // raw operands of step s: rows 2s, 2s+1 of this lane's columns and the pivot inverse
+      // raw operands of step s: entries 2s, 2s+1 of this lane's panels and the pivot inverse
       auto fetch = [&](int s, Ops &o) {
-        const int sc = max(s, 0);
+        const int sc = min(max(s, 0), npairs - 1);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          const double *q = C + cbase[r] + 4 * sc;
+          const double *q = C + cbase[RLO + r] + 4 * sc;
           o.l0[r] = q[0];
           o.l1[r] = q[2];
         }
@@ -224,10 +428,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
         const int j0 = 2 * s, l0 = j0 & 63;
         const double t0 = readlane_dyn_f64(t[r0], l0), t1 = readlane_dyn_f64(t[r0], l0 + 1);
         const double x0 = fma(o.p[1], t1, o.p[0] * t0), x1 = fma(o.p[2], t1, o.p[1] * t0);
-        // every lane updates: columns at or right of the pivot pair receive garbage, but they are finished (their
-        // solution sits in xo) and are never read again, so no per-lane masking on the single issuing wave
+        // every lane updates: finished columns receive garbage, but their solution sits in xo and they are never
+        // read again, so no per-lane masking on the single issuing wave
 #pragma unroll
-        for (int r = 0; r < R; r++) t[r] = fma(-o.l1[r], x1, fma(-o.l0[r], x0, t[r]));
+        for (int r = 0; r < R; r++) t[RLO + r] = fma(-o.l1[r], x1, fma(-o.l0[r], x0, t[RLO + r]));
         xo[r0] = (lane == l0) ? x0 : ((lane == l0 + 1) ? x1 : xo[r0]);
       };
       // keeps a prefetch where it was issued (otherwise the loads sink to their first use)
@@ -237,20 +441,48 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
         asm volatile("" : "+v"(o.p[0]), "+v"(o.p[1]), "+v"(o.p[2]));
       };
       // operands are fetched four steps at a time: one LDS round trip per four links of the dependent chain
-      for (int s = shi; s >= slo; s -= 4) {
+      for (int s = s_from; DIR > 0 ? s <= s_to : s >= s_to; s += 4 * DIR) {
         Ops o[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) fetch(s - q, o[q]);
+        for (int q = 0; q < 4; q++) fetch(s + q * DIR, o[q]);
 #pragma unroll
         for (int q = 0; q < 4; q++) pin(o[q]);
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          if (s - q >= slo) solve_step(s - q, o[q]);
+          if (DIR > 0 ? s + q <= s_to : s - q >= s_to) solve_step(s + q * DIR, o[q]);
       }
     };
-    if (npairs > 64) sweep(std::integral_constant<int, 2>{});
-    if (npairs > 32) sweep(std::integral_constant<int, 1>{});
-    sweep(std::integral_constant<int, 0>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using IM = std::integral_constant<int, -1>;
+    // the part of [lo, hi] in column group r0 (32 pairs per group), downwards or upwards
+    auto down = [&](auto rc, auto rhi, int lo, int hi) {
+      constexpr int r0 = decltype(rc)::value;
+      const int a_ = min(hi, 32 * r0 + 31), b_ = max(lo, 32 * r0);
+      if (a_ >= b_) sweep(rc, I0{}, rhi, IM{}, a_, b_);
+    };
+    auto up = [&](auto rc, int lo, int hi) {
+      constexpr int r0 = decltype(rc)::value;
+      const int a_ = max(lo, 32 * r0), b_ = min(hi, 32 * r0 + 31);
+      if (a_ <= b_) sweep(rc, rc, I2{}, I1{}, a_, b_);
+    };
+    const int mlo = 2 * c1, mhi = npairs - 1 - 2 * c1;
+    if (c1 > 0) {  // the bottom front's columns (in the upper groups) also take the middle's updates
+      down(I2{}, I2{}, mlo, mhi);
+      down(I1{}, I2{}, mlo, mhi);
+      down(I0{}, I2{}, mlo, mhi);
+      down(I2{}, I2{}, 0, mlo - 1);
+      down(I1{}, I1{}, 0, mlo - 1);
+      down(I0{}, I0{}, 0, mlo - 1);
+      up(I0{}, mhi + 1, npairs - 1);
+      up(I1{}, mhi + 1, npairs - 1);
+      up(I2{}, mhi + 1, npairs - 1);
+    } else {
+      down(I2{}, I2{}, 0, npairs - 1);
+      down(I1{}, I1{}, 0, npairs - 1);
+      down(I0{}, I0{}, 0, npairs - 1);
+    }
 
     // non-finite results count as failure too; failure => zero update (:1263-1266)
     bool bad = false;
@@ -266,13 +498,25 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void ba_solve_tile_kernel(const d
     if (lane == 0) meta[1] = failed;
   }
   TPROF(3);
+#if defined(PROFILE_SOLVE) && defined(TILE_DEBUG_DUMP)
+  __syncthreads();
+  {  // smem image: [0] = doubles of C, [1] = PBS, [2] = c1, then C | pinv | Cb (2 c1 slots)
+    double *dbg = (double *)(prof + 64);
+    const int nc = pair_off(npairs, T);
+    if (tid == 0) dbg[0] = nc, dbg[1] = PBS, dbg[2] = c1;
+    for (int e = tid; e < nc; e += blockDim.x) dbg[4 + e] = C[e];
+    for (int e = tid; e < 4 * npairs; e += blockDim.x) dbg[4 + nc + e] = pinv[e];
+    for (int e = tid; e < 2 * c1 * PBS; e += blockDim.x) dbg[4 + nc + 4 * npairs + e] = Cb[e];
+  }
+#endif
 }
 
 static int tile_rows(int n) { return (n + 1 + 3) / 4; }
 
 static size_t tile_lds_bytes(int n) {
   const int np = n / 2;
-  return ((size_t)pair_off(np, tile_rows(n)) + 4 * (size_t)np) * sizeof(double) + ((size_t)tile_rows(n) + 4) * sizeof(int);
+  // panels + pivot inverses, then first[T] colmax[T] flags[4] (+ 2 ints so that what follows is 16-byte aligned)
+  return ((size_t)pair_off(np, tile_rows(n)) + 4 * (size_t)np) * sizeof(double) + (2 * (size_t)tile_rows(n) + 4 + 2) * sizeof(int);
 }
 
 bool ba_solve_tile_supported(int n) {
@@ -285,20 +529,30 @@ int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, dou
                          hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_tile_kernel),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_tile_kernel<768>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_tile_kernel<TILE_MAX_THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_set = true;
   }
   const int T = tile_rows(n);
   const int threads = ((T * (T + 1) / 2 + 63) / 64) * 64;
+  // what is left of the LDS holds the bottom front's row panels (DBA_SOLVE_TWIST=0: one front only)
+  static const bool twist = [] { const char *e = getenv("DBA_SOLVE_TWIST"); return !(e && e[0] == '0'); }();
+  const int cb_doubles = twist ? (int)((SOLVE_MAX_LDS_BYTES - tile_lds_bytes(n)) / sizeof(double)) : 0;
 #ifdef PROFILE_SOLVE
   extern long long *g_tile_prof;
-  hipLaunchKernelGGL(ba_solve_tile_kernel, dim3(1), dim3(threads), tile_lds_bytes(n), stream, H, b, n, lm, ep, dx,
-                     meta, g_tile_prof);
+#define TILE_PROF_ARG , g_tile_prof
 #else
-  hipLaunchKernelGGL(ba_solve_tile_kernel, dim3(1), dim3(threads), tile_lds_bytes(n), stream, H, b, n, lm, ep, dx,
-                     meta);
+#define TILE_PROF_ARG
 #endif
+  if (threads <= 768)
+    hipLaunchKernelGGL(ba_solve_tile_kernel<768>, dim3(1), dim3(threads), SOLVE_MAX_LDS_BYTES, stream, H, b, n, lm, ep,
+                       dx, meta, cb_doubles TILE_PROF_ARG);
+  else
+    hipLaunchKernelGGL(ba_solve_tile_kernel<TILE_MAX_THREADS>, dim3(1), dim3(threads), SOLVE_MAX_LDS_BYTES, stream, H,
+                       b, n, lm, ep, dx, meta, cb_doubles TILE_PROF_ARG);
+#undef TILE_PROF_ARG
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -23,22 +23,29 @@ static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std:
   x = b; return true;
 }
 static double *gscratch;
+static int g_ex_i = -1, g_ex_j = -1;  // one extra off-band coupling (non-monotone skylines)
 int run(int n, int band, bool spd, bool timeit) {
   if (!gscratch) hipMalloc(&gscratch, 8 << 20);
   std::vector<double> H(n*n, 0.0), b(n);
   srand(n*7+band);
-  for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) { double v = (i-j < band) ? ((rand()%2001)-1000)/1000.0/(1+i-j) : 0.0; H[i*n+j] = v; H[j*n+i] = v; } H[i*n+i] = spd ? 6.0 + (rand()%100)/50.0 : ((i == n/2) ? -1.0 : 6.0); b[i] = std::sin(i*1.3); }
+  for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) { double v = (i-j < band) ? ((rand()%2001)-1000)/1000.0/(1+i-j) : 0.0; H[i*n+j] = v; H[j*n+i] = v; } if (g_ex_i >= 0 && g_ex_i < n && i == g_ex_i) { H[g_ex_i*n+g_ex_j] = 0.37; H[g_ex_j*n+g_ex_i] = 0.37; } H[i*n+i] = spd ? 6.0 + (rand()%100)/50.0 : ((i == n/2) ? -1.0 : 6.0); b[i] = std::sin(i*1.3); }
   const double lm = 1e-4, ep = 0.1;
   std::vector<double> Hd = H; for (int i = 0; i < n; i++) Hd[i*n+i] += ep + lm*Hd[i*n+i];
   std::vector<double> xr; bool ok = host_solve(Hd, b, n, xr);
   double *dH, *db; float* dx; int* meta;
   hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64);
   hipMemcpy(dH, H.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
-  { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); }
+  const bool use_tile = dba::ba_solve_tile_supported(n) && !getenv("HARNESS_BAND");
+  if (use_tile) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); }
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("n=%d launch error %s\n", n, hipGetErrorString(e)); return 1; }
   std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
-  printf("n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
+  printf("%s n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", use_tile ? "tile" : "band", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
+#ifdef TILE_DEBUG_DUMP
+  if (getenv("HARNESS_DUMP") && n == atoi(getenv("HARNESS_DUMP")) && use_tile) { std::vector<double> img(1 << 17); hipMemcpy(img.data(), (char*)dba::g_tile_prof + 512, 8 << 17, hipMemcpyDeviceToHost);
+    char fn[128]; snprintf(fn, 128, "gpurun_out/tile_dump_n%d_b%d.bin", n, band); FILE* f = fopen(fn, "wb"); double hdr[2] = {(double)n, (double)band}; fwrite(hdr, 8, 2, f); fwrite(H.data(), 8, n*n, f); fwrite(b.data(), 8, n, f); fwrite(img.data(), 8, 1 << 17, f); fclose(f); }
+#endif
+  if (getenv("HARNESS_DUMP") && n <= 64) { for (int i = 0; i < n; i++) printf("    x[%2d] dev % .6e ref % .6e%s\n", i, x[i], ok ? xr[i] : 0.0, fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6 ? "  <--" : ""); }
   if (timeit) { long long hp[12]; hipMemcpy(hp, dba::g_band_prof, 96, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld\n", hp[0],hp[1],hp[2],hp[3],hp[4]); }
   hipMemset(dba::g_band_prof, 0, 128);
   if (timeit) {
@@ -48,14 +55,24 @@ int run(int n, int band, bool spd, bool timeit) {
       for (int it = 0; it < 200; it++) { if (mode == 0) { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); } else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "band " : mode == 2 ? "tile " : "block", ms*1000/200);
+      if (mode == 2) { long long hp[8]; hipMemcpy(hp, dba::g_tile_prof, 64, hipMemcpyDeviceToHost); printf("   tile stages us: setup %.2f factor %.2f backsub %.2f\n", hp[0]/200.0/100, hp[1]/200.0/100, hp[3]/200.0/100); hipMemset(dba::g_tile_prof, 0, 2048); }
+
     }
   }
   return 0;
 }
 int main() {
-  hipMalloc(&dba::g_tile_prof, 128); hipMemset(dba::g_tile_prof, 0, 128); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 128); hipMemset(dba::g_band_prof, 0, 128);
+  hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 128); hipMemset(dba::g_band_prof, 0, 128);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
   run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
   run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(186, 36, true, true); run(240, 36, true, true); run(378, 36, true, true); run(378, 56, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);
   run(30, 30, false, false); run(150, 13, true, false); run(2, 2, true, false);
+  // two-front cases: band widths around the tile size, small and large n, odd tile counts, non-SPD in either front
+  run(144, 30, true, true); run(120, 12, true, false); run(24, 6, true, false); run(24, 2, true, false); run(48, 9, true, false); run(52, 8, true, false);
+  run(172, 30, true, true); run(100, 16, true, false); run(36, 4, true, false); run(144, 60, true, false); run(144, 24, false, false); run(64, 7, false, false);
+  g_ex_i = 141; g_ex_j = 2; run(144, 24, true, false);      // arrow: one front only
+  g_ex_i = 90; g_ex_j = 40; run(144, 24, true, false);      // a long coupling in the middle
+  g_ex_i = 139; g_ex_j = 100; run(144, 12, true, false);    // non-monotone skyline inside the bottom front
+  g_ex_i = 40; g_ex_j = 4; run(144, 12, true, false);       // ... inside the top front
+  g_ex_i = 30; g_ex_j = 1; run(64, 6, true, false); g_ex_i = -1;
 }
