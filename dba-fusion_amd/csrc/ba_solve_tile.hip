@@ -5,19 +5,28 @@
 // (/root/reference/src/droid_kernels.cu:200-218 solveDenseD, :1248-1269 SparseBlock::solve) for the window
 // sizes the tracker actually uses; ba_solve.hip keeps the general-size path.
 //
-// The solve is latency-bound (1 MFLOP), so the design minimises the length of the dependent chain per
-// eliminated column instead of counting flops:
+// The solve is latency-bound (1 MFLOP): a lone wave issues roughly one instruction per 5-8 cycles (a float64 FMA
+// every ~9.5), so a step of the elimination costs what the busiest wave's step body is long.  The design therefore
+// minimises the number of dependent steps and the instructions per step instead of counting flops:
 //   * the system, augmented with the right-hand side as an extra row, is cut into 4x4 tiles; every tile of the
-//     lower triangle lives in the registers of ONE thread for the whole factorisation (703 threads at n = 144);
-//   * elimination is a block LDL^T with 2x2 pivots: per step the owners of a column pair publish their raw
-//     values to LDS (one ds_write_b128 per row), ONE barrier, then every thread whose tile is inside the
-//     skyline reads the two panel rows it needs, inverts the 2x2 pivot redundantly (one v_rcp_f64 + Newton per
-//     TWO columns, no square roots) and applies the rank-2 update to its registers;
-//   * the published panels are never rewritten and are exactly what the block back-substitution needs
-//     (D L^T x = y with y the eliminated right-hand-side row), which one wave runs with v_readlane broadcasts;
+//     lower triangle lives in the registers of ONE thread for the whole factorisation (703 threads at n = 144),
+//     tiles in column-major order so that the tiles of a step sit in few waves;
+//   * elimination is a block LDL^T with 2x2 pivots (one v_rcp_f64 + Newton per TWO columns, no square roots): per
+//     step the owners of the pivot pair's panel have published their raw values to LDS (one ds_write_b128 per
+//     row) and the owner of the diagonal tile the inverted pivot; ONE barrier; every tile inside the skyline reads
+//     the panel entries of its rows and columns and applies the rank-2 update to its registers - first to the
+//     elements the NEXT panel consists of, which are published before the rest of the tile is touched;
+//   * banded systems (every sliding window) are eliminated from BOTH ends at once (a twisted factorisation): the
+//     top front takes the column pairs 0, 1, ..., the bottom front the row pairs npairs-1, npairs-2, ..., one
+//     pair each per barrier while their fill regions stay disjoint, then the top front finishes the middle:
+//     72 -> 50 barriers for the 25-keyframe window.  Both fronts address their panel by global row / column
+//     index, so one update body serves both; the step body is specialised per wave (top-only / bottom-only /
+//     both) because every instruction of a body is paid for whether or not a lane needs it;
+//   * the published panels are never rewritten and are exactly what the substitution needs (reverse elimination
+//     order: middle, then the two fronts), which one wave runs with v_readlane broadcasts;
 //   * structure: a row tile's first non-zero column tile (the skyline) is found once after the load; fill-in
-//     cannot leave the skyline, so tiles outside it never enter the update and waves without an active tile
-//     only meet the barrier.  A sliding-window system is block-banded, so 2-3 of the 11 waves work per step.
+//     cannot leave the (monotone) skyline, so tiles outside it never enter the update and waves without an
+//     active tile only meet the barrier.
 #include "ba_kernels.h"
 
 #include <type_traits>

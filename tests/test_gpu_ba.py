@@ -226,6 +226,13 @@ def test_ba_general_size_solver_path_matches_too():
                             "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd"], env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, kernel + r.stdout[-2000:] + r.stderr[-2000:]
+    # ... and the register-tile kernel with one elimination front only (two fronts are the default on banded systems)
+    env = dict(os.environ, DBA_SOLVE_TWIST="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(here, "test_gpu_ba.py"), os.path.join(here, "test_gpu_solve.py"),
+                        "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd or two_front or failing_pivot"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "one front" + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _random_graph(rng, num_kf, n_edges, t0, long_range):

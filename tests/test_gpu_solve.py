@@ -63,3 +63,50 @@ def test_non_spd_system_gives_a_zero_update(P):
     H, b = _system(rng, P, 18, spd=False)
     dx, failed = _solve_on_device(H, b, P, 1e-4, 0.1)
     assert failed == 1 and np.all(dx == 0.0)
+
+
+def _check(H, b, P, lm=1e-4, ep=0.1):
+    Hd = H.copy()
+    Hd[np.diag_indices_from(Hd)] += ep + lm * np.diag(H)
+    ref = np.linalg.solve(Hd, b)
+    dx, failed = _solve_on_device(H, b, P, lm, ep)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+
+
+# The register-tile kernel eliminates banded systems with n % 4 == 0 from both ends (two fronts, csrc/ba_solve_tile.hip).
+# Sizes with an even and an odd number of tile columns, bands around the tile width, and skylines that are not
+# monotone (a long coupling inside the top front, the bottom front, the middle, and an arrow that leaves one front).
+@pytest.mark.parametrize("P,band", [(4, 2), (4, 6), (6, 4), (8, 9), (10, 8), (12, 7), (16, 16), (20, 12), (22, 30), (24, 30), (24, 12), (24, 60), (28, 30)])
+def test_two_front_elimination_on_banded_systems(P, band):
+    rng = np.random.default_rng(7 * P + band)
+    H, b = _system(rng, P, band)
+    _check(H, b, P)
+
+
+@pytest.mark.parametrize("P,band,i,j", [(24, 24, 141, 2), (24, 24, 90, 40), (24, 12, 139, 100), (24, 12, 40, 4), (16, 6, 30, 1),
+                                         (24, 18, 143, 120), (24, 18, 72, 60), (20, 10, 119, 0)])
+def test_two_front_elimination_with_a_long_coupling(P, band, i, j):
+    rng = np.random.default_rng(P + band + i)
+    H, b = _system(rng, P, band)
+    H[i, j] = H[j, i] = 0.37
+    _check(H, b, P)
+
+
+def test_two_front_elimination_with_sparse_right_hand_sides():
+    # the bottom front fills the right-hand-side row to the left of its first non-zero
+    rng = np.random.default_rng(5)
+    H, _ = _system(rng, 24, 24)
+    for lo, hi in ((140, 144), (0, 4), (70, 74), (100, 144)):
+        b = np.zeros(144)
+        b[lo:hi] = 1.0 + np.arange(hi - lo)
+        _check(H, b, 24)
+
+
+@pytest.mark.parametrize("P,where", [(24, 3), (24, 140), (24, 70), (20, 118), (16, 1)])
+def test_a_failing_pivot_in_either_front_gives_a_zero_update(P, where):
+    rng = np.random.default_rng(P + where)
+    H, b = _system(rng, P, 18)
+    H[where, where] = -1.0
+    dx, failed = _solve_on_device(H, b, P, 1e-4, 0.1)
+    assert failed == 1 and np.all(dx == 0.0)
