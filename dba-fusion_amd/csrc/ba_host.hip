@@ -10,6 +10,8 @@
 
 #include "ba_kernels.h"
 
+#include <algorithm>
+
 namespace dba {
 
 static thread_local char g_last_error[512] = "";
@@ -129,13 +131,17 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   if (N > 0 && (!ii || !jj)) return DBA_ERR_ARG;
-  const size_t lds = sizeof(int) * ((size_t)B + plan.T.Mmax + 1 + 1024);
-  if (lds > 160 * 1024) return DBA_ERR_UNSUPPORTED;
+  // threads: enough for one edge / frame / pose each, at most 1024 (barriers among 2 waves cost a fraction of 16)
+  const int want = std::max(std::max(N, B), t1 - t0);
+  const int threads = std::min(1024, std::max(64, (want + 63) / 64 * 64));
+  const size_t scan_ints = std::max<size_t>(std::max(threads, t1 - t0), N > threads ? 1024 : 0) + 32;
+  const size_t lds = sizeof(int) * ((size_t)B + 2 * (size_t)plan.T.Mmax + 1 + scan_ints);
+  if (lds > 160 * 1024 || t1 - t0 > 16384) return DBA_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_prepare_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
-  hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
+  hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
                      plan.T);
   DBA_LAUNCH_CHECK();
   return DBA_OK;

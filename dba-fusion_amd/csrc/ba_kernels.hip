@@ -24,47 +24,66 @@ namespace dba {
 // stage 0: index sets
 // ---------------------------------------------------------------------------------------------
 // One workgroup. LDS: flag[B] | cnt[Mmax+1] | scan[1024]
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
+// One workgroup (a multiple of 64 threads, sized by the host to the graph: barriers among 2 waves are several times
+// cheaper than among 16).  LDS: flag[B] cnt[Mmax + 1] kxs[Mmax] scan[max(blockDim, 1024 if N > blockDim)].
 __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restrict__ ii,
                                                           const int64_t *__restrict__ jj, int N, int B,
                                                           int t0, int t1, BaTables T) {
   extern __shared__ int sm[];
   int *flag = sm;
   int *cnt = sm + B;
-  int *scan = cnt + T.Mmax + 1;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  int *kxs = cnt + T.Mmax + 1;
+  int *scan = kxs + T.Mmax;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int P = t1 - t0;
+  // this thread's first edge stays in registers (the usual graph has at most one edge per thread): the passes
+  // below then never wait for global memory again
+  const int my_i = (tid < N) ? (int)ii[tid] : -1, my_j = (tid < N) ? (int)jj[tid] : -1;
+  auto src = [&](int n) { return (n == tid) ? my_i : (int)ii[n]; };
+  auto dst = [&](int n) { return (n == tid) ? my_j : (int)jj[n]; };
 
   for (int f = tid; f < B; f += nt) flag[f] = 0;
-  for (int n = tid; n < N; n += nt) T.elist_rank[n] = 0;
+  for (int m = tid; m <= T.Mmax; m += nt) cnt[m] = 0;
   __syncthreads();
   for (int p = tid; p < P; p += nt) {
     const int f = t0 + p;
     if (f >= 0 && f < B) flag[f] = 1;
   }
   for (int n = tid; n < N; n += nt) {
-    const int f = (int)ii[n];
+    const int f = src(n);
     if (f >= 0 && f < B) flag[f] = 1;
   }
   __syncthreads();
 
-  // exclusive scan of flag over frames: each thread owns a contiguous run
+  // exclusive scan of flag over frames: each thread owns a contiguous run; wave scans + one pass over the wave sums
   const int per = (B + nt - 1) / nt;
   const int lo = min(tid * per, B), hi = min(lo + per, B);
   int c = 0;
   for (int f = lo; f < hi; f++) c += flag[f];
-  scan[tid] = c;
+  const int incl = wave_incl_scan(c, lane);
+  if (lane == 63) scan[wave] = incl;
   __syncthreads();
-  for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
-    const int v = (tid >= off) ? scan[tid - off] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  if (wave == 0) {
+    const int v = (lane < nw) ? scan[lane] : 0;
+    const int w = wave_incl_scan(v, lane);
+    if (lane < nw) scan[16 + lane] = w;  // inclusive sums of the waves
   }
-  int slot = scan[tid] - c;
-  const int M = scan[nt - 1];
+  __syncthreads();
+  int slot = incl - c + (wave > 0 ? scan[16 + wave - 1] : 0);
+  const int M = scan[16 + nw - 1];
   for (int f = lo; f < hi; f++) {
     if (flag[f]) {
-      if (slot < T.Mmax) T.kx[slot] = f;
+      if (slot < T.Mmax) T.kx[slot] = f, kxs[slot] = f;
       T.frame_slot[f] = (slot < T.Mmax) ? slot : -1;
       flag[f] = slot + 1;  // keep slot+1 in LDS for the passes below
       slot++;
@@ -72,83 +91,99 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
       T.frame_slot[f] = -1;
     }
   }
-  for (int m = tid; m <= T.Mmax; m += nt) cnt[m] = 0;
-  __syncthreads();
   if (tid == 0) {
     T.meta[0] = min(M, T.Mmax);
     T.meta[1] = 0;
     T.meta[2] = (M > T.Mmax) ? 1 : 0;
   }
+  __syncthreads();
+  auto slot_of = [&](int f) { return (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax) ? flag[f] - 1 : -1; };
 
-  // out-edges per slot
+  // out-edges per slot, then their exclusive scan (wave 0, 64 slots at a time with a running carry)
   for (int n = tid; n < N; n += nt) {
-    const int f = (int)ii[n];
-    if (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax) atomicAdd(&cnt[flag[f] - 1], 1);
+    const int m = slot_of(src(n));
+    if (m >= 0) atomicAdd(&cnt[m], 1);
   }
   __syncthreads();
-  if (tid == 0) {  // Mmax is small (<= P+N): a serial exclusive scan is a few hundred cycles
-    int run = 0;
-    for (int m = 0; m < T.Mmax; m++) {
-      const int v = cnt[m];
-      cnt[m] = run;
-      T.eoff[m] = run;
-      run += v;
+  if (wave == 0) {
+    int carry = 0;
+    for (int base = 0; base <= T.Mmax; base += 64) {
+      const int m = base + lane;
+      const int v = (m < T.Mmax) ? cnt[m] : 0;
+      const int w = wave_incl_scan(v, lane);
+      if (m <= T.Mmax) {
+        cnt[m] = carry + w - v;
+        T.eoff[m] = carry + w - v;
+      }
+      carry += __shfl(w, 63, 64);
     }
-    cnt[T.Mmax] = run;
-    T.eoff[T.Mmax] = run;
   }
   __syncthreads();
-  // ascending-n fill: position = #earlier edges with the same source frame (source frames staged in LDS,
-  // in chunks, so the O(N^2) comparison never goes back to global memory)
-  int *sii = scan;  // 1024 ints, free after the scan
-  for (int base = 0; base < N; base += 1024) {
+  // ascending-n fill: position = #earlier edges with the same source frame (source frames staged in LDS, so the
+  // O(N^2) comparison never goes back to global memory)
+  int *sii = scan;
+  if (N <= nt) {  // the usual case: one pass, the rank stays in a register
+    if (tid < N) sii[tid] = my_i;
     __syncthreads();
-    if (base + tid < N) sii[tid] = (int)ii[base + tid];
+    if (tid < N) {
+      const int f = sii[tid], m = slot_of(f);
+      if (m >= 0) {
+        int rank = 0;
+        for (int q = 0; q < tid; q++) rank += (sii[q] == f);
+        T.elist[cnt[m] + rank] = tid;
+      }
+    }
+  } else {        // chunks of 1024 source frames, ranks accumulated in global scratch
+    for (int n = tid; n < N; n += nt) T.elist_rank[n] = 0;
+    for (int base = 0; base < N; base += 1024) {
+      __syncthreads();
+      for (int q = tid; q < 1024 && base + q < N; q += nt) sii[q] = (int)ii[base + q];
+      __syncthreads();
+      const int lim = min(1024, N - base);
+      for (int n = tid; n < N; n += nt) {
+        if (n <= base) continue;
+        const int f = (int)ii[n];
+        if (slot_of(f) < 0) continue;
+        int rank = 0;
+        const int qend = min(lim, n - base);
+        for (int q = 0; q < qend; q++) rank += (sii[q] == f);
+        T.elist_rank[n] += rank;  // (each n belongs to one thread)
+      }
+    }
     __syncthreads();
-    const int lim = min(1024, N - base);
     for (int n = tid; n < N; n += nt) {
-      if (n <= base) continue;
-      const int f = (int)ii[n];
-      if (!(f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax)) continue;
-      int rank = 0;
-      const int qend = min(lim, n - base);
-      for (int q = 0; q < qend; q++) rank += (sii[q] == f);
-      atomicAdd(&T.elist_rank[n], rank);
+      const int m = slot_of((int)ii[n]);
+      if (m >= 0) T.elist[cnt[m] + T.elist_rank[n]] = n;
     }
-  }
-  __syncthreads();
-  for (int n = tid; n < N; n += nt) {
-    const int f = (int)ii[n];
-    if (!(f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax)) continue;
-    T.elist[cnt[flag[f] - 1] + T.elist_rank[n]] = n;
   }
   // Skyline of the reduced camera system at pose granularity, for the solver: the poses in
   // S_i = {targets of the edges leaving frame i} U {i} (window poses only) are mutually coupled (pose blocks and the
   // Schur products E Q E^T of the frame), so fpose[a] = min over the sets containing a of min S_i.
-  __threadfence_block();
   __syncthreads();
   const int Mv = min(M, T.Mmax);
-  int *minS = cnt;  // the offsets are in T.eoff by now
+  int *minS = cnt;    // the offsets are in T.eoff by now
+  int *fps = scan;    // fpose, built in LDS (P <= Mmax <= the scan area? no: P <= 1024 is checked by the host)
   for (int m = tid; m < Mv; m += nt) {
-    const int pp = T.kx[m] - t0;
+    const int pp = kxs[m] - t0;
     minS[m] = (pp >= 0 && pp < P) ? pp : 0x7fffffff;
   }
-  for (int pp = tid; pp < P; pp += nt) T.fpose[pp] = pp;
-  __threadfence_block();
+  for (int pp = tid; pp < P; pp += nt) fps[pp] = pp;
   __syncthreads();
   for (int n = tid; n < N; n += nt) {
-    const int f = (int)ii[n], tg = (int)jj[n] - t0;
-    if (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax && tg >= 0 && tg < P) atomicMin(&minS[flag[f] - 1], tg);
+    const int m = slot_of(src(n)), tg = dst(n) - t0;
+    if (m >= 0 && tg >= 0 && tg < P) atomicMin(&minS[m], tg);
   }
   __syncthreads();
   for (int n = tid; n < N; n += nt) {
-    const int f = (int)ii[n], tg = (int)jj[n] - t0;
-    if (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax && tg >= 0 && tg < P) atomicMin(&T.fpose[tg], minS[flag[f] - 1]);
+    const int m = slot_of(src(n)), tg = dst(n) - t0;
+    if (m >= 0 && tg >= 0 && tg < P) atomicMin(&fps[tg], minS[m]);
   }
   for (int m = tid; m < Mv; m += nt) {
-    const int pp = T.kx[m] - t0;
-    if (pp >= 0 && pp < P) atomicMin(&T.fpose[pp], minS[m]);
+    const int pp = kxs[m] - t0;
+    if (pp >= 0 && pp < P) atomicMin(&fps[pp], minS[m]);
   }
+  __syncthreads();
+  for (int pp = tid; pp < P; pp += nt) T.fpose[pp] = fps[pp];
 }
 
 // ---------------------------------------------------------------------------------------------

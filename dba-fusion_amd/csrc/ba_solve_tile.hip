@@ -403,7 +403,11 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
   // entry i of the panel of j's pair (a column panel for the top front / middle, a row panel for the bottom
   // front): lane l keeps t_j for the columns j = l, l + 64, l + 128 and reads its panels by unknown index.  Order =
   // reverse elimination: the middle downwards, then the top front's pairs downwards and the bottom front's upwards.
-  if (wave == 0) {
+  // With two fronts the substitution's two chains run on two waves (different SIMDs): both walk the middle, then
+  // wave 0 takes the top front's pairs and wave 1 the bottom front's (a lone wave is issue-bound here as well, so
+  // interleaving the chains in one wave buys nothing - measured).
+  const bool two_waves = c1 > 0 && blockDim.x >= 128;  // (tiny systems have a single wave: it walks both chains)
+  if (wave == 0 || (wave == 1 && two_waves)) {
     double t[3];
     int cbase[3];  // coef(i, j) = C[cbase + 2 i] for this lane's column j (columns past n alias column 0; masked)
 #pragma unroll
@@ -481,30 +485,40 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
       down(I2{}, I2{}, mlo, mhi);
       down(I1{}, I2{}, mlo, mhi);
       down(I0{}, I2{}, mlo, mhi);
-      down(I2{}, I2{}, 0, mlo - 1);
-      down(I1{}, I1{}, 0, mlo - 1);
-      down(I0{}, I0{}, 0, mlo - 1);
-      up(I0{}, mhi + 1, npairs - 1);
-      up(I1{}, mhi + 1, npairs - 1);
-      up(I2{}, mhi + 1, npairs - 1);
+      if (wave == 0) {
+        down(I2{}, I2{}, 0, mlo - 1);
+        down(I1{}, I1{}, 0, mlo - 1);
+        down(I0{}, I0{}, 0, mlo - 1);
+      }
+      if (wave == 1 || !two_waves) {
+        up(I0{}, mhi + 1, npairs - 1);
+        up(I1{}, mhi + 1, npairs - 1);
+        up(I2{}, mhi + 1, npairs - 1);
+      }
     } else {
       down(I2{}, I2{}, 0, npairs - 1);
       down(I1{}, I1{}, 0, npairs - 1);
       down(I0{}, I0{}, 0, npairs - 1);
     }
 
-    // non-finite results count as failure too; failure => zero update (:1263-1266)
+    // non-finite results count as failure too; failure => zero update (:1263-1266).  Wave 0 owns the columns of the
+    // middle and the top front, wave 1 those of the bottom front
+    const int jsplit = two_waves ? n - 4 * c1 : n;
     bool bad = false;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-      if (lane + 64 * r < n && !isfinite(xo[r])) bad = true;
-    const int failed = (*fail != 0) || (__ballot(bad) != 0ull);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const int j = lane + 64 * r;
-      if (j < n) dx[j] = failed ? 0.f : (float)xo[r];
+      if (j < n && (wave == 0) == (j < jsplit) && !isfinite(xo[r])) bad = true;
     }
-    if (lane == 0) meta[1] = failed;
+    if (__ballot(bad) != 0ull && lane == 0) *fail = 1;
+    if (two_waves) __syncthreads();  // (only these two waves are still alive: the others have left the kernel)
+    const int failed = (*fail != 0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int j = lane + 64 * r;
+      if (j < n && (wave == 0) == (j < jsplit)) dx[j] = failed ? 0.f : (float)xo[r];
+    }
+    if (tid == 0) meta[1] = failed;
   }
   TPROF(3);
 #if defined(PROFILE_SOLVE) && defined(TILE_DEBUG_DUMP)
