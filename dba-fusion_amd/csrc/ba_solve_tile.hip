@@ -363,6 +363,15 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
       if (valid & (I == Kbn) & (Kbn <= cmK) & (s + 1 < 2 * c1)) publish_bottom(bbn, sb - 1, hc);
     }
     if (topA | botA) {
+      // (the elements are pinned behind the publish: left alone, the compiler hoists these FMAs over the stores
+      // and the hand-off waits for the whole tile again)
+      auto pin_quarter = [&](int rh, int ch) {
+        asm volatile("" : "+v"(a[2 * rh][2 * ch]), "+v"(a[2 * rh][2 * ch + 1]), "+v"(a[2 * rh + 1][2 * ch]),
+                     "+v"(a[2 * rh + 1][2 * ch + 1]));
+      };
+      if (!BOT) pin_quarter(h, h), pin_quarter(hn, h);
+      if (BOT && TOP) pin_quarter(hn, h);
+      if (BOT && !TOP) pin_quarter(hn, h), pin_quarter(hn, hn);
       if (!BOT) quarter(h, h);
       if (TOP) quarter(hn, h);
       if (BOT && !TOP) quarter(hn, h), quarter(hn, hn);
