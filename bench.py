@@ -99,7 +99,13 @@ def main():
             s_ = slice(c0, min(c0 + 32, n_loc))
             cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3)
             corr = cb if corr is None else corr.cat(cb)
-    poses, disps = poses0.clone(), disps0.clone()
+    # poses and disparities live in one buffer, so that the per-step state reset is a single copy
+    npose = poses0.numel()
+    pad = (-npose) % 64
+    state0 = torch.cat([poses0.reshape(-1), poses0.new_zeros(pad), disps0.reshape(-1)])
+    state = state0.clone()
+    poses = state[:npose].view_as(poses0)
+    disps = state[npose + pad:].view_as(disps0)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
     ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 1)]
@@ -107,8 +113,7 @@ def main():
     def step(i):
         if args.step_events:
             ev_step[i].record()
-        poses.copy_(poses0)
-        disps.copy_(disps0)
+        state.copy_(state0)
         coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
         ev[2 * i].record()
         c = corr(coords1) if corr is not None else None
