@@ -348,8 +348,11 @@ struct FrameReduce {  // 27 per-frame sums held in fsum[]
 // 63 x (4 flops + one LDS deposit) + 27 x 4 flops per lane and the 17 KB transpose tile by 28 deposits and 8.5 KB.
 typedef float lin_f4 __attribute__((ext_vector_type(4)));
 constexpr int MFS_T = 32;                      // K steps of 4 residual rows
-constexpr int MFS_VALS = 4 * 16 * MFS_T;       // staged [k][i][t]
-constexpr int MFS_FLOATS = MFS_VALS + 4 * MFS_T;  // + weights [k][t]
+constexpr int MFS_P = 36;                      // row pitch in floats: the 16 rows a 16-lane group reads with one
+                                               // ds_read_b128 start 36 banks apart (pitch 32: 8-way conflicts, which
+                                               // made the operand reads the kernel's bottleneck)
+constexpr int MFS_VALS = 4 * 16 * MFS_P;       // staged [k][i][t]
+constexpr int MFS_FLOATS = MFS_VALS + 4 * MFS_P;  // + weights [k][t]
 
 template <int PPL, bool MF>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(
@@ -433,7 +436,6 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
       for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = R.r[c];
     }
     __syncthreads();
-
     float nx_t[PPL][2], nx_w[PPL][2];  // prefetched targets / weights of the next edge
     {
       const int n = s_edge[0][0];
@@ -508,35 +510,40 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
         }
 #endif
       }
-
       float acc;
       if constexpr (MF) {
         static_assert(!MF || PPL == 1, "the matrix-core reduction is written for one pixel per lane");
         // stage: residual row kappa = 2 lane + c -> [k = kappa & 3][value i][t = kappa >> 2]
         {
           const int t_ = lane >> 1, k0 = 2 * (lane & 1);
-          float *su = red_wave + (k0 * 16) * MFS_T + t_, *sv = su + 16 * MFS_T;
+          float *su = red_wave + (k0 * 16) * MFS_P + t_, *sv = su + 16 * MFS_P;
 #pragma unroll
           for (int i = 0; i < 12; i++) {
-            su[i * MFS_T] = L[0].Ju[i];
-            sv[i * MFS_T] = L[0].Jv[i];
+            su[i * MFS_P] = L[0].Ju[i];
+            sv[i * MFS_P] = L[0].Jv[i];
           }
-          su[12 * MFS_T] = L[0].ru;
-          sv[12 * MFS_T] = L[0].rv;
-          red_wave[MFS_VALS + k0 * MFS_T + t_] = L[0].wu;
-          red_wave[MFS_VALS + (k0 + 1) * MFS_T + t_] = L[0].wv;
+          su[12 * MFS_P] = L[0].ru;
+          sv[12 * MFS_P] = L[0].rv;
+          red_wave[MFS_VALS + k0 * MFS_P + t_] = L[0].wu;
+          red_wave[MFS_VALS + (k0 + 1) * MFS_P + t_] = L[0].wv;
         }
         wave_lds_fence();
         lin_f4 c4 = {0.f, 0.f, 0.f, 0.f};
         {
-          const lin_f4 *xs = reinterpret_cast<const lin_f4 *>(red_wave + ((lane >> 4) * 16 + (lane & 15)) * MFS_T);
-          const lin_f4 *ws = reinterpret_cast<const lin_f4 *>(red_wave + MFS_VALS + (lane >> 4) * MFS_T);
+          const lin_f4 *xs = reinterpret_cast<const lin_f4 *>(red_wave + ((lane >> 4) * 16 + (lane & 15)) * MFS_P);
+          const lin_f4 *ws = reinterpret_cast<const lin_f4 *>(red_wave + MFS_VALS + (lane >> 4) * MFS_P);
+          lin_f4 c4b = {0.f, 0.f, 0.f, 0.f};  // two accumulators: the 32 products are not one dependent chain
 #pragma unroll
-          for (int t4 = 0; t4 < MFS_T / 4; t4++) {
-            const lin_f4 x = xs[t4], w4 = ws[t4];
+          for (int t4 = 0; t4 < MFS_T / 4; t4 += 2) {
+            const lin_f4 x = xs[t4], w4 = ws[t4], y = xs[t4 + 1], v4 = ws[t4 + 1];
 #pragma unroll
-            for (int e = 0; e < 4; e++) c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e] * w4[e], x[e], c4, 0, 0, 0);
+            for (int e = 0; e < 4; e++) {
+              c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e] * w4[e], x[e], c4, 0, 0, 0);
+              c4b = __builtin_amdgcn_mfma_f32_16x16x4f32(y[e] * v4[e], y[e], c4b, 0, 0, 0);
+            }
           }
+#pragma unroll
+          for (int r = 0; r < 4; r++) c4[r] += c4b[r];
         }
         wave_lds_fence();
         // D: register r <-> row 4 (lane >> 4) + r, column lane & 15.  Rows 6..11 are this edge's Hji | Hjj | vj;
