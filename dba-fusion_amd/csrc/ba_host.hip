@@ -54,6 +54,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const size_t o_elist = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
   const size_t o_erank = take(sizeof(int) * (size_t)(N > 0 ? N : 1));
   const size_t o_fpose = take(sizeof(int) * (size_t)(P > 0 ? P : 1));
+  const size_t o_einfo = take(sizeof(int) * 2 * (size_t)(N > 0 ? N : 1));
+  const size_t o_rowinfo = take(sizeof(int) * 8 * (size_t)(P + N > 0 ? P + N : 1));
   L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
@@ -85,6 +87,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->T.elist = reinterpret_cast<int *>(base + o_elist);
     plan->T.elist_rank = reinterpret_cast<int *>(base + o_erank);
     plan->T.fpose = reinterpret_cast<int *>(base + o_fpose);
+    plan->T.einfo = reinterpret_cast<int *>(base + o_einfo);
+    plan->T.rowinfo = reinterpret_cast<int *>(base + o_rowinfo);
     plan->T.Mmax = Mmax;
     plan->T.B = B;
     plan->W.E = reinterpret_cast<float *>(base + L.E);

@@ -24,6 +24,11 @@ struct BaTables {
   int *elist;       // [N]      edge ids, ascending within a slot
   int *elist_rank;  // [N]      scratch of the prepare kernel
   int *fpose;       // [P]      first pose (index - t0) the reduced system couples pose p with (edges + Schur fill)
+  // flat copies of the above for the per-iteration kernels: one table row per workgroup instead of a chain of
+  // dependent lookups (ii -> frame_slot -> eoff -> elist -> jj is five round trips of ~1 us each before any work)
+  int *einfo;       // [N][2]     per list position: edge id, target frame jj
+  int *rowinfo;     // [P+N][8]   per row of E (pose p | P + edge n): slot (-1: nothing to do), target pose - t0,
+                    //            first partner position, end of the slot's list, source frame
   int Mmax, B;
 };
 

@@ -98,6 +98,14 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   }
   __syncthreads();
   auto slot_of = [&](int f) { return (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax) ? flag[f] - 1 : -1; };
+  // flat tables for the per-iteration kernels (needs cnt = exclusive offsets)
+  auto emit_edge = [&](int n, int m, int pos, int jx) {
+    const int tg = jx - t0;
+    int *ri = T.rowinfo + 8 * (P + n);
+    const bool ok = m >= 0 && tg >= 0 && tg < P;
+    ri[0] = ok ? m : -1, ri[1] = tg, ri[2] = pos + 1, ri[3] = (m >= 0) ? cnt[m + 1] : 0, ri[4] = (m >= 0) ? kxs[m] : -1;
+    if (pos >= 0) T.einfo[2 * pos] = n, T.einfo[2 * pos + 1] = jx;
+  };
 
   // out-edges per slot, then their exclusive scan (wave 0, 64 slots at a time with a running carry)
   for (int n = tid; n < N; n += nt) {
@@ -127,11 +135,14 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     __syncthreads();
     if (tid < N) {
       const int f = sii[tid], m = slot_of(f);
+      int pos = -1;
       if (m >= 0) {
         int rank = 0;
         for (int q = 0; q < tid; q++) rank += (sii[q] == f);
-        T.elist[cnt[m] + rank] = tid;
+        pos = cnt[m] + rank;
+        T.elist[pos] = tid;
       }
+      emit_edge(tid, m, pos, my_j);
     }
   } else {        // chunks of 1024 source frames, ranks accumulated in global scratch
     for (int n = tid; n < N; n += nt) T.elist_rank[n] = 0;
@@ -153,8 +164,15 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     __syncthreads();
     for (int n = tid; n < N; n += nt) {
       const int m = slot_of((int)ii[n]);
-      if (m >= 0) T.elist[cnt[m] + T.elist_rank[n]] = n;
+      const int pos = (m >= 0) ? cnt[m] + T.elist_rank[n] : -1;
+      if (m >= 0) T.elist[pos] = n;
+      emit_edge(n, m, pos, (int)jj[n]);
     }
+  }
+  for (int p = tid; p < P; p += nt) {  // pose rows: partners are the whole list of the pose's own frame
+    const int m = slot_of(t0 + p);
+    int *ri = T.rowinfo + 8 * p;
+    ri[0] = m, ri[1] = p, ri[2] = (m >= 0) ? cnt[m] : 0, ri[3] = (m >= 0) ? cnt[m + 1] : 0, ri[4] = t0 + p;
   }
   // Skyline of the reduced camera system at pose granularity, for the solver: the poses in
   // S_i = {targets of the edges leaving frame i} U {i} (window poses only) are mutually coupled (pose blocks and the
@@ -423,8 +441,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const int cnt = min(64, e1 - batch);
     __syncthreads();
     if ((int)threadIdx.x < cnt) {
-      const int n = T.elist[batch + threadIdx.x];
-      const int jx = (int)jj[n];
+      const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * (batch + threadIdx.x));
+      const int n = ei.x, jx = ei.y;
       float tij[3], qij[4];
       edge_pose(poses, frame, jx, tij, qij);
       const Rot3 R = quat_to_rot(qij);
@@ -749,29 +767,12 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
     if (blockIdx.y == 0 && blockIdx.z == 0) ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, T, W);
     return;
   }
+  // everything a row needs comes from its table row (one load): slot, target pose, partner range, source frame
   const int r1 = blockIdx.x;
-  int frame, tgt1;
-  if (r1 < P) {
-    frame = t0 + r1;
-    tgt1 = r1;
-  } else {
-    frame = (int)ii[r1 - P];
-    tgt1 = (int)jj[r1 - P] - t0;
-  }
-  if (tgt1 < 0 || tgt1 >= P) return;
-  if (frame < 0 || frame >= T.B) return;
-  const int m = T.frame_slot[frame];
+  const int4 ri = *reinterpret_cast<const int4 *>(T.rowinfo + 8 * r1);
+  const int m = ri.x, tgt1 = ri.y, first_partner = ri.z, e1 = ri.w;  // partners: r1 itself, then list positions [first_partner, e1)
   if (m < 0) return;
-  if (frame_owned && !frame_owned[frame]) return;
-  const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
-  int first_partner;  // partners: r1 itself, then edges elist[first_partner ..)
-  if (r1 < P) {
-    first_partner = e0;
-  } else {
-    first_partner = e1;
-    for (int e = e0; e < e1; e++)
-      if (T.elist[e] == r1 - P) { first_partner = e + 1; break; }
-  }
+  if (frame_owned && !frame_owned[T.rowinfo[8 * r1 + 4]]) return;
   const int chunk = (HW + gridDim.z - 1) / gridDim.z;
   const int k0 = blockIdx.z * chunk, k1 = min(HW, k0 + chunk);
 
@@ -781,8 +782,9 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
 
   for (int pe = first_partner - 1 + (int)blockIdx.y; pe < e1; pe += gridDim.y) {
     const bool self = (pe == first_partner - 1);
-    const int r2 = self ? r1 : P + T.elist[pe];
-    const int tgt2 = self ? tgt1 : (int)jj[r2 - P] - t0;
+    const int2 ei = self ? make_int2(0, 0) : *reinterpret_cast<const int2 *>(T.einfo + 2 * pe);
+    const int r2 = self ? r1 : P + ei.x;
+    const int tgt2 = self ? tgt1 : ei.y - t0;
     if (tgt2 < 0 || tgt2 >= P) continue;
     const float *E2 = W.E + (size_t)r2 * 6 * HW;
 
