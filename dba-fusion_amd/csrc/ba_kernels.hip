@@ -920,8 +920,9 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
   }
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
   for (int e = e0; e < e1; e++) {
-    const int n = T.elist[e];
-    const int tgt = (int)jj[n] - t0;
+    const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * e);  // edge id, target frame: one lookup
+    const int n = ei.x;
+    const int tgt = ei.y - t0;
     if (tgt <= 0 || tgt >= P) continue;
     const float *Er = W.E + ((size_t)(P + n) * 6) * HW + k;
     const float *x = W.dx + 6 * tgt;

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_ba.py tests/test_gpu_sharded.py tests/test_gpu_entrypoints.py -x -q 2>&1 | tail -5 > gpurun_out/tests.log
-timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_tab.json 2>/dev/null
-cd /tmp; export TMPDIR=/tmp; O=/root/repo/gpurun_out; rm -rf $O/tab_trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/tab_trace -- python /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp $(ls -t $(find $O/tab_trace -name "*kernel_stats.csv") | head -1) $O/tab_kernel_stats.csv
+{
+echo "== measured skyline"; timeout 120 scratch/bin/solve_twist 2>&1 | grep -E "MISMATCH|tile :|stages" | grep -v "0.[0-9]* us per\|0.00 factor" | head -4
+echo "== graph skyline"; HARNESS_FPOSE=1 timeout 120 scratch/bin/solve_twist 2>&1 | grep -v "block:\|band :\|ticks" | grep -v "^band"
+} > gpurun_out/solve_ab.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_solve.py tests/test_gpu_ba.py -x -q 2>&1 | tail -3 > gpurun_out/tests.log
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_sky.json 2>/dev/null
