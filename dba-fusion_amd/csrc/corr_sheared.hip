@@ -288,9 +288,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
         for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
       }
     } else {
-      const int bx0 = wave_minmax<true>(inlier ? ox : big), bx1 = wave_minmax<false>(inlier ? ox : -big);
+      const int bx0 = wave_minmax<true>(inlier ? ox : big);
       const int by0 = wave_minmax<true>(inlier ? oy : big), by1 = wave_minmax<false>(inlier ? oy : -big);
-      const int nx = bx1 - bx0 + WN, ny = min(by1 - by0 + WN, SH_NY);  // nx <= 16, ny <= 16 by construction
+      const int ny = min(by1 - by0 + WN, SH_NY);  // (the union is at most 16 x 16 by construction)
       // window origin of this lane inside the union (0 for lanes that stream nothing: they read row 0 with zero
       // weights and emit exact zeros -- except outliers, whose outputs are left to the gather phase)
       const int rx = inlier ? ox - bx0 : 0, ry = inlier ? oy - by0 : 0;

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-for w in 32_122 64_512; do timeout 300 python bench.py --no-cpu-baseline --window $w > gpurun_out/r01_bench_$w.json 2>/dev/null; done
+timeout 900 python -m pytest tests/test_gpu_corr.py tests/test_gpu_entrypoints.py -x -q 2>&1 | tail -3 > gpurun_out/tests.log
