@@ -74,7 +74,7 @@ __device__ __host__ __forceinline__ int bottom_stride(int n) {
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__restrict__ H,
                                                                          const double *__restrict__ bvec,
-                                                                         int n, double lm, double ep,
+                                                                         int n_in, int n, double lm, double ep,
                                                                          float *__restrict__ dx,
                                                                          int *__restrict__ meta, int cb_doubles
 #ifdef PROFILE_SOLVE
@@ -88,6 +88,8 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
 #define TPROF(slot)
 #endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // n_in = size of the system; n = n_in, or n_in + 2 when the host pads a system with n_in % 4 == 2 by two decoupled
+  // unknowns (unit diagonal, zero right-hand side, solution 0) so that it qualifies for the two-front elimination
   const int n1 = n + 1;                 // rows incl. the right-hand side
   const int T = (n1 + 3) >> 2;          // row tiles
   const int KT = (n + 3) >> 2;          // column tiles
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const int i = 4 * I + r, k = 4 * K + c;
-      okm[r][c] = valid && k < n && i <= n;
+      okm[r][c] = valid && k < n_in && (i < n_in || i == n);   // (padding unknowns: zero, unit diagonal below)
       const int hi = max(i, k), lo = min(i, k);   // diagonal tiles keep the mirrored upper half
-      const double *q = (i == n) ? bvec + k : H + (size_t)hi * n + lo;
+      const double *q = (i == n) ? bvec + k : H + (size_t)hi * n_in + lo;
       src[r][c] = okm[r][c] ? q : H;
     }
   }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       double v = okm[r][c] ? a[r][c] : 0.0;
-      if (4 * I + r == 4 * K + c && 4 * I + r < n) v += ep + lm * v;  // damping (:1252-1253)
+      if (4 * I + r == 4 * K + c && 4 * I + r < n) v = (4 * I + r < n_in) ? v + (ep + lm * v) : 1.0;  // damping (:1252-1253)
       a[r][c] = v;
       nz |= (v != 0.0);
     }
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const int j = lane + 64 * r;
-      if (j < n && (wave == 0) == (j < jsplit)) dx[j] = failed ? 0.f : (float)xo[r];
+      if (j < n_in && (wave == 0) == (j < jsplit)) dx[j] = failed ? 0.f : (float)xo[r];
     }
     if (tid == 0) meta[1] = failed;
   }
@@ -567,11 +569,18 @@ int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, dou
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_set = true;
   }
-  const int T = tile_rows(n);
-  const int threads = ((T * (T + 1) / 2 + 63) / 64) * 64;
   // what is left of the LDS holds the bottom front's row panels (DBA_SOLVE_TWIST=0: one front only)
   static const bool twist = [] { const char *e = getenv("DBA_SOLVE_TWIST"); return !(e && e[0] == '0'); }();
-  const int cb_doubles = twist ? (int)((SOLVE_MAX_LDS_BYTES - tile_lds_bytes(n)) / sizeof(double)) : 0;
+  // n % 4 == 2 (an odd number of poses): two padding unknowns make the system eligible for two fronts, as long as
+  // the padded system still fits the 768-thread variant
+  int nw = n;
+  if (twist && (n & 3) == 2) {
+    const int Tp = tile_rows(n + 2);
+    if (Tp * (Tp + 1) / 2 <= 768 && tile_lds_bytes(n + 2) <= (size_t)SOLVE_MAX_LDS_BYTES) nw = n + 2;
+  }
+  const int T = tile_rows(nw);
+  const int threads = ((T * (T + 1) / 2 + 63) / 64) * 64;
+  const int cb_doubles = twist ? (int)((SOLVE_MAX_LDS_BYTES - tile_lds_bytes(nw)) / sizeof(double)) : 0;
 #ifdef PROFILE_SOLVE
   extern long long *g_tile_prof;
 #define TILE_PROF_ARG , g_tile_prof
@@ -579,11 +588,11 @@ int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, dou
 #define TILE_PROF_ARG
 #endif
   if (threads <= 768)
-    hipLaunchKernelGGL(ba_solve_tile_kernel<768>, dim3(1), dim3(threads), SOLVE_MAX_LDS_BYTES, stream, H, b, n, lm, ep,
-                       dx, meta, cb_doubles TILE_PROF_ARG);
+    hipLaunchKernelGGL(ba_solve_tile_kernel<768>, dim3(1), dim3(threads), SOLVE_MAX_LDS_BYTES, stream, H, b, n, nw, lm,
+                       ep, dx, meta, cb_doubles TILE_PROF_ARG);
   else
     hipLaunchKernelGGL(ba_solve_tile_kernel<TILE_MAX_THREADS>, dim3(1), dim3(threads), SOLVE_MAX_LDS_BYTES, stream, H,
-                       b, n, lm, ep, dx, meta, cb_doubles TILE_PROF_ARG);
+                       b, n, nw, lm, ep, dx, meta, cb_doubles TILE_PROF_ARG);
 #undef TILE_PROF_ARG
   DBA_LAUNCH_CHECK();
   return DBA_OK;
