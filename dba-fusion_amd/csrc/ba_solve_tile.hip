@@ -199,11 +199,7 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
     if (lane == 0) fail[1] = c1;
   }
   __syncthreads();
-#ifdef TILE_NO_TWIST
-  constexpr int c1 = 0;
-#else
   const int c1 = __builtin_amdgcn_readfirstlane(fail[1]);  // wave-uniform: keeps the loop control on the scalar unit
-#endif
   const int sstart = valid ? max(first[I], first[min(K, T - 1)]) : 0x3fffffff;
   const int cmK = (c1 > 0 && valid) ? colmax[K] : -1;           // the bottom front reaches this tile from row cmK up
   const bool frozen = c1 > 0 && !rhs && I >= KT - c1;          // rows the bottom front eliminates
@@ -532,17 +528,6 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
     if (tid == 0) meta[1] = failed;
   }
   TPROF(3);
-#if defined(PROFILE_SOLVE) && defined(TILE_DEBUG_DUMP)
-  __syncthreads();
-  {  // smem image: [0] = doubles of C, [1] = PBS, [2] = c1, then C | pinv | Cb (2 c1 slots)
-    double *dbg = (double *)(prof + 64);
-    const int nc = pair_off(npairs, T);
-    if (tid == 0) dbg[0] = nc, dbg[1] = PBS, dbg[2] = c1;
-    for (int e = tid; e < nc; e += blockDim.x) dbg[4 + e] = C[e];
-    for (int e = tid; e < 4 * npairs; e += blockDim.x) dbg[4 + nc + e] = pinv[e];
-    for (int e = tid; e < 2 * c1 * PBS; e += blockDim.x) dbg[4 + nc + 4 * npairs + e] = Cb[e];
-  }
-#endif
 }
 
 static int tile_rows(int n) { return (n + 1 + 3) / 4; }

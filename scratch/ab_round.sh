@@ -1,7 +1,3 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out
-{
-echo "== twist"; timeout 120 scratch/bin/solve_twist 2>&1 | grep -v "block:\|band :\|ticks" | grep -v "^band"
-echo "== one front"; DBA_SOLVE_TWIST=0 timeout 120 scratch/bin/solve_twist 2>&1 | grep -E "n=138|MISMATCH" -A2 | grep -v "block:\|band :\|ticks"
-} > gpurun_out/solve_ab.log 2>&1
-timeout 900 python -m pytest tests/test_gpu_solve.py tests/test_gpu_ba.py -x -q 2>&1 | tail -3 > gpurun_out/tests.log
+cd /tmp; export TMPDIR=/tmp; O=/root/repo/gpurun_out; rm -rf $O/sr_trace
+DBA_HIP_LIB=/root/repo/scratch/abl/libdba_hip_schurred.so rocprofv3 --kernel-trace --stats --output-format csv -d $O/sr_trace -- python /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; cp $(ls -t $(find $O/sr_trace -name "*kernel_stats.csv") | head -1) $O/sr_kernel_stats.csv

@@ -41,10 +41,6 @@ int run(int n, int band, bool spd, bool timeit) {
   std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("%s n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", use_tile ? "tile" : "band", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
-#ifdef TILE_DEBUG_DUMP
-  if (getenv("HARNESS_DUMP") && n == atoi(getenv("HARNESS_DUMP")) && use_tile) { std::vector<double> img(1 << 17); hipMemcpy(img.data(), (char*)dba::g_tile_prof + 512, 8 << 17, hipMemcpyDeviceToHost);
-    char fn[128]; snprintf(fn, 128, "gpurun_out/tile_dump_n%d_b%d.bin", n, band); FILE* f = fopen(fn, "wb"); double hdr[2] = {(double)n, (double)band}; fwrite(hdr, 8, 2, f); fwrite(H.data(), 8, n*n, f); fwrite(b.data(), 8, n, f); fwrite(img.data(), 8, 1 << 17, f); fclose(f); }
-#endif
   if (getenv("HARNESS_DUMP") && n <= 64) { for (int i = 0; i < n; i++) printf("    x[%2d] dev % .6e ref % .6e%s\n", i, x[i], ok ? xr[i] : 0.0, fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6 ? "  <--" : ""); }
   if (timeit) { long long hp[12]; hipMemcpy(hp, dba::g_band_prof, 96, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld\n", hp[0],hp[1],hp[2],hp[3],hp[4]); }
   hipMemset(dba::g_band_prof, 0, 128);
