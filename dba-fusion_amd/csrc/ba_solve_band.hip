@@ -400,7 +400,9 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       xo[r0] = (lane == l0) ? x0 : ((lane == l0 + 1) ? x1 : xo[r0]);
     };
     // several steps per LDS round trip (four while the register budget allows it)
-    constexpr int CH = GP ? 4 : ((r0 <= 2) ? 4 : 2);
+    // (panels in global memory: one round trip per chunk, so the chunk is as long as the registers allow - each
+    // step in flight holds 2 (r0 + 1) + 3 doubles)
+    constexpr int CH = GP ? (r0 == 0 ? 16 : r0 == 1 ? 12 : r0 == 2 ? 10 : r0 == 3 ? 8 : r0 == 4 ? 7 : 6) : ((r0 <= 2) ? 4 : 2);
     for (int s = shi; s >= slo; s -= CH) {
       Ops o[CH];
 #pragma unroll
