@@ -76,14 +76,18 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
 #else
 #define BPROF(slot)
 #endif
+  // tile slots and what is left for the panels depend on the variant (threads x slots)
+  constexpr int NTILES = (THREADS * SLOTS > BD_TILES) ? THREADS * SLOTS : BD_TILES;
+  constexpr int NINTS = BD_INTS - BD_TILES + NTILES;
+  constexpr int CAP = (SOLVE_MAX_LDS_BYTES - NINTS * 4 - BD_PINV * 8) / 8;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int *first = (int *)smem;   // [T]    first non-zero column tile of a row tile (0 for the last, dense one)
   int *pre = first + 100;     // [T+1]  tiles before row tile I in the allocation order
   int *hiK = pre + 100;       // [KT]   last banded row tile below column tile K
   int *poff = hiK + 100;      // [npairs+1] doubles before the panel of a column pair
   int *tinfo = poff + 196;    // [1536] I | K << 8 | half << 16 | valid << 24
-  int *flags = tinfo + BD_TILES;  // 0: fail, 1: tile width, 2: unsupported, 3: doubles of the largest panel
-  double *pinv = smem + BD_INTS / 2;
+  int *flags = tinfo + NTILES;  // 0: fail, 1: tile width, 2: unsupported, 3: doubles of the largest panel
+  double *pinv = smem + NINTS / 2;
   double *C = pinv + BD_PINV;
 
   const int T = (n + 1 + 3) >> 2, KT = (n + 3) >> 2, npairs = n >> 1, Tl = T - 1;
@@ -182,10 +186,10 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     if (lane == 0) {
       poff[npairs] = total;
       flags[3] = big;
-      if (GP ? (total > gcap || 2 * big > BD_CAP) : (total > BD_CAP)) flags[2] = 1;
+      if (GP ? (total > gcap || 2 * big > CAP) : (total > CAP)) flags[2] = 1;
     }
   }
-  for (int e = tid; e < BD_TILES; e += nt) tinfo[e] = 0;
+  for (int e = tid; e < NTILES; e += nt) tinfo[e] = 0;
   __syncthreads();
   if (flags[2]) {  // skyline too large for one workgroup: the general kernel takes the system
     if (tid == 0) meta[3] = 0;
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     // several steps per LDS round trip (four while the register budget allows it)
     // (panels in global memory: one round trip per chunk, so the chunk is as long as the registers allow - each
     // step in flight holds 2 (r0 + 1) + 3 doubles)
-    constexpr int CH = GP ? (r0 == 0 ? 16 : r0 == 1 ? 12 : r0 == 2 ? 10 : r0 == 3 ? 8 : r0 == 4 ? 7 : 6) : ((r0 <= 2) ? 4 : 2);
+    constexpr int CH = (GP && THREADS <= 512) ? (r0 == 0 ? 16 : r0 == 1 ? 12 : r0 == 2 ? 10 : r0 == 3 ? 8 : r0 == 4 ? 7 : 6)
+                                             : (GP ? (r0 <= 3 ? 4 : 2) : ((r0 <= 2) ? 4 : 2));
     for (int s = shi; s >= slo; s -= CH) {
       Ops o[CH];
 #pragma unroll
@@ -459,6 +464,8 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_THREADS, 2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_set = true;
   }
   if (!big) {
@@ -467,6 +474,9 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
   } else {
     if (!scratch) return DBA_ERR_WORKSPACE;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
+    // two tiles per thread on 1024 threads first (a step costs what one wave's tiles cost), three on 512 for what is left
+    hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 2, true>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
+                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap BD_PROF_ARG);
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
                        SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap BD_PROF_ARG);
   }
