@@ -135,10 +135,24 @@ __global__ __launch_bounds__(MAXT) void ba_solve_tile_kernel(const double *__res
       src[r][c] = okm[r][c] ? q : H;
     }
   }
+  // Off-diagonal tiles whose four columns exist read each row as two 16-byte loads (the tile order puts the lanes of
+  // a wave in different cache lines, so the load phase is bound by the number of requests: 8 instead of 16 per
+  // tile); diagonal tiles (mirrored upper half: a gather) and ragged ones keep the scalar loads.
+  const bool vec = valid && I != K && 4 * K + 3 < n_in && ((((size_t)H | (size_t)bvec) & 15) == 0);
+  if (vec) {
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+    for (int r = 0; r < 4; r++) {
+      const int i = 4 * I + r;
+      const double *rowp = (i == n) ? bvec + 4 * K : H + (size_t)min(i, n_in - 1) * n_in + 4 * K;
+      const dbl2 v0 = *(const dbl2 *)rowp, v1 = *(const dbl2 *)(rowp + 2);
+      a[r][0] = v0.x, a[r][1] = v0.y, a[r][2] = v1.x, a[r][3] = v1.y;  // (rows past the system are masked by okm below)
+    }
+  } else {
 #pragma unroll
-    for (int c = 0; c < 4; c++) a[r][c] = *src[r][c];
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) a[r][c] = *src[r][c];
+  }
   // two fronts need n % 4 == 0 (the right-hand side alone in its tile row) and room for the row panels
   const int c1cap = ((n & 3) == 0) ? min((KT - 1) >> 1, cb_doubles / (2 * PBS)) : 0;
   {
