@@ -339,3 +339,43 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
                                       ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(H1), ctypes.c_int(W1),
                                       ctypes.c_int(H2), ctypes.c_int(W2), ctypes.c_int(C), ctypes.c_int(radius))
     return g1, g2
+
+
+# ---- pinning hooks (used only by tests/test_oracle_golden.py) -------------------------------------------
+
+def schur_rows(E, C, w, ii, jj, B, ht, wd, t0, t1, A, b, dx=None, dtype=np.float64):
+    """step_schur (+ step_backsub) of the restatement on caller-supplied blocks; returns (A - EQE^T, b - EQw, dz)."""
+    E, C, w = _c(E, dtype), _c(C, dtype), _c(w, dtype)
+    ii, jj = _c(ii, np.int64), _c(jj, np.int64)
+    A = _c(A, np.float64).copy()
+    b = _c(b, np.float64).copy()
+    M, HW = C.shape[0], ht * wd
+    dz = np.zeros((M, HW), dtype)
+    dxa = _c(dx, dtype) if dx is not None else None
+    fn = getattr(lib(), "oracle_schur_rows" + _sfx(dtype))
+    fn.restype = ctypes.c_int
+    m = fn(_p(E), _p(C), _p(w), _p(ii), _p(jj), ctypes.c_int(len(ii)), ctypes.c_int(B), ctypes.c_int(ht),
+           ctypes.c_int(wd), ctypes.c_int(t0), ctypes.c_int(t1), _p(A), _p(b), _p(dxa), _p(dz))
+    assert m == M, "depth-block row count mismatch: oracle %d, caller %d" % (m, M)
+    return A, b, dz
+
+
+def sys_solve(A, b, lm, ep, dtype=np.float64):
+    A, b = _c(A, np.float64), _c(b, np.float64)
+    x = np.zeros_like(b)
+    fn = getattr(lib(), "oracle_sys_solve" + _sfx(dtype))
+    fn.restype = ctypes.c_int
+    ok = fn(_p(A), _p(b), ctypes.c_int(b.shape[0]), ctypes.c_double(lm), ctypes.c_double(ep), _p(x))
+    return x, bool(ok)
+
+
+def _presystem(self, alpha):
+    n = 6 * self.P
+    A = np.zeros((n, n), np.float64)
+    v = np.zeros((n,), np.float64)
+    C = np.zeros((self.M, self.ht * self.wd), self.dtype)
+    getattr(self.L, "oracle_bacore_presystem" + _sfx(self.dtype))(self.h, _real(self.dtype)(alpha), _p(A), _p(v), _p(C))
+    return A, v, C
+
+
+BACore.presystem = _presystem

@@ -8,6 +8,9 @@ What is captured (SURVEY.md section 8(c) "oracle plan" items 2-3) -- data only, 
   schur_solve.npz    geom.chol.schur_solve / block_solve           dbaf/geom/chol.py:32-73
   pinhole.npz        pops.coords_grid / iproj / proj               dbaf/geom/projective_ops.py:11-65
   projective.npz     pops.projective_transform(jacobian=True)      dbaf/geom/projective_ops.py:96-125
+  ba_step.npz        geom.ba.BA (one full Gauss-Newton step)       dbaf/geom/ba.py:29-104
+schur_solve.npz and ba_step.npz also hold the reduced system (S, v) that reaches the reference's Cholesky
+(captured by wrapping geom.chol.CholeskySolver.apply -- the values are the reference's own).
 The native CUDA path (src/*.cu) cannot be built or run here (no nvcc / Eigen / NVIDIA device), and
 lietorch / torch_scatter / droid_backends are absent: `lietorch` resolves to this repo's SE3 shim,
 the other two to empty stubs (none of the captured functions call into them).
@@ -28,7 +31,16 @@ sys.path.insert(0, os.path.join(ROOT, "dba-fusion_amd"))  # lietorch shim
 sys.path.insert(0, REF)
 for name in ("droid_backends", "torch_scatter"):
     sys.modules[name] = types.ModuleType(name)
-sys.modules["torch_scatter"].scatter_sum = None
+
+
+def _scatter_sum(src, index, dim=-1, dim_size=None):
+    """stand-in for the absent third-party torch_scatter.scatter_sum (rusty1s/pytorch_scatter): out[index[i]] += src[i]"""
+    shape = list(src.shape)
+    shape[dim] = int(dim_size)
+    return torch.zeros(shape, dtype=src.dtype).index_add_(dim, index, src)
+
+
+sys.modules["torch_scatter"].scatter_sum = _scatter_sum
 sys.modules["torch_scatter"].scatter_mean = None
 
 _as_tensor = torch.as_tensor
@@ -42,6 +54,8 @@ def _as_tensor_cpu(*a, **k):
 torch.as_tensor = _as_tensor_cpu
 
 import geom.projective_ops as pops  # noqa: E402
+import geom.chol as chol  # noqa: E402
+import geom.ba as rba  # noqa: E402
 from geom.chol import schur_solve, block_solve  # noqa: E402
 from modules.corr import CorrBlock  # noqa: E402
 from lietorch import SE3  # noqa: E402
@@ -64,20 +78,82 @@ def gen_corr():
     np.savez_compressed(os.path.join(HERE, "corr_pyramid.npz"), **out)
 
 
+class _CaptureCholesky:
+    """records the (S, v) the reference hands to its Cholesky (chol.py:66-68) and forwards the call"""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = chol.CholeskySolver.apply
+
+    def __enter__(self):
+        def apply(H, b):
+            self.calls.append((H.detach().clone(), b.detach().clone()))
+            return self._orig(H, b)
+        chol.CholeskySolver.apply = staticmethod(apply)
+        return self
+
+    def __exit__(self, *a):
+        chol.CholeskySolver.apply = self._orig
+
+
 def gen_schur():
     g = torch.Generator().manual_seed(1)
     B, P, M, D, HW = 1, 3, 4, 6, 20
-    J = torch.randn(B, P * D, 64, generator=g, dtype=torch.float64)
-    H = (J @ J.transpose(1, 2)).view(B, P, D, P, D).permute(0, 1, 3, 2, 4).contiguous()
-    E = 0.1 * torch.randn(B, P, M, D, HW, generator=g, dtype=torch.float64)
-    C = 1.0 + torch.rand(B, M, HW, generator=g, dtype=torch.float64)
-    v = torch.randn(B, P, D, generator=g, dtype=torch.float64)
-    w = torch.randn(B, M, HW, generator=g, dtype=torch.float64)
-    dx, dz = schur_solve(H, E, C, v, w, ep=0.1, lm=1e-4)
-    dxb = block_solve(H, v, ep=0.1, lm=1e-4)
-    np.savez_compressed(os.path.join(HERE, "schur_solve.npz"), H=H.numpy(), E=E.numpy(), C=C.numpy(),
-                        v=v.numpy(), w=w.numpy(), dx=dx.numpy(), dz=dz.numpy(), dx_block=dxb.numpy(),
-                        ep=0.1, lm=1e-4)
+    out = {}
+    for tag in ("", "z_"):  # "z_": the first pose has no depth coupling (E[0] = 0), see test_oracle_golden.py
+        J = torch.randn(B, P * D, 64, generator=g, dtype=torch.float64)
+        H = (J @ J.transpose(1, 2)).view(B, P, D, P, D).permute(0, 1, 3, 2, 4).contiguous()
+        E = 0.1 * torch.randn(B, P, M, D, HW, generator=g, dtype=torch.float64)
+        if tag:
+            E[:, 0] = 0
+        C = 1.0 + torch.rand(B, M, HW, generator=g, dtype=torch.float64)
+        v = torch.randn(B, P, D, generator=g, dtype=torch.float64)
+        w = torch.randn(B, M, HW, generator=g, dtype=torch.float64)
+        with _CaptureCholesky() as cap:
+            dx, dz = schur_solve(H, E, C, v, w, ep=0.1, lm=1e-4)
+        S, vred = cap.calls[0]
+        dxb = block_solve(H, v, ep=0.1, lm=1e-4)
+        out.update({tag + "H": H.numpy(), tag + "E": E.numpy(), tag + "C": C.numpy(), tag + "v": v.numpy(),
+                    tag + "w": w.numpy(), tag + "dx": dx.numpy(), tag + "dz": dz.numpy(),
+                    tag + "dx_block": dxb.numpy(), tag + "S": S.numpy(), tag + "vred": vred.numpy()})
+    np.savez_compressed(os.path.join(HERE, "schur_solve.npz"), ep=0.1, lm=1e-4, **out)
+
+
+def gen_ba_step():
+    """One full Gauss-Newton step of the reference's torch BA (geom/ba.py:29-104) on the 4-KF fixture window
+    (every transformed depth > 0.25, no depth measurements: the conditions under which it and the CUDA path
+    assemble the same system).  Captured: the arguments of schur_solve (= the assembled
+    H, E, C, v, w), the reduced system that reaches the Cholesky, dx, dz and the retracted state."""
+    W = syn.window_tiny_a(3)
+    K = W.num_kf  # the torch BA optimises every row of `poses` from fixedp on: hand it the window only
+    poses = SE3(torch.from_numpy(W.poses[:K])[None])
+    disps = torch.from_numpy(W.disps[:K])[None]
+    intr = torch.from_numpy(np.tile(W.intrinsics, (K, 1)))[None]
+    ii, jj = torch.from_numpy(W.ii), torch.from_numpy(W.jj)
+    target = torch.from_numpy(W.target).permute(0, 2, 3, 1)[None].contiguous()
+    weight = torch.from_numpy(W.weight).permute(0, 2, 3, 1)[None].contiguous()
+    kx = torch.unique(ii)
+    eta = torch.from_numpy(W.eta)[None][:, :len(kx)]
+    rec = {}
+    orig = rba.schur_solve
+
+    def spy(H, E, C, v, w, **k):
+        rec.update(H=H.clone(), E=E.clone(), C=C.clone(), v=v.clone(), w=w.clone())
+        dx, dz = orig(H, E, C, v, w, **k)
+        rec.update(dx=dx.clone(), dz=dz.clone())
+        return dx, dz
+
+    rba.schur_solve = spy
+    try:
+        with _CaptureCholesky() as cap:
+            poses1, disps1 = rba.BA(target, weight, eta, poses, disps, intr, ii, jj, fixedp=W.t0)
+    finally:
+        rba.schur_solve = orig
+    S, vred = cap.calls[0]
+    np.savez_compressed(os.path.join(HERE, "ba_step.npz"), seed=3, t0=W.t0, kx=kx.numpy(),
+                        H=rec["H"][0].numpy(), E=rec["E"][0].numpy(), C=rec["C"][0].numpy(), v=rec["v"][0].numpy(),
+                        w=rec["w"][0].numpy(), S=S[0].numpy(), vred=vred[0].numpy(), dx=rec["dx"][0].numpy(),
+                        dz=rec["dz"][0].numpy(), poses1=poses1.data[0].numpy(), disps1=disps1[0].numpy())
 
 
 def gen_pinhole():
@@ -118,6 +194,7 @@ if __name__ == "__main__":
     gen_schur()
     gen_pinhole()
     gen_projective()
+    gen_ba_step()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

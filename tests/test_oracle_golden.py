@@ -23,25 +23,107 @@ def test_corr_pyramid_matches_reference_corrblock(golden_dir):
             np.testing.assert_allclose(pyr[lvl], ref, rtol=2e-5, atol=2e-5)
 
 
-def _dense_schur(H, E, C, v, w, ep, lm):
-    """numpy restatement of the algebra the goldens pin: S = H + damping - E Q E^T (chol.py:46-73)."""
-    B, P, M, D, HW = E.shape
-    Hd = H.transpose(0, 1, 3, 2, 4).reshape(P * D, P * D)
-    Ed = E.transpose(0, 1, 3, 2, 4).reshape(P * D, M * HW)
-    Q = (1.0 / C).reshape(M * HW)
-    Hd = Hd + (ep + lm * Hd) * np.eye(P * D)
-    S = Hd - (Ed * Q) @ Ed.T
-    b = v.reshape(-1) - Ed @ (Q * w.reshape(-1))
-    dx = np.linalg.solve(S, b)
-    dz = Q * (w.reshape(-1) - Ed.T @ dx)
-    return dx.reshape(P, D), dz.reshape(M, HW)
+def _schur_case_to_rows(E, t0):
+    """dense coupling blocks E [P, M, 6, HW] (chol.py:49-50) -> the CUDA path's row form (droid_kernels.cu:1480-1481):
+    rows 0..P-1 belong to the poses themselves (source frame == pose frame), one further row per (source frame m ->
+    pose p) pair."""
+    P, M, D, HW = E.shape
+    rows = [E[p, t0 + p] for p in range(P)]
+    ii, jj = [], []
+    for p in range(P):
+        for m in range(M):
+            if m != t0 + p:
+                rows.append(E[p, m])
+                ii.append(m)
+                jj.append(t0 + p)
+    return np.stack(rows), np.asarray(ii, np.int64), np.asarray(jj, np.int64)
 
 
-def test_schur_algebra_matches_reference_schur_solve(golden_dir):
+@pytest.mark.parametrize("tag", ["", "z_"])
+def test_oracle_schur_and_backsub_match_reference_schur_solve(golden_dir, tag):
+    """The C oracle's OWN step_schur / sys_solve / step_backsub (not a formula written here) against what the
+    reference's schur_solve computed (chol.py:46-73): the reduced system S, v that reached its Cholesky, dx and dz.
+    The torch path damps before the Schur complement, so the damped pose block goes in and the solve runs undamped."""
     g = _load(golden_dir, "schur_solve.npz")
-    dx, dz = _dense_schur(g["H"], g["E"], g["C"], g["v"], g["w"], float(g["ep"]), float(g["lm"]))
-    np.testing.assert_allclose(dx, g["dx"][0], rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(dz, g["dz"][0], rtol=1e-9, atol=1e-12)
+    H, E, C, v, w = (g[tag + k][0] for k in ("H", "E", "C", "v", "w"))
+    ep, lm = float(g["ep"]), float(g["lm"])
+    P, M, D, HW = E.shape
+    t0 = 1
+    A = H.transpose(0, 2, 1, 3).reshape(P * D, P * D).copy()
+    A[np.diag_indices(P * D)] += ep + lm * np.diag(A)  # chol.py:55-56
+    rows, ii, jj = _schur_case_to_rows(E, t0)
+    S, b, _ = orc.schur_rows(rows, C, w, ii, jj, M, 1, HW, t0, t0 + P, A, v.reshape(-1))
+    np.testing.assert_allclose(S, g[tag + "S"][0], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(b, g[tag + "vred"][0, :, 0], rtol=1e-11, atol=1e-12)
+    x, ok = orc.sys_solve(S, b, 0.0, 0.0)
+    assert ok
+    np.testing.assert_allclose(x.reshape(P, D), g[tag + "dx"][0], rtol=1e-9, atol=1e-12)
+    _, _, dz = orc.schur_rows(rows, C, w, ii, jj, M, 1, HW, t0, t0 + P, A, v.reshape(-1), dx=g[tag + "dx"][0])
+    if tag == "z_":  # first pose has no depth coupling: the two back-substitutions are the same function
+        np.testing.assert_allclose(dz, g[tag + "dz"][0], rtol=1e-9, atol=1e-12)
+    else:
+        # EvT6x1_kernel skips rows whose pose index is <= 0 (droid_kernels.cu:1150): the CUDA path's dz lacks the
+        # first optimised pose's term, Q * E[0]^T dx[0], and nothing else
+        missing = np.einsum("mdk,d->mk", E[0], g["dx"][0, 0]) / C
+        assert np.abs(missing).max() > 1e-3
+        np.testing.assert_allclose(dz - missing, g["dz"][0], rtol=1e-9, atol=1e-12)
+
+
+def _dense_from_rows(Erows, ii_exp, jj_exp, kx, t0, P):
+    M = len(kx)
+    dense = np.zeros((P, M) + Erows.shape[1:], Erows.dtype)
+    for r in range(len(ii_exp)):
+        p = int(jj_exp[r]) - t0
+        if 0 <= p < P:
+            dense[p, int(np.searchsorted(kx, ii_exp[r]))] += Erows[r]
+    return dense
+
+
+def test_oracle_gauss_newton_step_matches_reference_torch_BA(golden_dir):
+    """One Gauss-Newton step of the reference's torch BA (geom/ba.py:29-104, captured by make_golden.gen_ba_step):
+    the oracle's assembled system (pose block, coupling rows, depth block), its Schur complement, solve,
+    back-substitution and retraction reproduce it where the two variants coincide (every
+    Z > 0.25, no depth measurements; eta shifted by the torch path's +1e-7, damping moved before the Schur
+    complement, first-pose skip added back)."""
+    g = _load(golden_dir, "ba_step.npz")
+    W = syn.window_tiny_a(int(g["seed"]))
+    K, t0 = W.num_kf, int(g["t0"])
+    P, HW = K - t0, W.h * W.w
+    kx = g["kx"]
+    eta = W.eta[:len(kx)].astype(np.float64) + 1e-7  # ba.py:89
+    core = orc.BACore(W.poses[:K], W.disps[:K], W.intrinsics, W.disps_sens[:K], W.target, W.weight, eta, W.ii, W.jj,
+                      t0, K, dtype=np.float64)
+    assert core.M == len(kx)
+    A, v, C = core.presystem(0.05)
+    Erows, Q, w = core.get_EQw()
+    f32 = dict(rtol=2e-5)  # the golden is fp32 end to end; measured agreement 1e-7 .. 9e-7 of the largest entry
+    Hg = g["H"].transpose(0, 2, 1, 3).reshape(6 * P, 6 * P).astype(np.float64)
+    np.testing.assert_allclose(A, Hg, atol=5e-6 * np.abs(Hg).max(), **f32)
+    np.testing.assert_allclose(v, g["v"].reshape(-1), atol=5e-6 * np.abs(g["v"]).max(), **f32)
+    np.testing.assert_allclose(C, g["C"], atol=1e-12, **f32)
+    np.testing.assert_allclose(w, g["w"], atol=5e-6 * np.abs(g["w"]).max(), **f32)
+    ii_exp = np.concatenate([np.arange(t0, K), W.ii])
+    jj_exp = np.concatenate([np.arange(t0, K), W.jj])
+    Ed = _dense_from_rows(Erows, ii_exp, jj_exp, kx, t0, P)
+    np.testing.assert_allclose(Ed, g["E"], atol=5e-6 * np.abs(g["E"]).max(), **f32)
+    # reduced system, with the torch path's damping order (chol.py:55-56)
+    Ad = A.copy()
+    Ad[np.diag_indices(6 * P)] += 0.1 + 1e-4 * np.diag(A)
+    S, b, _ = orc.schur_rows(Erows, C, w, W.ii, W.jj, K, W.h, W.w, t0, K, Ad, v)
+    np.testing.assert_allclose(S, g["S"], atol=5e-6 * np.abs(g["S"]).max(), **f32)
+    np.testing.assert_allclose(b, g["vred"][:, 0], atol=5e-6 * np.abs(g["vred"]).max(), **f32)
+    x, ok = orc.sys_solve(S, b, 0.0, 0.0)
+    assert ok
+    np.testing.assert_allclose(x.reshape(P, 6), g["dx"], atol=2e-4 * np.abs(g["dx"]).max(), rtol=2e-4)
+    _, _, dz = orc.schur_rows(Erows, C, w, W.ii, W.jj, K, W.h, W.w, t0, K, Ad, v, dx=g["dx"])
+    missing = np.einsum("mdk,d->mk", Ed[0], g["dx"][0].astype(np.float64)) / C   # droid_kernels.cu:1150
+    np.testing.assert_allclose(dz - missing, g["dz"], atol=2e-4 * np.abs(g["dz"]).max(), rtol=2e-4)
+    # retraction: T <- Exp(dx) T (ba.py:25-27 / droid_kernels.cu:922-976); disps + dz, > 10 -> 0, clamp at 0 (ba.py:98-102)
+    poses1 = orc.pose_retr(W.poses[:K], g["dx"], t0, K, np.float64)
+    np.testing.assert_allclose(poses1, g["poses1"], rtol=0, atol=2e-6)
+    d1 = W.disps[:K].astype(np.float64) + g["dz"].reshape(len(kx), W.h, W.w)
+    d1 = np.clip(np.where(d1 > 10, 0.0, d1), 0.0, None)
+    np.testing.assert_allclose(d1, g["disps1"], rtol=0, atol=2e-6)
 
 
 def test_pinhole_conventions(golden_dir):
