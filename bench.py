@@ -1,21 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- DBA hot-path throughput on MI355X (contract: see the task statement / DESIGN.md section 6).
+"""bench.py -- DBA hot-path throughput on MI355X (contract: see the task statement / DESIGN.md section 5).
 
 A "step" is one `dba_update` = the in-scope part of one CovisibleGraph.update()
 (/root/reference/dbaf/covisible_graph.py:214-342) on one synthetic keyframe window:
-    reproject(N edges) -> 4-level correlation lookup(N edges) -> ba(iterations=2)
+    reproject(N edges) -> 4-level correlation lookup(N edges) -> ba(iterations=2) -> clamp
 The ConvGRU between lookup and BA is out of scope.
 N=1 workload = BASELINE.json configs[1] shape: 25 KF / 96 edges / 512x512 frames (64x64 maps).
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--window 64_512]
 
-Rank 0 prints ONE JSON line.  For N > 1 the edge set is sharded by source frame over the ranks, the
-reduced camera system is all-reduced over RCCL once per Gauss-Newton iteration and updated inverse depths
-are all-gathered (strong scaling of the same window).
+Rank 0 prints ONE JSON line.  For N > 1 the edge set is sharded by source frame over the ranks, the reduced camera
+system is all-reduced over RCCL once per Gauss-Newton iteration and the updated inverse depths of the frames a rank
+owns are all-gathered once per call (strong scaling of the same window).
+
+Cache state: a real update never finds its correlation windows in the 256 MB Infinity Cache (the ConvGRU and the BA
+run in between, and the volumes of a window are gigabytes), whereas a benchmark that replays one step would.  The
+timed steps therefore rotate over `--copies` (default 3) disjoint copies of the correlation pyramid and keep the last
+outputs alive, so that every lookup reads and writes lines that were not touched for two steps ("MALL-cold");
+`--copies 1` gives the warm figure, which is also reported (extra.lookup_warm_*), measured after the timed region.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,6 +37,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join("profiles", "r02_pmc_lookup.json")
+LOOKUP_SOURCES = ("dba-fusion_amd/csrc/corr_sheared.hip",)
 
 
 def lookup_algorithmic_bytes(n_edges, hw, levels=4, radius=3, elt=2):
@@ -40,17 +49,32 @@ def lookup_algorithmic_bytes(n_edges, hw, levels=4, radius=3, elt=2):
     return n_edges * (taps + coords + out)
 
 
+def build_algorithmic_bytes(C, hw, levels=4):
+    """per edge 2*C*HW*2 (feature maps) + HW^2 * (1 + 1/4 + 1/16 + 1/64) * 2 (pyramid written once)."""
+    return 2 * C * hw * 2 + int(hw * hw * sum(0.25 ** l for l in range(levels))) * 2, 2 * hw * hw * C
+
+
+def source_hash(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(os.path.join(ROOT, p), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
+    ap.add_argument("--copies", type=int, default=3, help="disjoint copies of the pyramid the steps rotate over")
     ap.add_argument("--step-events", action="store_true",
                     help="also record one event per step (p10/p50/p90 of the step time; costs ~1 us per step)")
     ap.add_argument("--window", default="25_96", choices=["25_96", "32_122", "64_512"],
-                    help="synthetic window (default = BASELINE.json configs[1]; the others are for profiling)")
+                    help="synthetic window (default = BASELINE.json configs[1]; 64_512 = configs[3], the multi-GPU case)")
     args = ap.parse_args()
 
     from dbaf_amd import synthetic as syn
@@ -73,7 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()
 
-    # ---- workload: 25 KF / 96 edges / 64x64 (synthetic) --------------------------------
+    # ---- workload (synthetic) -----------------------------------------------------------
     W = {"25_96": syn.window_25_96, "32_122": syn.window_32_122, "64_512": syn.window_64_512}[args.window](args.seed)
     h, w, HW, N = W.h, W.w, W.h * W.w, W.N
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -92,13 +116,19 @@ def main():
     target, weight = t(W.target[sel]), t(W.weight[sel])
     n_loc = len(sel)
 
-    fmaps = t(syn.make_fmaps(W.B, 128, h, w, args.seed + 1000))
-    corr = None
-    if n_loc > 0:  # volumes of this rank's edges, built in chunks to bound the staging memory
-        for c0 in range(0, n_loc, 32):
+    C = 128
+    fmaps = t(syn.make_fmaps(W.B, C, h, w, args.seed + 1000))
+
+    def build_block(layout=None):
+        blk = None
+        for c0 in range(0, n_loc, 32):  # volumes of this rank's edges, in chunks like add_factors adds them
             s_ = slice(c0, min(c0 + 32, n_loc))
-            cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3)
-            corr = cb if corr is None else corr.cat(cb)
+            cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3, layout=layout)
+            blk = cb if blk is None else blk.cat(cb)
+        return blk
+
+    ncopies = max(1, args.copies)
+    corrs = [build_block() for _ in range(ncopies)] if n_loc > 0 else []
     # poses and disparities live in one buffer, so that the per-step state reset is a single copy
     npose = poses0.numel()
     pad = (-npose) % 64
@@ -107,22 +137,27 @@ def main():
     poses = state[:npose].view_as(poses0)
     disps = state[npose + pad:].view_as(disps0)
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
-    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup + 1)]
+    total = args.steps + args.warmup
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * total)]
+    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
+    keep = [None] * ncopies  # the last outputs stay alive: the allocator hands out other lines for the next ones
 
-    def step(i):
+    def step(i, corr_of=lambda i: corrs[i % ncopies], lookup=None):
         if args.step_events:
             ev_step[i].record()
         state.copy_(state0)
         coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
-        ev[2 * i].record()
-        c = corr(coords1) if corr is not None else None
-        ev[2 * i + 1].record()
+        ev[4 * i].record()
+        c = (lookup(coords1) if lookup is not None else corr_of(i)(coords1)) if corrs else None
+        ev[4 * i + 1].record()
+        keep[i % ncopies] = c
+        ev[4 * i + 2].record()
         if shard is None:
             droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep,
                               False)
         else:
             shard.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, dist)
+        ev[4 * i + 3].record()
         disps.clamp_(min=0.001)  # depth_video.py:560
         return c
 
@@ -132,10 +167,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(args.warmup, total):
         step(i)
     if args.step_events:
-        ev_step[args.warmup + args.steps].record()
+        ev_step[total].record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -145,8 +180,67 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    lookup_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
-    lookup_ms = float(np.mean(lookup_ms)) if (lookup_ms and corr is not None) else float("nan")
+    ks = range(args.warmup, total)
+    look_us = np.array([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in ks]) * 1e3 if corrs and args.steps else np.zeros(1)
+    ba_us = np.array([ev[4 * i + 2].elapsed_time(ev[4 * i + 3]) for i in ks]) * 1e3 if args.steps else np.zeros(1)
+    lookup_ms = float(look_us.mean()) * 1e-3 if corrs and args.steps else float("nan")
+
+    # ---- untimed extras (rank 0, one GPU): warm lookup, zero-edit route, volume build ------------------------
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and corrs:
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) * 1e3 / reps  # us
+
+        coords1, _ = pops.projective_transform(poses0[None], disps0[None], K, ii, jj)
+        warm_us = timed(lambda: corrs[0](coords1), 20)
+        extras["lookup_warm_us"] = round(warm_us, 1)
+        extras["lookup_warm_frac_of_hbm_peak"] = round(lookup_algorithmic_bytes(n_loc, HW) / (warm_us * 1e-6) / 1e9
+                                                       / HBM_PEAK_GBS, 4)
+        # volume build (per add_factors batch of 32 edges): CorrBlock(fmap1, fmap2), MFMA + pooling + flow-aligned store
+        nb = min(32, n_loc)
+        f1, f2 = fmaps[ii[:nb]][None], fmaps[jj[:nb]][None]
+        b_us = timed(lambda: CorrBlock(f1, f2, num_levels=4, radius=3), 5) / nb
+        bbytes, bflops = build_algorithmic_bytes(C, HW)
+        extras["build_us_per_edge"] = round(b_us, 2)
+        extras["build_GBps"] = round(bbytes / (b_us * 1e-6) / 1e9, 1)
+        extras["build_frac_of_hbm_peak"] = round(bbytes / (b_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        extras["build_TFLOPs"] = round(bflops / (b_us * 1e-6) / 1e12, 1)
+        del f1, f2
+        # zero-edit route: reference-layout volumes + droid_backends.corr_index_forward per level + cat, i.e. what the
+        # reference's own modules/corr.py executes against this repo's droid_backends
+        del corrs[1:]
+        keep[:] = [None] * ncopies
+        torch.cuda.empty_cache()
+        ref_blk = build_block(layout="reference")
+
+        def zero_edit_lookup(coords):
+            cp = coords[0].permute(0, 3, 1, 2).contiguous()
+            outs = []
+            for lvl in range(4):
+                o, = droid_backends.corr_index_forward(ref_blk.corr_pyramid[lvl], cp / 2 ** lvl, 3)
+                outs.append(o.view(1, n_loc, -1, h, w))
+            return torch.cat(outs, dim=2)
+
+        nz = max(5, args.steps // 4)
+        for i in range(3):
+            step(i, lookup=zero_edit_lookup)
+        torch.cuda.synchronize()
+        tz = time.perf_counter()
+        for i in range(nz):
+            step(i, lookup=zero_edit_lookup)
+        torch.cuda.synchronize()
+        tz = time.perf_counter() - tz
+        extras["zero_edit_dba_update_per_s"] = round(nz / tz, 1)
+        extras["zero_edit_lookup_us"] = round(float(np.mean([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in range(nz)]))
+                                              * 1e3, 1)
 
     if rank == 0:
         ms_per_step = 1e3 * dt / max(args.steps, 1)
@@ -155,8 +249,9 @@ def main():
         if args.window != "25_96":
             args.no_cpu_baseline = True
         achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
+        gn_bytes = N * HW * 16 + W.M * HW * 16  # SURVEY 8(d) B_gn: target, weight + disps r/w, eta, disps_sens
         out = {
-            "metric": "DBA iterations/sec (25-KF, 96-edge, 512x512) [dba_update/s]",
+            "metric": "DBA iterations/sec (%d-KF, %d-edge, 512x512) [dba_update/s]" % (W.num_kf, N),
             "value": round(value, 3),
             "unit": "dba_update/s",
             "n_gpus": world,
@@ -169,10 +264,14 @@ def main():
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
             "config": {"workload": "synthetic TUM-VI-shape 512x512 -> %dx%d maps, %d-KF window, %d edges, "
-                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step" % (h, w, W.num_kf, N),
-                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world},
+                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step; lookups rotate over %d disjoint "
+                                   "pyramid copies (MALL-cold)" % (h, w, W.num_kf, N, ncopies),
+                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
+                       "pyramid_copies": ncopies},
             "roofline": {
-                "kernel": "corr_lookup_sheared_kernel<3> (fused 4-level r=3 lookup, f16, %d edges on rank 0)" % n_loc,
+                "kernel": "corr_lookup_sheared_kernel<3> (fused 4-level r=3 lookup, f16, %d edges on rank 0, "
+                          "%s)" % (n_loc, "MALL-cold: rotating pyramid copies and output buffers" if ncopies > 1
+                                   else "MALL-warm: one pyramid copy replayed"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
                 "peak": HBM_PEAK_GBS,
@@ -183,32 +282,38 @@ def main():
                 "avg_launch_ms": round(lookup_ms, 5) if lookup_ms == lookup_ms else None,
             },
         }
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_lookup.json")
-        if os.path.exists(pmc) and world == 1 and args.window == "25_96":
-            # HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-            # (FETCH_SIZE/WRITE_SIZE with the gfx950 corrections, see profiles/README.md); not re-measured here
+        pmc = os.path.join(ROOT, PMC_FILE)
+        if os.path.exists(pmc) and world == 1:
+            # HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of THIS command
+            # (tools/profile_round.sh; FETCH_SIZE / WRITE_SIZE with the gfx950 corrections, see profiles/README.md).
+            # The file records the hash of the kernel source it was measured on: a stale file is reported as such.
             with open(pmc) as fh:
-                out["roofline"]["traffic"] = int(json.load(fh)["traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_lookup.json"
+                rec = json.load(fh)
+            cur = source_hash(LOOKUP_SOURCES)
+            if rec.get("workload") == args.window and rec.get("copies", 1) == ncopies:
+                out["roofline"]["traffic"] = int(rec["traffic_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = PMC_FILE
+                out["roofline"]["traffic_kernel_source_sha"] = rec.get("kernel_source_sha")
+                out["roofline"]["traffic_stale"] = rec.get("kernel_source_sha") != cur
         # both units of work, and the spread of the per-step device times (events on the launch stream)
-        ks = range(args.warmup, args.warmup + args.steps)
         step_us = (np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3
                    if args.steps and args.step_events else np.zeros(1))
-        look_us = (np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in ks]) * 1e3
-                   if corr is not None and args.steps else np.zeros(1))
         out["extra"] = {"gn_iter_per_s": round(2.0 * value, 3),
                         "edge_lookups_per_s": round(N * value, 1),
                         "step_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])]
                                                 if args.step_events else None),
-                        "lookup_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(look_us, [10, 50, 90])]}
+                        "lookup_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(look_us, [10, 50, 90])],
+                        "ba_itrs2_us_p50": round(float(np.percentile(ba_us, 50)), 1),
+                        "gn_iter_GBps": round(gn_bytes / (float(np.percentile(ba_us, 50)) * 0.5e-6) / 1e9, 1),
+                        **extras}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W, corr, fmaps, ii, jj)
+            out["cpu_baseline"] = cpu_baseline(W, fmaps, ii, jj)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(W, corr, fmaps, ii, jj, sample_edges=8):
+def cpu_baseline(W, fmaps, ii, jj, sample_edges=8):
     """The CPU oracle (a port: the reference has no CPU implementation of this path) timed on the host cores
     for the same dba_update, on a bounded sample: full ba(itrs=2) on the 25/96 window, reprojection of all
     edges, and the 4-level lookup on `sample_edges` edges (volumes copied from the device) scaled to 96."""

@@ -29,9 +29,10 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   // waves beyond that (each wave-level reduction of the J^T W J sums is amortised over PPL pixels)
   int ppl = 1;
   {
-    const char *env = getenv("DBA_LINEARIZE_PPL");
+    // read once per process: every stage call re-plans, and linearise / reduce must agree on nparts
+    static const int env_ppl = [] { const char *e = getenv("DBA_LINEARIZE_PPL"); return e ? atoi(e) : 0; }();
     const long waves1 = (long)Mmax * ((HW + 63) / 64);
-    if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4)) ppl = atoi(env);
+    if (env_ppl == 1 || env_ppl == 2 || env_ppl == 4) ppl = env_ppl;
     else if (waves1 >= 16 * 1024) ppl = 4;
     else if (waves1 >= 8 * 1024) ppl = 2;  // measured: 25 KF/64x64 (1664 waves) and 64 KF (4096) best at 1 (matrix-core sums)
   }
@@ -161,6 +162,9 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   if (!poses || !disps || !intrinsics || !disps_sens || !eta || eta_rows < 1) return DBA_ERR_ARG;
+  // eta has one row per entry of kx, or one row that is broadcast (eta.view(-1, HW), droid_kernels.cu:1476); more rows
+  // than kx can have entries cannot be right (the exact |kx| is only known on the device: see droid_backends._ba_args)
+  if (eta_rows > 1 && eta_rows > plan.T.Mmax) return DBA_ERR_ARG;
   if (N > 0 && (!targets || !weights || !jj)) return DBA_ERR_ARG;
   dim3 grid(plan.nchunks, plan.T.Mmax + 1);
 #define LAUNCH_LIN(PPL, MF)                                                                                   \

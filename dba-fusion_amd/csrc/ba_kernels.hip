@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const size_t fk = (size_t)frame * HW + k;
     const float ds = disps_sens[fk];
     const float mm = (ds > 0.f) ? 1.f : 0.f;
-    const float et = eta[(size_t)(eta_rows == 1 ? 0 : m) * HW + k];
+    const float et = eta[(size_t)min(m, eta_rows - 1) * HW + k];
     const float C = (Csum[q] + mm * alpha) + (1.f - mm) * et;            // droid_kernels.cu:1476
     const float w = wsum[q] - (mm * alpha) * (disp[q] - ds);             // :1477
     W.Q[(size_t)m * HW + k] = 1.f / C;                                   // :1478

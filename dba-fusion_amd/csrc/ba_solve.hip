@@ -324,11 +324,11 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
   }
   const size_t small = solve_small_bytes(n), packed = solve_packed_bytes(n);
   if (packed + small <= (size_t)SOLVE_MAX_LDS_BYTES) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
       DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
-      attr_set = true;
+      attr_once.done();
     }
     hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), packed + small, stream, H, b, n,
                        lm, ep, dx, meta, Lscratch, prof, chained);

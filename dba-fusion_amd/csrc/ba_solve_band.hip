@@ -458,15 +458,15 @@ extern long long *g_band_prof;
 // does not fit it.
 int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
                          int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_THREADS, 1, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_THREADS, 2, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
-    attr_set = true;
+    attr_once.done();
   }
   if (!big) {
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,

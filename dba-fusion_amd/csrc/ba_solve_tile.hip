@@ -560,13 +560,13 @@ bool ba_solve_tile_supported(int n) {
 
 int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                          hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_tile_kernel<768>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_tile_kernel<TILE_MAX_THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
-    attr_set = true;
+    attr_once.done();
   }
   // what is left of the LDS holds the bottom front's row panels (DBA_SOLVE_TWIST=0: one front only)
   static const bool twist = [] { const char *e = getenv("DBA_SOLVE_TWIST"); return !(e && e[0] == '0'); }();

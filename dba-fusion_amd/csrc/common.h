@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/dba_hip.h"
 
 namespace dba {
@@ -22,6 +24,21 @@ void set_last_error(const char *what, hipError_t e);
   } while (0)
 
 #define DBA_LAUNCH_CHECK() DBA_HIP_CHECK(hipGetLastError())
+
+// Per-device one-time set-up (hipFuncSetAttribute applies to the CURRENT device only, and several host threads may
+// drive different devices): `DeviceOnce once; if (once.needed()) { ...set attributes...; once.done(); }`.  The flag of
+// a device is raised only after its set-up has completed, so a concurrent caller repeats the (idempotent) set-up
+// instead of launching without it.
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long bit() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;  // unknown device: always set up
+    return 1ull << dev;
+  }
+  bool needed() const { const unsigned long long b = bit(); return b == 0 || !(mask.load(std::memory_order_acquire) & b); }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -229,11 +229,11 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
   const size_t lds = sizeof(_Float16) * ((size_t)64 * T_PITCH);  // the pooled levels live inside the dead tile
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   hipLaunchKernelGGL(corr_build_fused_kernel, dim3(h1, h2 / FT_ROWS, n), dim3(512), lds, s, A, Bm, L, C, h1);
   DBA_LAUNCH_CHECK();

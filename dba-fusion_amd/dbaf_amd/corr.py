@@ -14,6 +14,7 @@ to droid_backends.corr_index_forward.
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 
@@ -137,6 +138,11 @@ class CorrBlock:
                    "dba_corr_lookup_pyramid")
         return out
 
+    def sheared_level(self, lvl):
+        """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1] (a view without the plane padding)"""
+        assert self.layout == "sheared"
+        return self.corr_pyramid[lvl]
+
     def cat(self, other):
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
@@ -146,3 +152,87 @@ class CorrBlock:
         for i in range(self.num_levels):
             self.corr_pyramid[i] = self.corr_pyramid[i][index]
         return self
+
+
+class CorrSampler(torch.autograd.Function):
+    """dbaf/modules/corr.py:6-20: windowed lookup on a reference-layout volume level, with its adjoint."""
+
+    @staticmethod
+    def forward(ctx, volume, coords, radius):
+        import droid_backends
+        ctx.save_for_backward(volume, coords)
+        ctx.radius = radius
+        corr, = droid_backends.corr_index_forward(volume, coords, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        import droid_backends
+        volume, coords = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_volume, = droid_backends.corr_index_backward(volume, coords, grad_output, ctx.radius)
+        return grad_volume, None, None
+
+
+class CorrLayer(torch.autograd.Function):
+    """dbaf/modules/corr.py:74-88: on-the-fly windowed correlation (altcorr), with its adjoint."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, coords, r):
+        import droid_backends
+        ctx.r = r
+        ctx.save_for_backward(fmap1, fmap2, coords)
+        corr, = droid_backends.altcorr_forward(fmap1, fmap2, coords, ctx.r)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_corr):
+        import droid_backends
+        fmap1, fmap2, coords = ctx.saved_tensors
+        grad_corr = grad_corr.contiguous()
+        fmap1_grad, fmap2_grad, coords_grad = droid_backends.altcorr_backward(
+            fmap1.float(), fmap2.float(), coords, grad_corr.float(), ctx.r)
+        return fmap1_grad.to(fmap1.dtype), fmap2_grad.to(fmap2.dtype), coords_grad, None
+
+
+class AltCorrBlock:
+    """dbaf/modules/corr.py:91-139: the memory-saving variant that never materialises the volume; keeps a channels-last
+    pyramid of the (pre-scaled) feature maps and correlates on the fly per lookup.  Same constructor, corr_fn and
+    __call__ as the reference class; the per-level work is droid_backends.altcorr_forward (csrc/altcorr.hip)."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        fmaps = fmaps.view(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(self.num_levels):
+            sz = (B, N, H // 2 ** i, W // 2 ** i, C)
+            fmap_lvl = fmaps.permute(0, 2, 3, 1).contiguous()
+            self.pyramid.append(fmap_lvl.view(*sz))
+            fmaps = F.avg_pool2d(fmaps, 2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+        corr_list = []
+        for i in range(self.num_levels):
+            fmap1_i = self.pyramid[0][:, ii]
+            fmap2_i = self.pyramid[i][:, jj]
+            coords_i = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
+            fmap1_i = fmap1_i.reshape((B * N,) + fmap1_i.shape[2:])
+            fmap2_i = fmap2_i.reshape((B * N,) + fmap2_i.shape[2:])
+            corr = CorrLayer.apply(fmap1_i.float(), fmap2_i.float(), coords_i, self.radius)
+            corr = corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2)
+            corr_list.append(corr)
+        return torch.cat(corr_list, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze_output = False
+        if len(coords.shape) == 5:
+            coords = coords.unsqueeze(dim=-2)
+            squeeze_output = True
+        corr = self.corr_fn(coords, ii, jj)
+        if squeeze_output:
+            corr = corr.squeeze(dim=-1)
+        return corr.contiguous()

@@ -7,8 +7,11 @@ The reference is single-GPU (no NCCL anywhere); this is new design for the MI355
     Gauss-Newton iteration (83 KB at P = 24) over RCCL/xGMI -- latency-bound, not bandwidth-bound;
   * every rank then solves the identical system redundantly (identical bits in -> identical dx out; RCCL
     delivers the same reduced buffer to all ranks), retracts all poses, back-substitutes the depths of the
-    frames it owns; the per-frame depth updates are exchanged once per call with one more small all-reduce
-    (a sum in which exactly one rank contributes a non-zero per element, hence exact).
+    frames it owns; the updated depth maps are exchanged once per call with ONE all-gather of the rows each rank
+    owns (64 KF / 8 ranks: 8 rows x 16 KB per rank), after which the replicas are bit-identical;
+  * the IMU / GNSS fusion path (`ShardedBACore`, mirroring droid_backends.BACore as DepthVideo.ba drives it,
+    dbaf/depth_video.py:469-559): the reduced system is summed onto rank 0 (one RCCL reduce), handed to the host
+    there (GTSAM runs on rank 0 only), the externally solved dx is broadcast, every rank retracts.
 The stage executor is pluggable so the partition / exchange logic is testable on CPU with the gloo backend
 (tests/test_sharded_cpu.py drives it with a CPU stand-in); the product executor is `HipStages` (C ABI).
 """
@@ -56,15 +59,36 @@ class ShardedWindow:
         kx_local = np.unique(np.concatenate([np.arange(t0, t1, dtype=np.int64), self.ii_all[self.local_edges]]))
         self.kx_local = kx_local
         self.eta_rows = np.searchsorted(self.kx_global, kx_local)
+        # depth exchange: rank r contributes the rows (frames) it owns, padded to the largest share
+        self.rows_of = [np.array(sorted(k for k, r in self.owner.items() if r == q), np.int64) for q in range(world)]
+        self.kmax = max(1, max(len(r) for r in self.rows_of))
         self._dev = {}
 
     def _on(self, device):
         key = str(device)
         if key not in self._dev:
+            flat = np.concatenate([np.pad(r, (0, self.kmax - len(r)), constant_values=-1) for r in self.rows_of])
             self._dev[key] = dict(owned=torch.from_numpy(self.owned).to(device),
                                   eta_rows=torch.from_numpy(self.eta_rows).to(device),
-                                  kx=torch.from_numpy(self.kx_global).to(device))
+                                  kx=torch.from_numpy(self.kx_global).to(device),
+                                  my_rows=torch.from_numpy(self.rows_of[self.rank]).to(device),
+                                  all_rows=torch.from_numpy(flat[flat >= 0]).to(device),        # frames, rank-major
+                                  all_slots=torch.from_numpy(np.nonzero(flat >= 0)[0]).to(device))  # their gather slots
         return self._dev[key]
+
+    def merge_disps(self, disps, dist):
+        """all-gather of the depth maps each rank owns (and has just updated) -> coherent replicas.
+        [kmax, h, w] per rank; slots beyond a rank's share are padding."""
+        if dist is None:
+            return
+        d = self._on(disps.device)
+        send = disps.new_zeros((self.kmax,) + tuple(disps.shape[1:]))
+        n_mine = int(d["my_rows"].numel())
+        if n_mine:
+            send[:n_mine] = disps.index_select(0, d["my_rows"])
+        recv = disps.new_empty((self.world * self.kmax,) + tuple(disps.shape[1:]))
+        dist.all_gather_into_tensor(recv, send)
+        disps.index_copy_(0, d["all_rows"], recv.index_select(0, d["all_slots"]))
 
     def ba(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, iterations, lm, ep, dist,
            stages=None, alpha=0.05, motion_only=False):
@@ -78,34 +102,95 @@ class ShardedWindow:
         n6 = 6 * (self.t1 - self.t0)
         ctx = stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
                            self.t0, self.t1, alpha)
-        kmin, kmax = int(self.kx_global[0]), int(self.kx_global[-1]) + 1
-        own_rows = d["owned"][kmin:kmax].to(torch.bool)
-        before = disps[kmin:kmax].clone()
         inplace = getattr(stages, "system_view", None)
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
             hb = inplace(ctx) if inplace is not None else None
             if hb is not None:                              # float64 view of [H | pad | b] inside the workspace
-                if dist is not None and self.world > 1:
+                if dist is not None:
                     dist.all_reduce(hb)                     # RCCL sum over xGMI, in place: no staging copies
             else:
                 hb = stages.get_system(ctx)                 # float64 [n6*n6 + n6], this rank's partial sums
-                if dist is not None and self.world > 1:
+                if dist is not None:
                     dist.all_reduce(hb)                     # (gloo in the CPU tests)
                 stages.set_system(ctx, hb)
             stages.solve(ctx, lm, ep)
             stages.update(ctx, update_disps=not motion_only)
         # Between iterations a rank only reads the depths of the frames it owns (the source frames of its own
-        # edges), so the replicas are made coherent ONCE per call: owner-masked deltas, summed over ranks
-        # (exactly one non-zero contributor per element, hence exact).
+        # edges), so the replicas are made coherent ONCE per call: every rank sends the rows it owns.
         if not motion_only:
-            delta = disps[kmin:kmax] - before
-            delta[~own_rows] = 0
-            if dist is not None and self.world > 1:
-                dist.all_reduce(delta)
-            disps[kmin:kmax] = before + delta
+            self.merge_disps(disps, dist)
         assert hb.numel() >= n6 * n6 + n6
         return stages.finish(ctx)
+
+    def bacore(self, dist, stages=None):
+        return ShardedBACore(self, dist, stages)
+
+
+class ShardedBACore:
+    """droid_backends.BACore over the ranks of a node, for the IMU / GNSS fusion path
+    (/root/reference/dbaf/depth_video.py:469-559; src/bacore.h:4-70):
+
+        init(...)        this rank's edges (targets / weights / ii / jj), replicated poses / disps, GLOBAL eta
+        hessian(H, v)    every rank linearises and Schur-reduces its share (alpha = 0.001, droid_kernels.cu:1872); the
+                         partial systems are summed onto rank 0 with one RCCL reduce; rank 0 copies the sum into the
+                         caller's CPU float64 H [6P,6P], v [6P] (through pinned staging) -- other ranks' H, v stay as
+                         they are (GTSAM runs on rank 0 only)
+        retract(dx)      rank 0 passes the externally solved CPU float64 dx [6P]; it is broadcast, every rank retracts
+                         all poses and back-substitutes the depths of the frames it owns with the E, Q, w its last
+                         hessian() cached; owned depth rows are all-gathered.  Returns [dx, None].
+    """
+
+    def __init__(self, window, dist, stages=None):
+        self.win, self.dist = window, dist
+        self.stages = stages if stages is not None else HipStages()
+        self.ctx = None
+
+    def init(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+             motion_only):
+        win = self.win
+        assert (int(t0), int(t1)) == (win.t0, win.t1), "ShardedBACore.init: window differs from the partition's"
+        d = win._on(poses.device)
+        eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
+        eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
+        self.poses, self.disps = poses, disps
+        self.ctx = self.stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
+                                     win.t0, win.t1, 0.001)
+        n = 6 * (win.t1 - win.t0)
+        self.n = n
+        pin = poses.is_cuda
+        self._Hpin = torch.zeros(n * n + n, dtype=torch.float64, pin_memory=pin)
+        self._dxdev = torch.zeros(n, dtype=torch.float64, device=poses.device)
+
+    def hessian(self, H, v):
+        st, c, n = self.stages, self.ctx, self.n
+        st.linearize_reduce(c, False)
+        hb = st.system_view(c) if hasattr(st, "system_view") else None
+        if hb is None:
+            hb = st.get_system(c)
+        if self.dist is not None:
+            self.dist.reduce(hb, dst=0)          # RCCL sum onto rank 0 (in place on the workspace view there)
+        if self.win.rank != 0:
+            return
+        flat = torch.cat([hb[:n * n], hb[-n:]]) if hb.numel() != n * n + n else hb
+        self._Hpin.copy_(flat, non_blocking=True)  # one D2H into pinned staging
+        if flat.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        H.copy_(self._Hpin[:n * n].view(n, n)[:H.shape[0], :H.shape[1]])
+        v.copy_(self._Hpin[n * n:][:v.shape[0]])
+
+    def retract(self, dx):
+        st, c, n = self.stages, self.ctx, self.n
+        if self.win.rank == 0:
+            if dx is None:
+                raise RuntimeError("ShardedBACore.retract: rank 0 must pass the solved dx")
+            self._dxdev.copy_(dx.detach().reshape(-1)[:n].to(torch.float64), non_blocking=False)
+        if self.dist is not None:
+            self.dist.broadcast(self._dxdev, src=0)
+        st.set_dx(c, self._dxdev)
+        st.update(c, update_disps=True)
+        self.win.merge_disps(self.disps, self.dist)
+        return [st.finish(c), None]
 
 
 class HipStages:
@@ -173,6 +258,12 @@ class HipStages:
         _lib.check(c["lib"].dba_ba_update(p(c["poses"]), p(c["disps"]), p(c["ii"]), p(c["jj"]), p(c["owned"]),
                                           *c["dims"], 1, int(bool(update_disps)), None, p(c["ws"]), c["nbytes"],
                                           self._s()), "dba_ba_update")
+
+    def set_dx(self, c, dx64):
+        """externally solved update (float64, device) -> the workspace's dx slot (float32, droid_kernels.cu:1929-1930)"""
+        n = 6 * (c["dims"][5] - c["dims"][4])
+        lay = c["lay"]
+        c["ws"][lay.dx:lay.dx + 4 * n].view(torch.float32).copy_(dx64.reshape(-1)[:n].to(torch.float32))
 
     def finish(self, c):
         n = 6 * (c["dims"][5] - c["dims"][4])

@@ -61,6 +61,18 @@ def _num_kx(eta, ii, t0, t1, ht, wd):
     return int(torch.unique(torch.cat([ts, ii])).numel())
 
 
+def _check_eta_rows(eta_rows, ii, t0, t1):
+    """eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): one row, or one per kx entry.
+    The reference raises a broadcast error otherwise; here the count is checked on the host when it is cheap to know
+    (t1 - t0 >= all source frames is the common case: kx = arange(min(ii, t0), t1)) and bounded otherwise."""
+    if eta_rows == 1:
+        return
+    P, N = max(t1 - t0, 0), int(ii.shape[0])
+    if eta_rows > P + N or eta_rows < min(P, 1):
+        raise RuntimeError("eta has %d rows; it must have 1 or |unique(arange(t0,t1) U ii)| rows (at most %d here)"
+                           % (eta_rows, P + N))
+
+
 def _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj):
     _check(targets, "targets", torch.float32)
     _check(weights, "weights", torch.float32)
@@ -74,6 +86,8 @@ def _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj
         eta = eta.contiguous()  # the reference takes eta.view(-1, ht*wd) of whatever it is given
     eta = _check(eta, "eta", torch.float32)
     B, ht, wd = disps.shape
+    if eta.numel() % (ht * wd) != 0:
+        raise RuntimeError("eta must view as [-1, ht*wd] (droid_kernels.cu:1476), got %s" % (tuple(eta.shape),))
     return eta, int(ii.shape[0]), int(B), int(ht), int(wd), int(eta.numel() // (ht * wd))
 
 
@@ -83,8 +97,11 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
     t0, t1 = int(t0), int(t1)
     P = t1 - t0
+    _check_eta_rows(eta_rows, ii, t0, t1)
+    if int(iterations) <= 0:   # the reference returns two undefined tensors and touches nothing (:1437, :1511)
+        return [None, None]
     ws, nbytes = _ws(N, B, ht, wd, t0, t1, poses.device)
-    dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by dba_ba
+    dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
     Mmax = min(B, P + N)
     dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
     rc = _lib.load().dba_ba(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
@@ -168,6 +185,11 @@ class BACore:
         self.P = self.t1 - self.t0
         self.ws, self.nbytes = _ws(N, B, ht, wd, self.t0, self.t1, poses.device)
         self.dx = None
+        # pinned host staging for the hand-off to the factor-graph side: the reduced system leaves
+        # the device with ONE DMA per hessian() call and is only then copied into the caller's pageable H, v
+        # (torch's caching host allocator recycles the block across the BACore objects DepthVideo.ba creates per call)
+        n = 6 * self.P
+        self._stage = torch.empty(n * n + n, dtype=torch.float64, pin_memory=True)
         self._ready = True
 
     def _dims(self):
@@ -178,17 +200,23 @@ class BACore:
         if H.is_cuda or v.is_cuda or H.dtype != torch.float64 or v.dtype != torch.float64:
             raise RuntimeError("BACore.hessian: H, v must be CPU float64 tensors (droid_kernels.cu:1889-1890)")
         n = 6 * self.P
-        Hh = H if (H.is_contiguous() and tuple(H.shape) == (n, n)) else torch.zeros(n, n, dtype=torch.float64)
-        vh = v if (v.is_contiguous() and tuple(v.shape) == (n,)) else torch.zeros(n, dtype=torch.float64)
+        direct = (H.is_pinned() and v.is_pinned() and H.is_contiguous() and v.is_contiguous()
+                  and tuple(H.shape) == (n, n) and tuple(v.shape) == (n,))
+        Hh = H if direct else self._stage[:n * n].view(n, n)   # DMA target: the caller's own pinned buffers, or ours
+        vh = v if direct else self._stage[n * n:]
         rc = _lib.load().dba_bacore_hessian(
             _ptr(self.poses), _ptr(self.disps), _ptr(self.intrinsics), _ptr(self.disps_sens), _ptr(self.targets),
             _ptr(self.weights), _ptr(self.eta), self.eta_rows, _ptr(self.ii), _ptr(self.jj), *self._dims(),
             ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream())
         _lib.check(rc, "dba_bacore_hessian")
-        if Hh is not H:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
+        if not direct:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
             H.copy_(Hh[:H.shape[0], :H.shape[1]])
-        if vh is not v:
             v.copy_(vh[:v.shape[0]])
+
+    def hessian_staging(self):
+        """zero-copy access to the pinned staging buffers the last hessian() filled: (H [6P,6P], v [6P]) float64"""
+        n = 6 * self.P
+        return self._stage[:n * n].view(n, n), self._stage[n * n:]
 
     def optimize(self, H, v):
         assert self._ready, "BACore.init must be called first"

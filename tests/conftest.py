@@ -19,3 +19,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """the parity report (tests/util.py::check_state) starts empty in the outermost pytest session; sessions spawned by
+    tests (other solver kernels) append to it"""
+    if not os.environ.get("DBA_PARITY_SESSION"):
+        os.environ["DBA_PARITY_SESSION"] = "1"
+        rep = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+        if os.path.exists(rep):
+            os.remove(rep)

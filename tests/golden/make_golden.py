@@ -9,6 +9,7 @@ What is captured (SURVEY.md section 8(c) "oracle plan" items 2-3) -- data only, 
   pinhole.npz        pops.coords_grid / iproj / proj               dbaf/geom/projective_ops.py:11-65
   projective.npz     pops.projective_transform(jacobian=True)      dbaf/geom/projective_ops.py:96-125
   ba_step.npz        geom.ba.BA (one full Gauss-Newton step)       dbaf/geom/ba.py:29-104
+  ba2gtsam.npz       BA2GTSAM (numpy twin of the GTSAM fork's op)  dbaf/depth_video.py:20-29
 schur_solve.npz and ba_step.npz also hold the reduced system (S, v) that reaches the reference's Cholesky
 (captured by wrapping geom.chol.CholeskySolver.apply -- the values are the reference's own).
 The native CUDA path (src/*.cu) cannot be built or run here (no nvcc / Eigen / NVIDIA device), and
@@ -189,12 +190,55 @@ def gen_projective():
     np.savez_compressed(os.path.join(HERE, "projective.npz"), **out)
 
 
+def gen_ba2gtsam():
+    """depth_video.py imports gtsam / multi_sensor / droid_net at module level (absent here), so its BA2GTSAM --
+    ten lines of numpy that only need `Tbc.inverse().AdjointMap()` -- is executed from the reference file's own text,
+    located by its `def` line, with a small Pose3 stand-in for the (absent) gtsam.Pose3."""
+    import ast
+    import textwrap
+    src = open(os.path.join(REF, "depth_video.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "BA2GTSAM")
+    fn.args.args[2].annotation = None  # `Tbc: gtsam.Pose3`
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"np": np}
+    exec(compile(ast.fix_missing_locations(mod), "depth_video.py:BA2GTSAM", "exec"), ns)
+
+    class Pose3:  # gtsam::Pose3 semantics: AdjointMap = [[R, 0], [[t]x R, R]] (rotation, translation order)
+        def __init__(self, M):
+            self.M = np.asarray(M, np.float64)
+
+        def inverse(self):
+            return Pose3(np.linalg.inv(self.M))
+
+        def AdjointMap(self):
+            R, t = self.M[:3, :3], self.M[:3, 3]
+            tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+            return np.block([[R, np.zeros((3, 3))], [tx @ R, R]])
+
+    rng = np.random.default_rng(4)
+    P = 4
+    M = rng.standard_normal((6 * P, 6 * P + 2))
+    H, v = M @ M.T, rng.standard_normal(6 * P)
+    q = np.array([0.1, -0.2, 0.3, 0.9])
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    T = np.eye(4)
+    T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                 [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                 [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+    T[:3, 3] = [0.05, -0.02, 0.11]
+    Hg, vg = ns["BA2GTSAM"](H, v, Pose3(T))
+    np.savez_compressed(os.path.join(HERE, "ba2gtsam.npz"), H=H, v=v, Tbc=T, Hg=Hg, vg=vg, Ad=Pose3(T).AdjointMap())
+
+
 if __name__ == "__main__":
     gen_corr()
     gen_schur()
     gen_pinhole()
     gen_projective()
     gen_ba_step()
+    gen_ba2gtsam()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -42,3 +42,67 @@ def test_every_lietorch_name_the_reference_imports_exists():
         se3_used |= set(re.findall(r"\b(?:Gs?|Gij|Gi|Gj|poses|Ps?|dP|d)\s*(?:\[[^\]]*\])?\.(inv|retr|adjT|adj|matrix|translation|data|log|exp|scale|vec|cpu|act)\b", text))
     missing = sorted(n for n in se3_used if not hasattr(lietorch.SE3, n) and n != "data")
     assert not missing, missing
+
+
+def _ref_corr_module():
+    """the reference's dbaf/modules/corr.py imported with an empty stand-in for its native module"""
+    import importlib.util
+    import sys
+    import types
+    sys.dont_write_bytecode = True
+    saved = sys.modules.get("droid_backends")
+    sys.modules["droid_backends"] = types.ModuleType("droid_backends")
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_modules_corr", os.path.join(REF, "dbaf", "modules", "corr.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if saved is not None:
+            sys.modules["droid_backends"] = saved
+        else:
+            del sys.modules["droid_backends"]
+    return mod
+
+
+def test_corr_mirrors_have_the_reference_signatures():
+    """dbaf_amd.corr is what INTEGRATION.md swaps in for `from modules.corr import CorrBlock, AltCorrBlock`
+    (covisible_graph.py:7, motion_filter.py:8): every public name and every parameter list must match"""
+    import inspect
+    from dbaf_amd import corr as mine
+    ref = _ref_corr_module()
+    for cls in ("CorrBlock", "AltCorrBlock", "CorrSampler", "CorrLayer"):
+        assert hasattr(mine, cls), cls
+        rc, mc = getattr(ref, cls), getattr(mine, cls)
+        for name, member in inspect.getmembers(rc, predicate=inspect.isfunction):
+            if name.startswith("_") and name not in ("__init__", "__call__", "__getitem__"):
+                continue
+            assert hasattr(mc, name), (cls, name)
+            rp = list(inspect.signature(member).parameters)
+            mp = list(inspect.signature(getattr(mc, name)).parameters)
+            assert mp[:len(rp)] == rp, (cls, name, rp, mp)   # the mirror may add trailing keyword options only
+            extra = [inspect.signature(getattr(mc, name)).parameters[k] for k in mp[len(rp):]]
+            assert all(e.default is not inspect.Parameter.empty for e in extra), (cls, name, mp)
+
+
+def test_droid_backends_signatures_match_the_bindings():
+    """src/droid.cpp: every m.def / class method bound there exists here with the same number of parameters"""
+    import inspect
+    import droid_backends
+    text = open(os.path.join(REF, "src", "droid.cpp")).read()
+    bound = re.findall(r'm\.def\("(\w+)",\s*&(\w+)', text)
+    assert len(bound) >= 10
+    for pyname, cname in bound:
+        m = re.search(r"\b%s\s*\(([^)]*)\)\s*\{" % cname, text)
+        assert m, cname
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        fn = getattr(droid_backends, pyname)
+        assert len(inspect.signature(fn).parameters) == nargs, (pyname, nargs, inspect.signature(fn))
+    methods = re.findall(r'\.def\("(\w+)",\s*&BACore::(\w+)\)', text)
+    assert {m for m, _ in methods} >= {"init", "hessian", "optimize", "retract"}
+    hdr = open(os.path.join(REF, "src", "bacore.h")).read()
+    for pyname, cname in methods:
+        m = re.search(r"\b%s\s*\(([^)]*)\)\s*;" % cname, hdr)
+        assert m, cname
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        fn = getattr(droid_backends.BACore, pyname)
+        assert len(inspect.signature(fn).parameters) == nargs + 1, (pyname, nargs)  # + self

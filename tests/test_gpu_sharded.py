@@ -1,7 +1,16 @@
-"""GPU: the edge-sharded BA driver with the real stage executor (HipStages over the C ABI, incl. the
-frame_owned masks in the kernels).  The box has one GPU, so the two ranks run as two Python threads of one
-process and exchange through an in-process stand-in for torch.distributed (RCCL itself is exercised by the
-driver's multi-GPU bench; the exchange logic is also covered on CPU with gloo in test_sharded_cpu.py)."""
+"""GPU: the edge-sharded BA drivers (dbaf_amd.sharded) with the real stage executor (HipStages over the C ABI, incl.
+the frame_owned masks in the kernels).
+
+* loop-back: the test box has one GPU, so the ranks run as Python threads of one process on that GPU and exchange
+  through an in-process stand-in for torch.distributed with the same collective semantics (all_reduce, reduce,
+  broadcast, all_gather_into_tensor) -- incl. the 64-KF / 512-edge window split 8 ways (BASELINE configs[3]) and the
+  fusion-path ShardedBACore (configs[4]);
+* RCCL: real `torch.distributed` process groups with backend "nccl" (= RCCL): one rank on one GPU always (the
+  collectives really go through RCCL), two ranks on two GPUs when the box has them."""
+import os
+import socket
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -16,33 +25,87 @@ pytestmark = pytest.mark.gpu
 
 
 class LoopbackDist:
-    """all_reduce(sum) between `world` threads of this process"""
+    """sum / gather / broadcast between `world` threads of this process (all on one device)"""
 
     def __init__(self, world):
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
         self.local = threading.local()
+        self.calls = {"all_reduce": 0, "reduce": 0, "broadcast": 0, "all_gather_into_tensor": 0}
 
     def bind(self, rank):
         self.local.rank = rank
 
-    def all_reduce(self, t):
+    def _exchange(self, t):
         torch.cuda.synchronize()
         self.slots[self.local.rank] = t.clone()
         self.barrier.wait()
-        total = self.slots[0].clone()
-        for r in range(1, self.world):
-            total += self.slots[r]
+        got = [s.clone() for s in self.slots]
         torch.cuda.synchronize()
         self.barrier.wait()
+        return got
+
+    def all_reduce(self, t):
+        if self.local.rank == 0:
+            self.calls["all_reduce"] += 1
+        got = self._exchange(t)
+        total = got[0]
+        for r in range(1, self.world):   # fixed rank order on every rank: identical bits everywhere
+            total = total + got[r]
         t.copy_(total)
-        torch.cuda.synchronize()
-        self.barrier.wait()
+
+    def reduce(self, t, dst=0):
+        if self.local.rank == 0:
+            self.calls["reduce"] += 1
+        got = self._exchange(t)
+        if self.local.rank == dst:
+            total = got[0]
+            for r in range(1, self.world):
+                total = total + got[r]
+            t.copy_(total)
+
+    def broadcast(self, t, src=0):
+        if self.local.rank == 0:
+            self.calls["broadcast"] += 1
+        t.copy_(self._exchange(t)[src])
+
+    def all_gather_into_tensor(self, out, t):
+        if self.local.rank == 0:
+            self.calls["all_gather_into_tensor"] += 1
+        out.copy_(torch.cat(self._exchange(t), 0))
+
+
+def _run_ranks(world, body):
+    dist = LoopbackDist(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            dist.bind(rank)
+            torch.cuda.set_device(0)
+            results[rank] = body(rank, dist)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+            dist.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
+    return results, dist
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
 @pytest.mark.parametrize("mk,world", [(lambda: syn.window_tiny_b(3), 2), (lambda: syn.window_25_96(1), 2),
-                                     (lambda: syn.window_25_96(2), 4)])
+                                     (lambda: syn.window_25_96(2), 4), (lambda: syn.window_64_512(1), 8)],
+                         ids=["tiny_b-2", "25kf_96edges-2", "25kf_96edges-4", "64kf_512edges-8"])
 def test_sharded_hip_ba_matches_single_gpu_ba(mk, world):
     import droid_backends
     W = mk()
@@ -52,33 +115,158 @@ def test_sharded_hip_ba_matches_single_gpu_ba(mk, world):
     torch.cuda.synchronize()
     ref_poses, ref_disps = d["poses"].cpu().numpy(), d["disps"].cpu().numpy()
 
-    dist = LoopbackDist(world)
-    results, errors = [None] * world, []
+    def body(rank, dist):
+        sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+        sel = sh.local_edges
+        dd = to_dev(W)
+        sh.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], _t(W.target[sel]), _t(W.weight[sel]),
+              dd["eta"], _t(W.ii[sel]), _t(W.jj[sel]), 2, W.lm, W.ep, dist)
+        torch.cuda.synchronize()
+        return dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy(), len(sel)
 
-    def run(rank):
-        try:
-            dist.bind(rank)
-            torch.cuda.set_device(0)
-            sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
-            sel = sh.local_edges
-            dd = to_dev(W)
-            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-            sh.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], t(W.target[sel]), t(W.weight[sel]),
-                  dd["eta"], t(W.ii[sel]), t(W.jj[sel]), 2, W.lm, W.ep, dist)
-            torch.cuda.synchronize()
-            results[rank] = (dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy(), len(sel))
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
-            dist.barrier.abort()
-
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    assert not errors, errors
+    results, dist = _run_ranks(world, body)
     assert sum(r[2] for r in results) == W.N and all(r[2] < W.N for r in results)
+    assert dist.calls["all_reduce"] == 2 and dist.calls["all_gather_into_tensor"] == 1  # one exchange per GN iteration
     for r in range(1, world):  # replicas coherent
         assert np.array_equal(results[r][0], results[0][0]) and np.array_equal(results[r][1], results[0][1])
     # same state as the single-GPU call (summation order of the f64 atomics differs, nothing else)
-    check_state(results[0][0], results[0][1], ref_poses, ref_disps, W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5)
+    print(check_state(results[0][0], results[0][1], ref_poses, ref_disps, W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_bacore_matches_single_gpu_bacore(world):
+    """fusion path (BASELINE configs[4], depth_video.py:469-559) on a WHU-shaped window with depth measurements: two
+    rounds of hessian -> external dense solve on rank 0 -> retract, sharded vs droid_backends.BACore on one GPU"""
+    import droid_backends
+    W = syn.make_window(*syn.graph_banded(10, 3), 10, 48, 64, seed=4, intr=(30.0, 30.0, 31.5, 23.7), sensor_frac=0.2)
+    n = 6 * (W.t1 - W.t0)
+
+    def solve(H, v):
+        Hn, vn = H.numpy(), v.numpy()
+        return torch.from_numpy(np.linalg.solve(Hn + np.diag(W.ep + W.lm * np.diag(Hn)), vn))
+
+    d = to_dev(W)
+    core = droid_backends.BACore()
+    core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+              d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    H1 = None
+    for it in range(2):
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        core.hessian(H, v)
+        H1 = H.numpy().copy() if it == 0 else H1
+        core.retract(solve(H, v))
+    torch.cuda.synchronize()
+    ref_poses, ref_disps = d["poses"].cpu().numpy(), d["disps"].cpu().numpy()
+
+    def body(rank, dist):
+        sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+        sel = sh.local_edges
+        dd = to_dev(W)
+        sc = sh.bacore(dist)
+        sc.init(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], _t(W.target[sel]), _t(W.weight[sel]),
+                dd["eta"], _t(W.ii[sel]), _t(W.jj[sel]), W.t0, W.t1, 2, W.lm, W.ep, False)
+        H0 = None
+        for it in range(2):
+            H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+            sc.hessian(H, v)
+            if rank == 0 and it == 0:
+                H0 = H.numpy().copy()
+            sc.retract(solve(H, v) if rank == 0 else None)
+        torch.cuda.synchronize()
+        return dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy(), H0
+
+    results, dist = _run_ranks(world, body)
+    assert dist.calls["reduce"] == 2 and dist.calls["broadcast"] == 2 and dist.calls["all_gather_into_tensor"] == 2
+    np.testing.assert_allclose(results[0][2], H1, rtol=0, atol=1e-9 * np.abs(H1).max())
+    for r in range(1, world):
+        assert np.array_equal(results[r][0], results[0][0]) and np.array_equal(results[r][1], results[0][1])
+    print(check_state(results[0][0], results[0][1], ref_poses, ref_disps, W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
+
+
+# ---- real RCCL ------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rccl_worker(rank, world, port, out):
+    """one process per GPU, backend "nccl" (RCCL): sharded ba + sharded BACore, results written by rank 0"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    W = syn.window_25_96(7)
+    sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+    sel = sh.local_edges
+    dd = to_dev(W)
+    sh.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], _t(W.target[sel]), _t(W.weight[sel]), dd["eta"],
+          _t(W.ii[sel]), _t(W.jj[sel]), 2, W.lm, W.ep, dist)
+    torch.cuda.synchronize()
+    res = dict(ba_poses=dd["poses"].cpu().numpy(), ba_disps=dd["disps"].cpu().numpy())
+    # replicas bit-identical across ranks
+    chk = torch.stack([dd["poses"].double().sum(), dd["disps"].double().sum()])
+    lst = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(lst, chk)
+    assert all(torch.equal(x, lst[0]) for x in lst)
+    dd = to_dev(W)
+    n = 6 * (W.t1 - W.t0)
+    sc = sh.bacore(dist)
+    sc.init(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], _t(W.target[sel]), _t(W.weight[sel]),
+            dd["eta"], _t(W.ii[sel]), _t(W.jj[sel]), W.t0, W.t1, 2, W.lm, W.ep, False)
+    for _ in range(2):
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        sc.hessian(H, v)
+        dx = None
+        if rank == 0:
+            Hn, vn = H.numpy(), v.numpy()
+            dx = torch.from_numpy(np.linalg.solve(Hn + np.diag(W.ep + W.lm * np.diag(Hn)), vn))
+        sc.retract(dx)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out, core_poses=dd["poses"].cpu().numpy(), core_disps=dd["disps"].cpu().numpy(), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_paths_over_real_rccl(world, tmp_path):
+    """`backend="nccl"` process group(s): world 1 runs everywhere (every collective of the sharded drivers goes
+    through RCCL on one rank); world 2 needs two GPUs and is skipped on a one-GPU box."""
+    import droid_backends
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, torch.cuda.device_count()))
+    out = str(tmp_path / "rccl.npz")
+    port = _free_port()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = ("import sys; import test_gpu_sharded as T; "
+            "T._rccl_worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port), out], env=env, cwd=here)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    W = syn.window_25_96(7)
+    d = to_dev(W)
+    droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"],
+                      d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    torch.cuda.synchronize()
+    print(check_state(got["ba_poses"], got["ba_disps"], d["poses"].cpu().numpy(), d["disps"].cpu().numpy(), W.disps,
+                      t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
+    d = to_dev(W)
+    n = 6 * (W.t1 - W.t0)
+    core = droid_backends.BACore()
+    core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+              d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    for _ in range(2):
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        core.hessian(H, v)
+        Hn, vn = H.numpy(), v.numpy()
+        core.retract(torch.from_numpy(np.linalg.solve(Hn + np.diag(W.ep + W.lm * np.diag(Hn)), vn)))
+    torch.cuda.synchronize()
+    print(check_state(got["core_poses"], got["core_disps"], d["poses"].cpu().numpy(), d["disps"].cpu().numpy(), W.disps,
+                      t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))

@@ -41,6 +41,9 @@ class OracleStages:
         L = c["H"] + np.diag(ep + lm * np.diag(c["H"]))
         c["dx"] = np.linalg.solve(L, c["v"])
 
+    def set_dx(self, c, dx64):
+        c["dx"] = dx64.numpy().copy()
+
     def update(self, c, update_disps=True):
         c["core"].retract(c["dx"])
         c["poses"].copy_(torch.from_numpy(c["core"].poses))
@@ -76,6 +79,43 @@ def _worker(rank, world, port, out):
     assert all(torch.equal(r, ref[0]) for r in ref)
     if rank == 0:
         np.savez(out, poses=poses.numpy(), disps=disps.numpy(), dx=dx.numpy(), nloc=len(sel))
+    dist.destroy_process_group()
+
+
+def _worker_bacore(rank, world, port, out):
+    """the fusion path: hessian -> (rank 0: external solve) -> retract, twice (depth_video.py:524-558)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W = _window()
+    sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+    sel = sh.local_edges
+    poses, disps = _t(W.poses), _t(W.disps)
+    core = sh.bacore(dist, stages=OracleStages())
+    core.init(poses, disps, _t(W.intrinsics), _t(W.disps_sens), _t(W.target[sel]), _t(W.weight[sel]), _t(W.eta),
+              _t(W.ii[sel], torch.int64), _t(W.jj[sel], torch.int64), W.t0, W.t1, 2, W.lm, W.ep, False)
+    n = 6 * (W.t1 - W.t0)
+    Hs = []
+    for _ in range(2):
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        core.hessian(H, v)
+        dx = None
+        if rank == 0:
+            Hn, vn = H.numpy(), v.numpy()
+            Hs.append(Hn.copy())
+            dx = torch.from_numpy(np.linalg.solve(Hn + np.diag(W.ep + W.lm * np.diag(Hn)), vn))
+        else:
+            assert float(H.abs().max()) == 0.0   # the system goes to rank 0 only
+        core.retract(dx)
+    ref = [torch.zeros_like(disps) for _ in range(world)]
+    dist.all_gather(ref, disps)
+    assert all(torch.equal(r, ref[0]) for r in ref)
+    refp = [torch.zeros_like(poses) for _ in range(world)]
+    dist.all_gather(refp, poses)
+    assert all(torch.equal(r, refp[0]) for r in refp)
+    if rank == 0:
+        np.savez(out, poses=poses.numpy(), disps=disps.numpy(), H0=Hs[0], nloc=len(sel))
     dist.destroy_process_group()
 
 
@@ -124,3 +164,27 @@ def test_sharded_ba_matches_unsharded_world2(tmp_path):
         poses, disps = core.poses, core.disps
     np.testing.assert_allclose(got["poses"], poses, rtol=0, atol=1e-9)
     np.testing.assert_allclose(got["disps"], disps, rtol=1e-8, atol=1e-9)
+
+
+def test_sharded_bacore_matches_unsharded_world2(tmp_path):
+    """the IMU-path counterpart (BASELINE config 5): reduce onto rank 0, external solve there, dx broadcast"""
+    from oracle import oracle as orc
+    out = str(tmp_path / "rank0_core.npz")
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="2", OMP_WAIT_POLICY="passive", PYTHONPATH=os.pathsep.join(sys.path))
+    code = "import sys; import test_sharded_cpu as T; T._worker_bacore(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3])"
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), out], env=env,
+                              cwd=os.path.dirname(os.path.abspath(__file__))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    W = _window()
+    core = orc.BACore(W.poses.astype(np.float64), W.disps.astype(np.float64), W.intrinsics, W.disps_sens, W.target,
+                      W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, W.lm, W.ep, np.float64)
+    for it in range(2):
+        H, v = core.hessian()
+        if it == 0:
+            np.testing.assert_allclose(got["H0"], H, rtol=1e-10, atol=1e-12 * np.abs(H).max())
+        core.retract(np.linalg.solve(H + np.diag(W.ep + W.lm * np.diag(H)), v))
+    np.testing.assert_allclose(got["poses"], core.poses, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["disps"], core.disps, rtol=1e-8, atol=1e-9)

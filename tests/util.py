@@ -1,3 +1,6 @@
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -19,32 +22,65 @@ def quat_angle(qa, qb):
     return 2.0 * np.arcsin(np.clip(cr / 2.0, 0, 1))
 
 
+REPORT = os.environ.get("DBA_PARITY_REPORT") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "parity_report.jsonl")
+
+
+def _record(rec):
+    """one line per parity comparison (test id, measured worst cases): the committed copy under profiles/ makes the
+    slack between the measured error and the asserted tolerance visible"""
+    rec = dict(test=os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0],
+               solver=os.environ.get("DBA_SOLVE_KERNEL", "default"), **rec)
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
 def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None, t_tol=1e-5, r_tol=1e-6,
-                d_rtol=1e-4, frac=0.995):
+                d_rtol=1e-4, frac=0.995, ref32_factor=2.0):
     """north_star tolerances: poses 1e-5 m / 1e-6 rad; inverse depths 1e-4 relative -- measured against the
     float64 arbiter instantiation of the oracle.
 
-    Depth criterion, per pixel:  |d - d_ref| <= max(d_rtol * max(|d_ref|, |d_old|), 2 * |d_ref32 - d_ref|)
+    Depth criterion, per pixel:  |d - d_ref| <= max(d_rtol * max(|d_ref|, |d_old|), ref32_factor * |d_ref32 - d_ref|)
       * the update is d_old + dz and may cancel, so the natural scale of fp32 rounding is the larger of the two;
       * at the few ill-conditioned pixels where the reference's OWN fp32 arithmetic (the faithful fp32
         restatement, ref32) is further than that from exact arithmetic, the HIP path must be no worse than
-        twice the reference's own deviation (measured: oracle32 vs oracle64 reaches 2e-4 on such pixels).
+        ref32_factor times the reference's own deviation (pass ref32_disps=None to switch the allowance off).
     In addition at least `frac` of the non-cancelling pixels (|d_ref| >= 0.1 |d_old|) must meet the pure relative
-    bound d_rtol * |d_ref|."""
+    bound d_rtol * |d_ref|.  Every call appends its measured worst cases to gpurun_out/parity_report.jsonl."""
     poses, ref_poses = np.asarray(poses, np.float64), np.asarray(ref_poses, np.float64)
     dt = np.abs(poses[:, :3] - ref_poses[:, :3]).max()
     dr = quat_angle(poses[:, 3:], ref_poses[:, 3:]).max()
     d, r, o = np.asarray(disps, np.float64), np.asarray(ref_disps, np.float64), np.asarray(old_disps, np.float64)
     err = np.abs(d - r)
     scale = np.maximum(np.abs(r), np.abs(o))
-    allowed = d_rtol * scale
+    base = d_rtol * scale
+    allowed = base
+    n_allow = 0
+    ref32_worst = None
     if ref32_disps is not None:
-        allowed = np.maximum(allowed, 2.0 * np.abs(np.asarray(ref32_disps, np.float64) - r))
+        dev32 = np.abs(np.asarray(ref32_disps, np.float64) - r)
+        allowed = np.maximum(base, ref32_factor * dev32)
+        n_allow = int((err > base).sum())             # pixels that needed the allowance
+        ref32_worst = float((dev32 / np.maximum(scale, 1e-12)).max())
     worst = (err / np.maximum(allowed, 1e-300)).max()
     solid = np.abs(r) >= 0.1 * np.abs(o)
-    pure = (err[solid] <= d_rtol * np.abs(r[solid])).mean() if solid.any() else 1.0
-    msg = "dt=%.3e m dr=%.3e rad depth max(err/allowed)=%.3f max(err/scale)=%.3e pure-rel frac=%.6f" % (
-        dt, dr, worst, (err / np.maximum(scale, 1e-12)).max(), pure)
+    pure_err = err[solid] / np.abs(r[solid]) if solid.any() else np.zeros(1)
+    pure = (pure_err <= d_rtol).mean()
+    rec = dict(dt_m=float(dt), dr_rad=float(dr), depth_max_err_over_scale=float((err / np.maximum(scale, 1e-12)).max()),
+               depth_max_err_over_dref_noncancelling=float(pure_err.max()), depth_p999_err_over_dref=float(
+                   np.quantile(pure_err, 0.999)), frac_pure_rel_ok=float(pure), pixels=int(err.size),
+               pixels_needing_ref32_allowance=n_allow, ref32_own_max_dev_over_scale=ref32_worst,
+               tol=dict(t=t_tol, r=r_tol, d_rtol=d_rtol, frac=frac,
+                        ref32_factor=ref32_factor if ref32_disps is not None else None))
+    _record(rec)
+    msg = ("dt=%.3e m dr=%.3e rad depth max(err/allowed)=%.3f max(err/scale)=%.3e max(err/|d_ref|)=%.3e "
+           "pure-rel frac=%.6f ref32-allowance pixels=%d/%d" % (
+               dt, dr, worst, rec["depth_max_err_over_scale"], rec["depth_max_err_over_dref_noncancelling"], pure,
+               n_allow, err.size))
     assert dt <= t_tol, msg
     assert dr <= r_tol, msg
     assert worst <= 1.0, msg
