@@ -22,6 +22,8 @@
 
 #include <type_traits>
 
+#include <cstdlib>
+
 namespace dba {
 
 constexpr int SH_MAX_LEVELS = 8;
@@ -35,7 +37,7 @@ struct ShLevels {
 // 64 contiguous halves of plane (dy, dx).
 __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restrict__ V,
                                                          _Float16 *__restrict__ Vs, int h1, int w1, int h2l,
-                                                         int w2l, int lvl) {
+                                                         int w2l, int lvl, int HW1p) {
   extern __shared__ _Float16 tile[];  // [64][w2l + 2]
   const int pitch = w2l + 2;
   const int x0 = blockIdx.x * 64;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restr
   int dy = ty - (y1 >> lvl);
   dy %= h2l;
   if (dy < 0) dy += h2l;
-  const size_t HW1 = (size_t)h1 * w1;
+  const size_t HW1 = (size_t)HW1p;  // planes are padded to a multiple of 64 pixels (see the resident lookup)
   for (int idx = threadIdx.x; idx < nx * w2l; idx += blockDim.x) {
     const int dx = idx / nx, xi = idx - dx * nx;
     const int tx = (((x0 + xi) >> lvl) + dx) % w2l;
@@ -118,7 +120,10 @@ constexpr int SH_NX = 16;     // plane-rows per step held in LDS (union width in
 constexpr int SH_NY = 72;     // longest union in y walked by the streaming path
 // cache-policy bits of the buffer instructions (gfx950: 1 = sc0, 2 = nt, 16 = sc1); 0 = default policy
 #ifndef SH_LOAD_AUX
-#define SH_LOAD_AUX 2  // nt: every window is read once; -10 % (82 -> 74 us) on the 96-edge lookup
+// 2 (nt) is 10 % faster when the same windows are replayed out of the 256 MB Infinity Cache (76 vs 88 us on the 96-edge
+// window), the default policy is 6 % faster when they come from HBM (rotating pyramid copies: 94.9 vs 101.0 us; 512
+// edges: 517 vs 540 us) -- which is what an update sees, so the default policy it is
+#define SH_LOAD_AUX 0
 #endif
 #ifndef SH_STORE_AUX
 #define SH_STORE_AUX 0
@@ -499,11 +504,333 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   }
 }
 
+
+// =====================================================================================================================
+// Lookup, second form ("resident"): the union of the wave's windows is brought into LDS ONCE, then every lane reads
+// its own 8x8 taps from there.
+//
+//   * a wave = 64 CONSECUTIVE PIXELS of the flattened (y1, x1) index of one edge, one pyramid level; planes of the
+//     sheared volume are padded to a multiple of 64 pixels (HW1p), so a strip is one aligned 128-byte line of every plane
+//     whatever the map width is (28x107, 55x55 and 48x64 stream exactly like 64x64; a strip may span a row end: the
+//     offsets (dy, dx) are per pixel anyway);
+//   * staging: exec-masked `buffer_load_dwordx4 ... lds` (LDS-DMA, 16 B per lane, no VGPR round trip, no ds_write) of the
+//     union rows; all of a wave's lines are in flight at once, one wait, no per-row hand-shake;
+//   * because the whole union is resident, all lanes walk their OWN tap rows j = 0..7 in lock-step: 7 emitting steps
+//     instead of 8 + spread, and every store instruction writes one channel for all 64 pixels = one full 128-byte line
+//     (the streaming form wrote partial lines whenever lanes sat on different rows);
+//     (exchanging channel pairs between neighbouring lanes so that a lane stores 4 bytes -- 4 store instructions per step
+//     instead of 7 -- was built and measured 3 % SLOWER: neither form of the kernel is bound by store instructions);
+//   * lanes whose window is far from the others (flow discontinuities, strips that span a row end on strongly divergent
+//     flow) are taken in further passes of the same code on the remaining lanes (up to SH2_MAXPASS), the rest by a
+//     per-lane gather; the union of a pass must fit SH2_LCAP lines of LDS (the band around the pass's reference lane is
+//     halved until it does: a single window always fits).
+// Arithmetic: identical to the streaming form and to the reference, bit for bit (same packed-f16 blend order).
+#ifndef SH2_LCAP_CFG
+#define SH2_LCAP_CFG 144  // 96: 138 us, 120: 122 us, 144: 104 us, 160-192: 120 us on the KITTI-shaped window (LDS per wave vs passes)
+#endif
+#ifndef SH2_WAVES_CFG
+#define SH2_WAVES_CFG 2
+#endif
+#ifndef SH2_MAXPASS_CFG
+#define SH2_MAXPASS_CFG 3
+#endif
+#ifndef SH2_MINOCC_CFG
+#define SH2_MINOCC_CFG 2
+#endif
+constexpr int SH2_LCAP = SH2_LCAP_CFG;      // lines (128 B) of staging per wave
+constexpr int SH2_WAVES = SH2_WAVES_CFG;    // independent waves per workgroup
+constexpr int SH2_MAXPASS = SH2_MAXPASS_CFG;
+constexpr int SH2_WAVE_BYTES = SH2_LCAP * 128 + 1024;  // + 8 zero lines (tap rows of lanes that touch nothing)
+
+// v mod n for |v| < ~2^22, n >= 1 (inv_n = 1.0f / n): float quotient estimate + one correction either way
+__device__ __forceinline__ int sh2_mod(int v, int n, float inv_n, bool pow2) {
+  if (pow2) return v & (n - 1);
+  int q = (int)floorf(((float)v + 0.5f) * inv_n);
+  int m = v - q * n;
+  m += (m < 0) ? n : 0;
+  m -= (m >= n) ? n : 0;
+  return m;
+}
+
+template <int R>
+__global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_resident_kernel(
+    ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
+    int num_levels, int HW1p, float inv_w1) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  static_assert(WN == 8, "written for radius 3");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HW1 = h1 * w1;
+  const int strips = HW1p >> 6;  // per edge
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give each XCD a contiguous range of strips
+#ifndef SH2_NO_XCD
+  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
+  const int lb = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
+#else
+  const int lb = blockIdx.x;
+#endif
+  const int lvl = blockIdx.y;
+  const int sid = lb * SH2_WAVES + wave;
+  if (sid >= n * strips) return;  // (waves of a workgroup are independent: no barriers below)
+  const int e = sid / strips, p0 = (sid - e * strips) << 6;
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+  const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
+  const float inv_w2l = 1.0f / (float)w2l, inv_h2l = 1.0f / (float)h2l;
+
+  unsigned char *const stage = smem + wave * SH2_WAVE_BYTES;   // [row][nxa][64] halves
+  unsigned char *const zeros = stage + SH2_LCAP * 128;         // 8 lines of zeros
+  {
+    u4v z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u4v *>(zeros + lane * 16) = z;
+  }
+
+  const int p = p0 + lane;
+  const bool active = p < HW1;
+  const int pc = min(p, HW1 - 1);
+  int y1 = (int)(((float)pc + 0.5f) * inv_w1);
+  int x1 = pc - y1 * w1;
+  if (x1 < 0) { y1--; x1 += w1; }
+  if (x1 >= w1) { y1++; x1 -= w1; }
+  const ShPixel P = sh_pixel<R>(coords[(size_t)e * HW1 + pc], lvl, x1, y1, h2l, w2l, active);
+  const bool touches = P.touches;
+  const int ox = P.ox, oy = P.oy;
+
+  _Float16 *obase = out + ((size_t)e * num_levels + lvl) * RD * RD * HW1;  // this edge, this level: [49][HW1]
+  const size_t rowstride = (size_t)w2l * HW1p;                              // elements between consecutive dy
+  const unsigned rowbytes = (unsigned)(2 * rowstride);
+  const _Float16 *vedge = L.vol[lvl] + (size_t)e * h2l * rowstride;
+  const bool can_stream = ((size_t)h2l * rowbytes < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
+  constexpr unsigned OOR = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, can_stream ? (int)((unsigned)h2l * rowbytes) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout =
+      __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, can_stream ? (int)(2u * RD * RD * (unsigned)HW1) : 0, 0x00020000);
+
+  h2v W00, W01, W10, W11;
+  W00.x = W00.y = P.h00;
+  W01.x = W01.y = P.h01;
+  W10.x = W10.y = P.h10;
+  W11.x = W11.y = P.h11;
+
+  // validity of this lane's taps (image border): columns i in [ia, ib), rows j in [ja, jb)
+  const int ia = max(0, -P.ix0), ib = min(WN, w2l - P.ix0);
+  const int ja = max(0, -P.iy0), jb = min(WN, h2l - P.iy0);
+  const bool clipped = touches && (ia > 0 || ib < WN || ja > 0 || jb < WN);
+  unsigned cm[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    cm[k] = ((2 * k >= ia && 2 * k < ib) ? 0x0000ffffu : 0u) | ((2 * k + 1 >= ia && 2 * k + 1 < ib) ? 0xffff0000u : 0u);
+
+  unsigned long long todo = can_stream ? __ballot(touches) : 0ull;
+  const unsigned long long untouched = __ballot(active && !touches);
+  bool first = true;
+  const int big = 1 << 28;
+
+  for (int pass = 0; pass < SH2_MAXPASS && (todo != 0ull || (first && untouched != 0ull)); pass++) {
+    const bool mine = ((todo >> lane) & 1ull) != 0ull;
+    // ---- which lanes this pass takes: all remaining ones if their union fits, else a band around the first of them
+    bool in = mine;
+    int bx0 = 0, by0 = 0, nxa = 8, ny = 8;
+    if (todo != 0ull) {
+      const int fl = __ffsll((long long)todo) - 1;
+      const int refx = __builtin_amdgcn_readlane(ox, fl), refy = __builtin_amdgcn_readlane(oy, fl);
+      int band = 64;  // first try: everything
+      for (;;) {
+        in = mine && (abs(ox - refx) <= band) && (abs(oy - refy) <= band);
+        bx0 = wave_minmax<true>(in ? ox : big);
+        by0 = wave_minmax<true>(in ? oy : big);
+        const int bx1 = wave_minmax<false>(in ? ox : -big), by1 = wave_minmax<false>(in ? oy : -big);
+        nxa = bx1 - bx0 + WN;
+        ny = by1 - by0 + WN;
+        if (nxa <= 16 && ny <= 16 && nxa * ny <= SH2_LCAP) break;
+        band = (band > 4) ? 4 : (band >> 1);  // 64 -> 4 -> 2 -> 1 -> 0; band 0 is one window: 8 x 8 lines
+      }
+    } else {
+      in = false;
+    }
+    const unsigned long long inmask = __ballot(in);
+    const int rx = in ? ox - bx0 : 0, ry = in ? oy - by0 : 0;
+
+    // ---- staging -----------------------------------------------------------------------------------------------
+    if (inmask != 0ull) {
+      // per 8-lane group (= the 16-byte piece `sub` of every line): range of window origins inside the group
+      const int gx0 = group8_minmax<true>(in ? rx : 31), gx1 = group8_minmax<false>(in ? rx : -1);
+      const int gy0 = group8_minmax<true>(in ? ry : 31), gy1 = group8_minmax<false>(in ? ry : -1);
+      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
+      const int sub = lane & 7;
+      const int pg = __builtin_amdgcn_ds_bpermute(sub * 32, packed);  // from lane 8 * sub
+      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
+      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
+      unsigned goff[2], jlo, jlen[2];
+      jlo = (unsigned)py0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int jx = (lane >> 3) + 8 * t;
+        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN) && (jx < nxa);
+        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
+        const int m = sh2_mod(bx0 + jx, w2l, inv_w2l, pow2);
+        goff[t] = 2u * ((unsigned)m * (unsigned)HW1p + (unsigned)p0 + (unsigned)sub * 8u);
+      }
+      int dym = __builtin_amdgcn_readfirstlane(sh2_mod(by0, h2l, inv_h2l, pow2));
+      const bool wide = nxa > 8;
+      unsigned ldsrow = (unsigned)(stage - smem);
+      const unsigned ldspitch = (unsigned)nxa * 128u;
+      for (int row = 0; row < ny; row++) {
+        const unsigned soff = (unsigned)dym * rowbytes;
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+#ifndef SH2_ABLATE_LOADS
+        if (((unsigned)row - jlo) < jlen[0])
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow), 16,
+                                                   goff[0], soff, 0, SH_LOAD_AUX);
+        if (wide) {
+          if (((unsigned)row - jlo) < jlen[1])
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow + 1024u),
+                                                     16, goff[1], soff, 0, SH_LOAD_AUX);
+        }
+#endif
+        ldsrow += ldspitch;
+      }
+    }
+    // the LDS-DMA writes are tracked by vmcnt; LDS operations of one wave are then in program order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- compute: tap rows j = 0..7 of every lane in lock-step ------------------------------------------------------
+    const bool zero_lane = first && active && !touches;   // exact zeros, produced by the arithmetic (zero weights)
+    const bool writes = in || zero_lane;
+    const unsigned long long wm = __ballot(writes);
+    const bool masked = __ballot(in && clipped) != 0ull;
+    const unsigned pix2 = 2u * (unsigned)p;
+    const unsigned tb = in ? (unsigned)(stage - smem) + (unsigned)((ry * nxa + rx) * 128) + 2u * (unsigned)lane
+                           : (unsigned)(zeros - smem) + 2u * (unsigned)lane;
+    const unsigned radv = in ? (unsigned)nxa * 128u : 0u;
+    const unsigned voff = writes ? pix2 : OOR;
+    const unsigned chb = 2u * (unsigned)HW1;  // bytes per channel plane
+
+    ShTaps A, B;
+    auto load_row = [&](int j, ShTaps &T) {
+      sh_read_taps(reinterpret_cast<const _Float16 *>(smem + tb + (unsigned)j * radv), T);
+      if (masked) {
+        const bool rowok = (j >= ja) && (j < jb);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned keep = (rowok || !in) ? ((in && clipped) ? cm[k] : 0xffffffffu) : 0u;
+          T.e[k] = __builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, T.e[k]) & keep);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned lo = __builtin_bit_cast(unsigned, T.e[k]);
+          const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, T.e[k < 3 ? k + 1 : 3]) : 0u;
+          T.o[k] = __builtin_bit_cast(h2v, __builtin_amdgcn_alignbit(hi, lo, 16));
+        }
+      }
+    };
+    auto emit = [&](int b, const ShTaps &prev, const ShTaps &cur) {  // output row b = j - 1 of all 7 columns a
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+#ifdef SH2_ABLATE_COMPUTE  // scratch builds: memory traffic only
+        const unsigned bits = __builtin_bit_cast(unsigned, W00) + (unsigned)b;
+#else
+        h2v acc = prev.e[k] * W00;
+        acc = acc + cur.e[k] * W01;
+        acc = acc + prev.o[k] * W10;
+        acc = acc + cur.o[k] * W11;
+        const unsigned bits = __builtin_bit_cast(unsigned, acc);
+#endif
+#ifdef SH2_ABLATE_STORES
+        if (k != 0 || b != 0) { asm volatile("" ::"v"(bits)); continue; }
+#endif
+        const unsigned soff = (unsigned)((2 * k) * RD + b) * chb;  // channel (a = 2k, b), uniform
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, soff, SH_STORE_AUX);
+        if (k < 3)
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, soff + (unsigned)RD * chb, SH_STORE_AUX);
+      }
+    };
+#ifdef SH2_ABLATE_COMPUTE
+#define load_row(j, T) (void)0
+#endif
+    if (wm != 0ull) {
+      load_row(0, A);
+      load_row(1, B); emit(0, A, B);
+      load_row(2, A); emit(1, B, A);
+      load_row(3, B); emit(2, A, B);
+      load_row(4, A); emit(3, B, A);
+      load_row(5, B); emit(4, A, B);
+      load_row(6, A); emit(5, B, A);
+      load_row(7, B); emit(6, A, B);
+    }
+#ifdef SH2_ABLATE_COMPUTE
+#undef load_row
+#endif
+    __builtin_amdgcn_wave_barrier();  // the next pass overwrites the staging area
+    todo &= ~inmask;
+    first = false;
+  }
+
+  // ---- what no pass took (or could take): per-lane gather straight from the sheared volume ---------------------------
+  const bool left = can_stream ? (((todo >> lane) & 1ull) != 0ull) : active;
+  if (left) {
+    const _Float16 *vol = vedge + p;
+    _Float16 *o = obase + p;
+    if (!touches) {
+#pragma unroll
+      for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
+    } else {
+      int dxm[WN];
+      bool cok[WN];
+#pragma unroll
+      for (int i = 0; i < WN; i++) {
+        dxm[i] = sh2_mod(P.ox + i, w2l, inv_w2l, pow2);
+        const int tx = P.ix0 + i;
+        cok[i] = (tx >= 0) && (tx < w2l);
+      }
+      int dym = sh2_mod(P.oy, h2l, inv_h2l, pow2);
+      _Float16 prev[WN];
+#pragma unroll
+      for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
+      for (int j = 0; j < WN; j++) {
+        const int ty = P.iy0 + j;
+        const bool rok = (ty >= 0) && (ty < h2l);
+        _Float16 cur[WN];
+#pragma unroll
+        for (int i = 0; i < WN; i++)
+          cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1p] : (_Float16)0.f;
+        if (j >= 1) {
+#pragma unroll
+          for (int a = 0; a < RD; a++)
+            o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
+        }
+#pragma unroll
+        for (int i = 0; i < WN; i++) prev[i] = cur[i];
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+      }
+    }
+  }
+}
+
 }  // namespace dba
 
 using namespace dba;
 
+// 0 = automatic, 1 = streaming form, 2 = resident form (initialised from DBA_LOOKUP_KERNEL)
+static std::atomic<int> g_lookup_select{[] {
+  const char *e = getenv("DBA_LOOKUP_KERNEL");
+  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : 0;
+}()};
+
 extern "C" {
+
+int dba_corr_lookup_select(int kernel) {
+  if (kernel < 0 || kernel > 2) return DBA_ERR_ARG;
+  g_lookup_select.store(kernel, std::memory_order_relaxed);
+  return DBA_OK;
+}
+
+int dba_corr_sheared_plane_elems(int h1, int w1) {
+  if (h1 <= 0 || w1 <= 0) return 0;
+  return (h1 * w1 + 63) / 64 * 64;
+}
 
 int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int h1, int w1, int h2l, int w2l,
                          int lvl, dba_stream_t stream) {
@@ -515,7 +842,7 @@ int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int 
   dim3 grid((w1 + 63) / 64, h2l, n * h1);
   hipLaunchKernelGGL(corr_shear_kernel, grid, dim3(256), lds, (hipStream_t)stream,
                      static_cast<const _Float16 *>(ref_level), static_cast<_Float16 *>(sheared_level), h1, w1, h2l,
-                     w2l, lvl);
+                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1));
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -527,15 +854,44 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
   if (radius != 3) return DBA_ERR_UNSUPPORTED;
   if (n == 0) return DBA_OK;
   if (!volumes || !coords_nhw2 || !corr) return DBA_ERR_ARG;
+  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
   ShLevels L;
   for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
-  const int xtiles = (w1 + 63) / 64;
   if ((long)n * h1 * w1 >= 2147483647L) return DBA_ERR_UNSUPPORTED;
-  const long rows = (long)n * h1 * xtiles;
-  dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), num_levels);
-  hipLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, L,
+  const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
+  // Two forms of the kernel (see the comments at each): "streaming" walks the union row by row (2 KB of LDS per wave,
+  // any union height; needs waves that are whole 64-pixel rows), "resident" holds the union in LDS (any map size, 7
+  // lock-step steps, full-line stores).  Measured from HBM (rotating pyramid copies): 64x64 maps, 96 / 512 edges:
+  // streaming 95.8 / 523 us, resident 102 / 535 us; 28x107, 122 edges: streaming 128, resident 104 us; 55x55 streams
+  // only in the resident form.  Automatic choice: streaming for 64-pixel-wide rows, resident otherwise;
+  // dba_corr_lookup_select() / DBA_LOOKUP_KERNEL=stream|resident override it.
+  const bool stream_ok = (w1 % 64 == 0);
+  const int sel = g_lookup_select.load(std::memory_order_relaxed);
+  const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
+  if (want_stream && stream_ok) {
+    const int xtiles = (w1 + 63) / 64;
+    const long rows = (long)n * h1 * xtiles;
+    dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), num_levels);
+    hipLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, L,
+                       reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                       num_levels);
+    DBA_LAUNCH_CHECK();
+    return DBA_OK;
+  }
+  const long strips = (long)n * (HW1p / 64);
+  dim3 grid((unsigned)((strips + SH2_WAVES - 1) / SH2_WAVES), num_levels);
+  const size_t lds = (size_t)SH2_WAVES * SH2_WAVE_BYTES;
+  if (lds > 64 * 1024) {
+    static DeviceOnce attr_once;
+    if (attr_once.needed()) {
+      DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_lookup_resident_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_once.done();
+    }
+  }
+  hipLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, L,
                      reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                     num_levels);
+                     num_levels, HW1p, 1.0f / (float)w1);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -29,7 +29,8 @@ def _stream():
 
 class CorrBlock:
     """layout="sheared" (default when the shapes allow it) keeps every level flow-aligned,
-    Vs_l[n, dy, dx, y1, x1] (csrc/corr_sheared.hip), so the lookup fetches full cache lines;
+    Vs_l[n, dy, dx, pixel] with pixel = y1 * w1 + x1 and the pixel axis padded to a multiple of 64
+    (csrc/corr_sheared.hip), so the lookup fetches full cache lines for any map size;
     layout="reference" keeps the reference's [n, y1, x1, y2, x2] tensors, which are also valid inputs to
     droid_backends.corr_index_forward.  Both give bit-identical lookups."""
 
@@ -45,6 +46,7 @@ class CorrBlock:
         if layout == "sheared" and not can_shear:
             raise RuntimeError("CorrBlock: sheared layout needs radius 3 and equal feature-map sizes")
         self.layout = layout
+        self.h1, self.w1 = int(h1), int(w1)
         self.h2, self.w2 = int(h2), int(w2)
         if layout == "sheared":
             fused = CorrBlock.build_sheared_fused(fmap1, fmap2, num_levels)
@@ -84,7 +86,8 @@ class CorrBlock:
         n = batch * num
         f1 = fmap1.reshape(n, dim, h1, w1).to(torch.float16).contiguous()
         f2 = fmap2.reshape(n, dim, h2, w2).to(torch.float16).contiguous()
-        levels = [torch.empty(n, h2 >> l, w2 >> l, h1, w1, dtype=torch.float16, device=f1.device)
+        assert lib.dba_corr_sheared_plane_elems(h1, w1) == h1 * w1   # the fused build takes unpadded planes only
+        levels = [torch.empty(n, h2 >> l, w2 >> l, h1 * w1, dtype=torch.float16, device=f1.device)
                   for l in range(num_levels)]
         sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, h2, w2)
         scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)
@@ -96,12 +99,14 @@ class CorrBlock:
 
     @staticmethod
     def shear_pyramid(ref_levels):
-        """reference-layout levels [n,h1,w1,h2l,w2l] -> flow-aligned levels [n,h2l,w2l,h1,w1]"""
+        """reference-layout levels [n,h1,w1,h2l,w2l] -> flow-aligned levels [n,h2l,w2l,HW1p] (pixel axis padded to a
+        multiple of 64; the padding is never read for a real pixel)"""
         lib = _lib.load()
         out = []
         for lvl, v in enumerate(ref_levels):
             n, h1, w1, h2l, w2l = v.shape
-            vs = torch.empty(n, h2l, w2l, h1, w1, dtype=v.dtype, device=v.device)
+            vs = torch.empty(n, h2l, w2l, lib.dba_corr_sheared_plane_elems(int(h1), int(w1)), dtype=v.dtype,
+                             device=v.device)
             _lib.check(lib.dba_corr_shear_level(_ptr(v), _ptr(vs), int(n), int(h1), int(w1), int(h2l), int(w2l),
                                                 lvl, _stream()), "dba_corr_shear_level")
             out.append(vs)
@@ -128,6 +133,7 @@ class CorrBlock:
         vols = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
         ptrs = (ctypes.c_void_p * self.num_levels)(*[v.data_ptr() for v in vols])
         if self.layout == "sheared":
+            assert (ht, wd) == (self.h1, self.w1), "coords / volume map size mismatch"
             _lib.check(lib.dba_corr_lookup_pyramid_sheared(ptrs, _ptr(c), _ptr(out), n, ht, wd, self.h2, self.w2,
                                                            self.num_levels, self.radius, _stream()),
                        "dba_corr_lookup_pyramid_sheared")
@@ -141,7 +147,8 @@ class CorrBlock:
     def sheared_level(self, lvl):
         """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1] (a view without the plane padding)"""
         assert self.layout == "sheared"
-        return self.corr_pyramid[lvl]
+        v = self.corr_pyramid[lvl]
+        return v[..., :self.h1 * self.w1].unflatten(-1, (self.h1, self.w1))
 
     def cat(self, other):
         for i in range(self.num_levels):

@@ -155,15 +155,21 @@ int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device
                             const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
                             int w2, int num_levels, int radius, int dtype, dba_stream_t stream);
 
-/* Flow-aligned ("sheared") volume: Vs_l[n][dy][dx][y1][x1] = V_l[n][y1][x1][ty][tx] with
- * dy = (ty - (y1 >> l)) mod h2l, dx = (tx - (x1 >> l)) mod w2l -- same size as the reference tensor of
- * dbaf/modules/corr.py:31-36, but the taps that neighbouring source pixels read become contiguous, so a
- * wave fetches full 128-byte lines (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup
- * result is bit-identical to corr_index_forward on the reference layout.  f16 only, radius 3. */
+/* Flow-aligned ("sheared") volume: Vs_l[n][dy][dx][pixel] = V_l[n][y1][x1][ty][tx] with pixel = y1 * w1 + x1,
+ * dy = (ty - (y1 >> l)) mod h2l, dx = (tx - (x1 >> l)) mod w2l; the pixel axis is padded to
+ * dba_corr_sheared_plane_elems(h1, w1) = h1 * w1 rounded up to a multiple of 64 (padding is never read for a real
+ * pixel) -- the size of the reference tensor of dbaf/modules/corr.py:31-36 (+ padding), but the taps that
+ * neighbouring source pixels read become contiguous, so a wave fetches full, aligned 128-byte lines for ANY map
+ * size (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup result is bit-identical to
+ * corr_index_forward on the reference layout.  f16 only, radius 3. */
+int dba_corr_sheared_plane_elems(int h1, int w1);
+/* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 1 = streaming
+ * (64-pixel-wide rows only, falls back to resident otherwise), 2 = resident.  Process-wide; results are bit-identical. */
+int dba_corr_lookup_select(int kernel);
 /* Fused build of the sheared pyramid straight from the feature maps (csrc/corr_build_fused.hip): MFMA GEMM,
  * 2x2 pooling of the rounded levels and the flow-aligned store in one pass; every output byte is written once.
  * Supported when dba_corr_volume_build_sheared_supported(...) returns 1 (h1 == h2, w1 == w2 == 64, h2 % 8 == 0,
- * C % 16 == 0, 4 levels); sheared_levels[l] is [n, h2>>l, w2>>l, h1, w1] f16.  scratch as for
+ * C % 16 == 0, 4 levels); sheared_levels[l] is [n, h2>>l, w2>>l, h1 * w1] f16 (no padding: h1 * w1 is a multiple of 64).  scratch as for
  * dba_corr_volume_build. */
 int dba_corr_volume_build_sheared_supported(int C, int h1, int w1, int h2, int w2, int num_levels);
 int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *const *sheared_levels, int n, int C,

@@ -29,3 +29,13 @@ def pytest_sessionstart(session):
         rep = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
         if os.path.exists(rep):
             os.remove(rep)
+
+
+@pytest.fixture(params=["auto", "stream", "resident"])
+def lookup_kernel(request):
+    """runs a test under each form of the sheared lookup kernel (csrc/corr_sheared.hip); results must not differ"""
+    from dbaf_amd import _lib
+    lib = _lib.load()
+    assert lib.dba_corr_lookup_select({"auto": 0, "stream": 1, "resident": 2}[request.param]) == 0
+    yield request.param
+    lib.dba_corr_lookup_select(0)

@@ -34,7 +34,17 @@ WINDOWS = {
     "25kf_96edges_64x64": lambda: syn.window_25_96(0),
     "kitti360_32kf_122edges_28x107": lambda: syn.window_32_122(0),
     "64kf_512edges_64x64": lambda: syn.window_64_512(0),  # n = 378: solver runs from the global scratch
+    # BASELINE configs[0]: TUM-VI corridor at the demo's resolution (55x55 maps), max_factors = 36
+    "tumvi_corridor_9kf_36edges_55x55": lambda: syn.make_window(*syn.graph_banded(9, 2, extra=[(0, 3), (1, 4), (2, 5)]),
+                                                                 9, 55, 55, seed=14, intr=(20.5, 20.5, 27.4, 27.6)),
+    # BASELINE configs[4] map shape (WHU, 48x64) with depth measurements on a quarter of the pixels
+    "whu_10kf_48x64_sensor_depth": lambda: syn.make_window(*syn.graph_banded(10, 3), 10, 48, 64, seed=15,
+                                                           intr=(30.0, 30.0, 31.5, 23.7), sensor_frac=0.25),
 }
+
+
+STRICT = ("25kf_96edges_64x64", "kitti360_32kf_122edges_28x107", "64kf_512edges_64x64", "tumvi_corridor_9kf_36edges_55x55",
+          "whu_10kf_48x64_sensor_depth")
 
 
 @pytest.mark.parametrize("name", list(WINDOWS))
@@ -49,8 +59,15 @@ def test_ba_matches_oracle(name):
     assert dz.shape == r32["dz"].shape
     # a14: DepthVideo.ba clamps all disps after the call (depth_video.py:560)
     clamp = lambda a: np.maximum(a, 0.001)  # noqa: E731
-    print(name, "vs fp64 arbiter:", check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
-                                                ref32_disps=clamp(r32["disps"])))
+    if name in STRICT:
+        # the windows of BASELINE.json's configs: north_star as written -- EVERY pixel within 1e-4 of the arbiter,
+        # relative to |d_ref| itself wherever the update does not cancel the depth, no allowance for the reference's
+        # own fp32 deviation (measured worst cases: profiles/r02_parity_report.jsonl, 1.1e-5 .. 4.5e-5)
+        msg = check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps, ref32_disps=None, frac=1.0)
+    else:
+        msg = check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
+                          ref32_disps=clamp(r32["disps"]))
+    print(name, "vs fp64 arbiter:", msg)
     np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
 
 

@@ -68,8 +68,11 @@ def _smooth_coords(rng, n, h, w):
 
 
 @pytest.mark.parametrize("layout", ["reference", "sheared"])
-@pytest.mark.parametrize("shape", [(3, 32, 16, 24), (2, 16, 24, 64), (1, 16, 16, 136), (2, 16, 20, 44)])
-def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape):
+@pytest.mark.parametrize("shape", [(3, 32, 16, 24), (2, 16, 24, 64), (1, 16, 16, 136), (2, 16, 20, 44), (2, 16, 17, 23),
+                                   (1, 16, 18, 71)])
+def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape, lookup_kernel):
+    if layout == "reference" and lookup_kernel != "auto":
+        pytest.skip("the kernel selection only concerns the sheared layout")
     """fused CorrBlock.__call__ == 4x corr_index_forward(coords / 2^l) + cat (corr.py:40-50), for both
     internal volume layouts, on random and on coherent coordinates"""
     from dbaf_amd.corr import CorrBlock
@@ -90,7 +93,9 @@ def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape):
 
 
 @pytest.mark.parametrize("layout", ["reference", "sheared"])
-def test_lookup_non_finite_coords_do_not_fault(layout):
+def test_lookup_non_finite_coords_do_not_fault(layout, lookup_kernel):
+    if layout == "reference" and lookup_kernel != "auto":
+        pytest.skip("the kernel selection only concerns the sheared layout")
     """NaN / inf / 1e30 coordinates (undefined behaviour in the reference's float->int cast) read nothing:
     the HIP path treats them as entirely out of bounds and must neither fault nor disturb other pixels."""
     from dbaf_amd.corr import CorrBlock
@@ -126,7 +131,7 @@ def test_fused_sheared_build_equals_unfused_pipeline(shape):
     unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
     for lvl in range(4):
         a, b = fused[lvl].cpu().numpy(), unfused[lvl].cpu().numpy()
-        assert a.shape == b.shape
+        assert a.shape == b.shape   # [n, h2l, w2l, h*w]: 64-wide maps need no plane padding
         assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (lvl, (a != b).mean())
 
 
@@ -140,6 +145,8 @@ def test_sheared_volume_is_a_permutation_of_the_reference_volume():
     shr = CorrBlock.shear_pyramid(ref)
     for lvl, (v, vs) in enumerate(zip(ref, shr)):
         v, vs = v.cpu().numpy(), vs.cpu().numpy()
+        assert vs.shape[-1] == 384 and vs.shape[-1] % 64 == 0   # 16 x 24 pixels: already a multiple of 64
+        vs = vs.reshape(vs.shape[:3] + (h, w))
         hl, wl = v.shape[3], v.shape[4]
         y1, x1, ty, tx = np.meshgrid(np.arange(h), np.arange(w), np.arange(hl), np.arange(wl), indexing="ij")
         dy, dx = (ty - (y1 >> lvl)) % hl, (tx - (x1 >> lvl)) % wl
@@ -236,7 +243,7 @@ def test_altcorr_backward_matches_oracle():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,h", [(1, 8), (1, 24), (3, 8), (5, 24), (7, 40), (11, 8)])
-def test_sheared_lookup_with_workgroup_counts_that_are_not_multiples_of_8(n, h):
+def test_sheared_lookup_with_workgroup_counts_that_are_not_multiples_of_8(n, h, lookup_kernel):
     """the lookup re-maps workgroups to XCDs (csrc/corr_sheared.hip): every row must still be covered exactly once
     for any grid size"""
     from dbaf_amd.corr import CorrBlock

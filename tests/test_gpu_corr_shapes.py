@@ -89,7 +89,7 @@ def test_volume_pyramid_at_config_shape(name):
 
 
 @pytest.mark.parametrize("name", list(SHAPES))
-def test_lookups_at_config_shape(name):
+def test_lookups_at_config_shape(name, lookup_kernel):
     import droid_backends
     from dbaf_amd.corr import CorrBlock
     orc = _oracle()
