@@ -8,10 +8,13 @@
 // on v_mfma_f32_32x32x16_f16; it is still write-bound (46.7 MB/edge, 92 FLOP/B), which is why the
 // store path matters more than the MFMA schedule.
 //
-// Stage A: re-lay both feature maps pixel-major [HW][C] (K contiguous) and apply the /4 in half.
+// Stage A: re-lay both feature maps k-block-major [C/16][HW][16] and apply the /4 in half: the fragment of one
+//          16-deep MFMA k-step for 32 consecutive pixels is then 1 KB contiguous, so a wave's 16-byte-per-lane
+//          fragment load touches 8 full cache lines (pixel-major [HW][C] touched 32 lines for 32 B each, and the
+//          vector L1 handles one line per cycle: fragment loads were a third of the fused kernel's time).
 // Stage B: 128x128 output tile per workgroup, four waves of 64x64 (2x2 MFMA tiles), the whole K in
 //          registers' reach (C = 128 -> 8 MFMA k-steps); fragments are 16-byte loads straight from the
-//          pixel-major maps (L2-resident: 1 MB per map).
+//          re-laid maps (L2-resident: 1 MB per map).
 // Stage C: pyramid levels by 2x2 averaging in fp32 of the rounded halves (== ATen's half avg_pool2d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,7 +26,7 @@ namespace dba {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-// [n][C][HW] -> [n][HW][C], value / 4 rounded to half (corr.py:67-68)
+// [n][C][HW] -> [n][C/16][HW][16], value / 4 rounded to half (corr.py:67-68); C is a multiple of 16
 __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
                                                                _Float16 *__restrict__ out, int C, int HW) {
   __shared__ _Float16 tile[64][66];
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *_
   __syncthreads();
   for (int r = threadIdx.x >> 6; r < 64; r += 4) {  // r: pixel within tile, lane: channel
     const int p = p0 + r, c = c0 + (threadIdx.x & 63);
-    if (p < HW && c < C) dst[(size_t)p * C + c] = tile[threadIdx.x & 63][r];
+    if (p < HW && c < C) dst[((size_t)(c >> 4) * HW + p) * 16 + (c & 15)] = tile[threadIdx.x & 63][r];
   }
 }
 
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void corr_gemm_kernel(const _Float16 *__restri
     half8 a[2], b[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      a[t] = *reinterpret_cast<const half8 *>(Ae + (size_t)ar[t] * C + k + kh);
-      b[t] = *reinterpret_cast<const half8 *>(Be + (size_t)br[t] * C + k + kh);
+      a[t] = *reinterpret_cast<const half8 *>(Ae + ((size_t)(k >> 4) * HW1 + ar[t]) * 16 + kh);
+      b[t] = *reinterpret_cast<const half8 *>(Be + ((size_t)(k >> 4) * HW2 + br[t]) * 16 + kh);
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)

@@ -1,200 +1,328 @@
-// Fused all-pairs correlation + 4-level pyramid + flow-aligned ("sheared") store, gfx950 MFMA.
+// Fused all-pairs correlation + 4-level pyramid + flow-aligned ("sheared") store, gfx950 MFMA, any map size.
 //
 // One pass replaces CorrBlock.corr (torch.matmul), the three avg_pool2d passes of CorrBlock.__init__
 // (/root/reference/dbaf/modules/corr.py:24-38, :63-71) and the re-layout into the sheared volume
-// (corr_sheared.hip): the reference materialises level 0 (33.5 MB/edge), reads it back three times for the
+// (corr_sheared.hip): the reference materialises level 0 (33.5 MB/edge at 64x64), reads it back three times for the
 // pooling, and this repo's unfused path then reads and rewrites every level once more for the shear.
 // Here every output byte is written exactly once (44.6 MB/edge) and the inputs (2 x 1 MB/edge) stay in L2.
 //
-// Workgroup = 8 waves; tile = 64 source pixels (one source row segment x1 = 0..63 of row y1) x 512 targets
-// (8 target rows ty0..ty0+7 x w2 = 64 columns), full K = C in registers' reach:
-//   * wave w owns target row ty0 + w: 64 x 64 outputs = 2 x 2 v_mfma_f32_32x32x16_f16 tiles, 16-byte
-//     fragment loads straight from the pixel-major feature maps;
-//   * accumulators -> f16 (the single rounding of the reference's half GEMM) -> LDS tile T[x1][ty][tx];
-//   * level 0: each wave re-reads its own row along diagonals and writes 128-byte segments of the sheared
-//     volume Vs0[dy][dx][y1][x1]; levels 1..3: 2x2 averages of the ROUNDED level below (== F.avg_pool2d on
-//     half), kept unsheared in LDS for the next level and written sheared.
-// Shapes: h1 == h2, w1 == w2 == 64, h2 % 8 == 0, C % 16 == 0, 4 levels (64x64 is the 512x512 benchmark shape);
-// anything else takes the unfused path of corr_build.hip + corr_shear_kernel.
+// Workgroup = 8 waves; tile = one STRIP of 64 consecutive source pixels of the flattened (y1, x1) index (the unit the
+// lookup reads, see corr_sheared.hip) x 8 target rows ty0..ty0+7 x all w2 target columns (w2 <= 128):
+//   * wave w owns target row ty0 + w: 64 sources x (32 NT) targets = 2 x NT v_mfma_f32_32x32x16_f16 tiles computed as
+//     targets x sources, so that a register quad is four consecutive targets of one source (one 8-byte LDS write);
+//     16-byte fragment loads straight from the k-block-major feature maps [C/16][HW][16] (corr_build.hip; L2-resident,
+//     8 full lines per load instruction), the next k-step's fragments are requested before the current one is
+//     multiplied;
+//   * accumulators -> f16 (the single rounding of the reference's half GEMM) -> LDS tile T[source][ty][tx];
+//   * stores: every element goes from the tile to Vs_l[(ty_l - (y1 >> l)) mod h2l][dx][pixel] with PER-PIXEL offsets, so
+//     any map width works (a strip may span a row end).  Levels 0 and 1 (94 % of the bytes): a lane owns four
+//     consecutive pixels of one of four (dy, dx) lines and stores 8 bytes (four 2-byte stores for a quad that spans a row
+//     end); levels 2, 3: a lane is one pixel.  The barriers synchronise LDS only (`s_waitcnt lgkmcnt(0); s_barrier`): a
+//     `__syncthreads()` would drain every outstanding store first;
+//   * levels 1..3: 2x2 averages of the ROUNDED level below (== F.avg_pool2d on half, floor sizes), each element pooled
+//     straight from the level-0 tile by the lane that stores it (the rounded intermediate levels are recomputed in
+//     registers), so the tile is the only LDS buffer and there is no barrier after it is complete;
+//   * the strip's source operand (16 KB at C = 128) is staged ONCE per workgroup in the LDS the tile will take, and the
+//     target fragments are requested two k-steps ahead.
+// Where the time goes (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges, per workgroup of 42.7 k cycles): source operand
+// 4.6 k, MFMA phase 15.4 k (of which the target-fragment loads 12.7 k: 16 KB per wave out of L2 at ~20 B/clk/CU; the 32
+// MFMAs per wave alone 6.6 k), tile write 2.3 k, level-0 stores 8.3-9.7 k, pooled levels 8.8-9.7 k (the CU's store path
+// takes ~10 B/clk whatever the store width).  All of these share the CU's vector memory pipe, so they add up: 24 us per
+// edge = 1.9 TB/s of output, 0.24 of the HBM peak.  Running the two co-resident workgroups out of phase (staggered
+// start) changes nothing; halving the fragment traffic needs a 128-pixel tile (132 KB of LDS, one workgroup per CU).
+// Shapes: w2 <= 128, C % 16 == 0, 4 levels, h2 >> 3 >= 1, w2 >> 3 >= 1; anything else takes the unfused path of
+// corr_build.hip + corr_shear_kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
 namespace dba {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 struct FusedLevels {
   _Float16 *vs[4];
 };
 
-struct __attribute__((aligned(16))) H8 {
-  _Float16 v[8];
-};
-
-constexpr int FW = 64;         // w1 == w2
-constexpr int FT_ROWS = 8;     // target rows per tile
-constexpr int T_PITCH = FT_ROWS * FW + 4;  // halves per source pixel in the LDS tile (+4: the 32 lanes of an 8-byte
-                                           // accumulator write land in 32 different bank pairs)
+constexpr int FT_ROWS = 8;  // target rows per tile
 
 __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
   // ATen avg_pool2d on half: float accumulate, one rounding
   return (_Float16)(((float)a + (float)b + (float)c + (float)d) / 4.0f);
 }
 
-__global__ __launch_bounds__(512, 4) void corr_build_fused_kernel(const _Float16 *__restrict__ A,
-                                                               const _Float16 *__restrict__ Bm, FusedLevels L,
-                                                               int C, int h) {
+// workgroup barrier that orders LDS traffic only (global stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT>
+__global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kernel(
+    const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm, FusedLevels L, int C, int h1, int w1, int h2, int w2,
+    int HW1p, float inv_w1
+#ifdef FB_PROF
+    , unsigned long long *prof
+#endif
+) {
+#ifdef FB_PROF
+#define FB_STAMP(i) do { if ((threadIdx.x & 63) == 0) prof[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FB_STAMP(i) (void)0
+#endif
+  FB_STAMP(0);
+  constexpr int W2P = 32 * NT;               // tile columns (targets beyond w2 are computed and never read)
+  constexpr int PITCH = FT_ROWS * W2P + 4;   // halves per source pixel (+4: the 32 lanes of an 8-byte accumulator write
+                                             // land in 32 different bank pairs)
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-  // 66 KB per workgroup, two workgroups per CU: the pooled levels reuse the level-0 tile once it is dead
-  _Float16 *T = smem;                         // [64][T_PITCH]           level 0, rounded
-  _Float16 *P1 = T;                           // [64][4][32]             level 1, rounded, unsheared (after T)
-  _Float16 *P2 = P1 + 64 * 4 * 32;            // [64][2][16]
-  _Float16 *P3 = P2 + 64 * 2 * 16;            // [64][1][8]
+  _Float16 *T = smem;                              // [64][PITCH]  level 0, rounded; before that: the strip's A operand
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int y1 = blockIdx.x;                  // source row
-  const int ty0 = blockIdx.y * FT_ROWS;       // first target row of the tile
+  const int p0 = blockIdx.x * 64;                  // first source pixel of the strip
+  const int ty0 = blockIdx.y * FT_ROWS;            // first target row of the tile
   const int e = blockIdx.z;
-  const int HW = h * FW;
-  const _Float16 *Ae = A + ((size_t)e * HW + (size_t)y1 * FW) * C;            // 64 source pixels
-  const _Float16 *Be = Bm + ((size_t)e * HW + (size_t)(ty0 + wave) * FW) * C; // this wave's 64 targets
+  const int HW1 = h1 * w1, HW2 = h2 * w2;
   const int l31 = lane & 31, kh = (lane >> 5) * 8;
 
-  // ---- MFMA: acc[i][j] = 32x32 tile (sources 32 i .. , targets 32 j ..) ---------------------------------
-  float16v acc[2][2];
+  // ---- the strip's source operand, shared by the 8 waves: [C/16][64 pixels][16] halves into the (still unused) tile ----
+  // (k-block-major like the global map, so a k-step's fragment is 32 lanes x 32 B contiguous: conflict-free b128 reads)
+#ifndef FB_ABLATE_MFMA
+  {
+    const _Float16 *Ae = A + (size_t)e * HW1 * C;
+    const int kblocks = C >> 4;
+    for (int idx = tid; idx < kblocks * 128; idx += 512) {  // 16-byte pieces: [kblock][pixel][half of the 16 channels]
+      const int kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
+      const half8 v = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(p0 + px, HW1 - 1)) * 16 + hf * 8);
+      *reinterpret_cast<half8 *>(T + (kbk * 64 + px) * 16 + hf * 8) = v;
+    }
+  }
+#endif
+  __syncthreads();
+  FB_STAMP(1);
+
+  // ---- MFMA: acc[i][j] = 32x32 tile (sources 32 i .. , targets 32 j ..) of target row ty0 + wave ------------------
+  float16v acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  for (int k = 0; k < C; k += 16) {
-    half8 a[2], b[2];
+  {
+    const int ty = min(ty0 + wave, h2 - 1);  // rows past the map are computed on a valid row and never stored
+    const _Float16 *bp[NT];  // k-block-major map: element (k, pixel) at ((k >> 4) * HW + pixel) * 16 + (k & 15)
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      a[t] = *reinterpret_cast<const half8 *>(Ae + (size_t)(t * 32 + l31) * C + k + kh);
-      b[t] = *reinterpret_cast<const half8 *>(Be + (size_t)(t * 32 + l31) * C + k + kh);
+    for (int t = 0; t < NT; t++) bp[t] = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + t * 32 + l31, HW2 - 1) * 16 + kh;
+    const size_t kb = (size_t)HW2;  // elements between consecutive k-blocks / 16
+    // target fragments two k-steps ahead of their use (L2 latency), source fragments from LDS right before it
+    half8 b0[NT], b1[NT], b2[NT];
+    const int ksteps = C >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      b0[t] = *reinterpret_cast<const half8 *>(bp[t]);
+      b1[t] = *reinterpret_cast<const half8 *>(bp[t] + (size_t)min(1, ksteps - 1) * 16 * kb);
     }
+#ifdef FB_ABLATE_MFMA  // scratch builds only
+    for (int ks = 0; ks < 0; ks++) {
+#else
+    for (int ks = 0; ks < ksteps; ks++) {
+#endif
+      const int kn = min(ks + 2, ksteps - 1);  // (the last steps re-request a fragment: no branch in the loop)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+      for (int t = 0; t < NT; t++) b2[t] = *reinterpret_cast<const half8 *>(bp[t] + (size_t)kn * 16 * kb);
+      half8 a[2];
 #pragma unroll
-      for (int j = 0; j < 2; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);  // targets x sources
+      for (int t = 0; t < 2; t++) a[t] = *reinterpret_cast<const half8 *>(T + (ks * 64 + t * 32 + l31) * 16 + kh);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0[j], a[i], acc[i][j], 0, 0, 0);  // targets x sources
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        b0[t] = b1[t];
+        b1[t] = b2[t];
+      }
+    }
   }
-  // D layout: col = lane & 31 (source x1 within the 32-block), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (target tx):
+  FB_STAMP(2);
+  lds_barrier();  // every wave is done with the source operand: the tile takes its place
+  // D layout: col = lane & 31 (source within the 32-block), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (target tx):
   // four consecutive targets of one source per register quad -> one 8-byte LDS write
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) {
-        const int x1 = i * 32 + l31;
+        const int src = i * 32 + l31;
         const int tx = j * 32 + 8 * rq + 4 * (lane >> 5);
-        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
         half4 v;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[i][j][4 * rq + e];
-        *reinterpret_cast<half4 *>(T + x1 * T_PITCH + wave * FW + tx) = v;
+        for (int q = 0; q < 4; q++) v[q] = (_Float16)acc[i][j][4 * rq + q];
+        *reinterpret_cast<half4 *>(T + src * PITCH + wave * W2P + tx) = v;
       }
-  __syncthreads();
+  lds_barrier();  // the last barrier: everything below reads the tile only
+  FB_STAMP(3);
 
-  const size_t eoff = (size_t)e;  // level l volume of edge e: [h>>l][64>>l][HW]
-  const int dl = lane >> 3, sub = lane & 7;  // 8 lanes x 16 B = one 128-byte segment of 64 x1
-  // ---- level 0 (this wave's own target row): Vs0[dy][dx][y1][x1] = T[x1][ty][(x1 + dx) & 63] -----------------
+  // ---- this lane's source pixel (levels 2, 3: a lane is one pixel) and its QUAD of pixels (levels 0, 1) ------------------
+  const int p = p0 + lane;
+  const bool active = p < HW1;
+  int x1, y1;
+  auto pixel_xy = [&](int pix, int &x, int &y) {
+    const int pc = min(pix, HW1 - 1);
+    y = (int)(((float)pc + 0.5f) * inv_w1);
+    x = pc - y * w1;
+    if (x < 0) { y--; x += w1; }
+    if (x >= w1) { y++; x -= w1; }
+  };
+  pixel_xy(p, x1, y1);
+  constexpr unsigned OOR = 0x80000000u;
+  // level l volume of edge e: [h2l][w2l][HW1p] halves, addressed through a buffer resource (an edge-level is < 2 GB)
+  auto level_rsrc = [&](int lvl) {
+    const size_t elems = (size_t)(h2 >> lvl) * (w2 >> lvl) * HW1p;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)e * elems), 0, (int)(2 * elems), 0x00020000);
+  };
+  const unsigned plane_bytes = 2u * (unsigned)HW1p;
+  const _Float16 *mine = T + lane * PITCH;  // this pixel's [8][W2P] targets
+
+  // Levels 0 and 1 carry 94 % of the bytes.  A 2-byte-per-lane store instruction costs the vector memory pipe as much as
+  // an 8-byte one (~13 cycles per wave instruction: 10 B/clk/CU, which capped the store phases), so there a lane owns
+  // FOUR consecutive pixels (q = lane & 15) of one of four lines (g = lane >> 4) and stores 8 bytes: one instruction is
+  // four full 128-byte lines.  A quad whose pixels do not share a source row (a strip that spans a row end, or the last
+  // pixels of the map) falls back to four 2-byte stores.
+  const int q4 = (lane & 15) * 4, g = lane >> 4;
+  int qx[4], qy[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) pixel_xy(p0 + q4 + i, qx[i], qy[i]);
+  const bool quad_regular = (p0 + q4 + 3 < HW1) && (qy[0] == qy[3]);
+  const _Float16 *quad = T + q4 * PITCH;
+  auto store_quad = [&](const __amdgpu_buffer_rsrc_t &rl, int lvl, int tyg, int dx, int h2l, int w2l, _Float16 v0, _Float16 v1,
+                        _Float16 v2, _Float16 v3, bool on) {
+    const _Float16 vv[4] = {v0, v1, v2, v3};
+    if (quad_regular) {
+      int dy = tyg - (qy[0] >> lvl);
+      dy += (dy < 0) ? h2l : 0;
+      const unsigned voff = on ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + q4) : OOR;
+      typedef unsigned u2v __attribute__((ext_vector_type(2)));
+      u2v d;
+      d.x = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
+      d.y = (unsigned)__builtin_bit_cast(unsigned short, v2) | ((unsigned)__builtin_bit_cast(unsigned short, v3) << 16);
+      __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int dy = tyg - (qy[i] >> lvl);
+        dy += (dy < 0) ? h2l : 0;
+        const bool ok = on && (p0 + q4 + i < HW1);
+        const unsigned voff = ok ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + q4 + i) : OOR;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vv[i]), rl, voff, 0, 0);
+      }
+    }
+  };
+
+  // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's own target row ----
   {
     const int ty = ty0 + wave;
-    int dy = ty - y1;
-    dy += (dy < 0) ? h : 0;
-    _Float16 *dst = L.vs[0] + (eoff * h + dy) * (size_t)FW * HW + (size_t)y1 * FW + sub * 8;
-#pragma unroll 2
-    for (int it = 0; it < 8; it++) {
-      const int dx = it * 8 + dl;
-      H8 v;
+#ifdef FB_ABLATE_L0STORE
+    if (ty < 0) {
+#else
+    if (ty < h2) {  // (wave-uniform)
+#endif
+      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+      const _Float16 *row = quad + wave * W2P;
+      for (int dx0 = 0; dx0 < w2; dx0 += 4) {
+        const int dx = dx0 + g;
+        _Float16 v[4];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int x1 = sub * 8 + q;
-        v.v[q] = T[x1 * T_PITCH + wave * FW + ((x1 + dx) & 63)];
+        for (int i = 0; i < 4; i++) {
+          int tx = qx[i] + dx;
+          tx -= (tx >= w2) ? w2 : 0;
+          tx = min(tx, w2 - 1);  // (dx beyond the map in the last group of four: read something valid, store nothing)
+          v[i] = row[i * PITCH + tx];
+        }
+        store_quad(r0, 0, ty, dx, h2, w2, v[0], v[1], v[2], v[3], dx < w2);
       }
-      *reinterpret_cast<H8 *>(dst + (size_t)dx * HW) = v;
     }
   }
-  // ---- level 1, unsheared: P1[x1][ty1][tx1], through registers because it takes the tile's place --------------
-  {
-    _Float16 p1v[16];
+  FB_STAMP(4);
+#ifndef FB_ABLATE_POOLSTORE
+  // ---- levels 1..3: every element is pooled straight from the level-0 tile by the lane that stores it (the rounded
+  // intermediate levels are recomputed in registers: 4, 16, 64 tile reads per element, as 4-byte LDS reads), so no
+  // further barrier and no staging of the pooled levels is needed; (ty_l, dx) segments are dealt to the waves ----
+  {  // level 1: 4 rows x (w2 >> 1) offsets, four lines per store instruction
+    const int w2l = w2 >> 1, h2l = h2 >> 1;
+    const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
+    const int groups = (w2l + 3) >> 2;  // groups of four dx per row
+    for (int sg = wave; sg < 4 * groups; sg += 8) {
+      const int tyl = sg / groups, dx = (sg - tyl * groups) * 4 + g;
+      const int tyg = (ty0 >> 1) + tyl;
+      if (tyg >= h2l) continue;  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
+      _Float16 v[4];
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int idx = tid + 512 * u;
-      const int tx1 = idx & 31, ty1 = (idx >> 5) & 3, x1 = idx >> 7;
-      const _Float16 *s = T + x1 * T_PITCH + (2 * ty1) * FW + 2 * tx1;
-      p1v[u] = pool4(s[0], s[1], s[FW], s[FW + 1]);
-    }
-    __syncthreads();  // every read of the level-0 tile is done (its sheared store above included)
-#pragma unroll
-    for (int u = 0; u < 16; u++) P1[tid + 512 * u] = p1v[u];
-  }
-  __syncthreads();
-  // level 2 and the sheared store of level 1 only read P1
-  for (int idx = tid; idx < 64 * 2 * 16; idx += 512) {
-    const int tx2 = idx & 15, ty2 = (idx >> 4) & 1, x1 = idx >> 5;
-    const _Float16 *s = P1 + (x1 * 4 + 2 * ty2) * 32 + 2 * tx2;
-    P2[idx] = pool4(s[0], s[1], s[32], s[33]);
-  }
-  {
-    // Vs1[dy][dx][y1][x1], dy = (ty1g - (y1 >> 1)) mod h/2, dx = (tx1 - (x1 >> 1)) mod 32: 4 x 32 segments
-    const int h1l = h >> 1;
-    for (int seg = wave * 8 + dl; seg < 4 * 32; seg += 64) {
-      const int ty1 = seg >> 5, dx = seg & 31;
-      int dy = (ty0 >> 1) + ty1 - (y1 >> 1);
-      dy += (dy < 0) ? h1l : 0;
-      H8 v;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int x1 = sub * 8 + q;
-        v.v[q] = P1[(x1 * 4 + ty1) * 32 + (((x1 >> 1) + dx) & 31)];
+      for (int i = 0; i < 4; i++) {
+        int tx = (qx[i] >> 1) + dx;
+        tx -= (tx >= w2l) ? w2l : 0;
+        tx = min(tx, w2l - 1);
+        const _Float16 *s = quad + i * PITCH + (2 * tyl) * W2P + 2 * tx;
+        const half2v r0v = *reinterpret_cast<const half2v *>(s), r1v = *reinterpret_cast<const half2v *>(s + W2P);
+        v[i] = pool4(r0v.x, r0v.y, r1v.x, r1v.y);
       }
-      *reinterpret_cast<H8 *>(L.vs[1] + ((eoff * h1l + dy) * 32 + dx) * (size_t)HW + (size_t)y1 * FW + sub * 8) = v;
+      store_quad(rl, 1, tyg, dx, h2l, w2l, v[0], v[1], v[2], v[3], dx < w2l);
     }
   }
-  __syncthreads();
-  if (tid < 64 * 8) {  // level 3 from P2: [64][1][8]
-    const int tx3 = tid & 7, x1 = tid >> 3;
-    const _Float16 *s = P2 + (x1 * 2) * 16 + 2 * tx3;
-    P3[tid] = pool4(s[0], s[1], s[16], s[17]);
-  }
-  {
-    const int h2l = h >> 2;
-    for (int seg = wave * 8 + dl; seg < 2 * 16; seg += 64) {
-      const int ty2 = seg >> 4, dx = seg & 15;
-      int dy = (ty0 >> 2) + ty2 - (y1 >> 2);
+  auto pooled1 = [&](int ty1, int tx1) {  // rounded level-1 value of this pixel
+    const _Float16 *s = mine + (2 * ty1) * W2P + 2 * tx1;
+    const half2v r0v = *reinterpret_cast<const half2v *>(s), r1v = *reinterpret_cast<const half2v *>(s + W2P);
+    return pool4(r0v.x, r0v.y, r1v.x, r1v.y);
+  };
+  auto pooled2 = [&](int ty2, int tx2) {  // rounded level-2 value: 2x2 of rounded level-1 values
+    return pool4(pooled1(2 * ty2, 2 * tx2), pooled1(2 * ty2, 2 * tx2 + 1), pooled1(2 * ty2 + 1, 2 * tx2),
+                 pooled1(2 * ty2 + 1, 2 * tx2 + 1));
+  };
+  {  // level 2: 2 rows x (w2 >> 2) offsets
+    const int w2l = w2 >> 2, h2l = h2 >> 2;
+    const __amdgpu_buffer_rsrc_t rl = level_rsrc(2);
+    const int x1l = x1 >> 2, y1l = y1 >> 2;
+    for (int seg = wave; seg < 2 * w2l; seg += 8) {
+      const int tyl = seg / w2l, dx = seg - tyl * w2l;
+      const int tyg = (ty0 >> 2) + tyl;
+      if (tyg >= h2l) continue;
+      int dy = tyg - y1l;
       dy += (dy < 0) ? h2l : 0;
-      H8 v;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int x1 = sub * 8 + q;
-        v.v[q] = P2[(x1 * 2 + ty2) * 16 + (((x1 >> 2) + dx) & 15)];
-      }
-      *reinterpret_cast<H8 *>(L.vs[2] + ((eoff * h2l + dy) * 16 + dx) * (size_t)HW + (size_t)y1 * FW + sub * 8) = v;
+      int tx = x1l + dx;
+      tx -= (tx >= w2l) ? w2l : 0;
+      const _Float16 v = pooled2(tyl, tx);
+      const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, 0);
     }
   }
-  __syncthreads();
-  {
-    const int h3l = h >> 3;
-    for (int seg = wave * 8 + dl; seg < 8; seg += 64) {
-      const int dx = seg;
-      int dy = (ty0 >> 3) - (y1 >> 3);
-      dy += (dy < 0) ? h3l : 0;
-      H8 v;
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int x1 = sub * 8 + q;
-        v.v[q] = P3[x1 * 8 + (((x1 >> 3) + dx) & 7)];
+  {  // level 3: 1 row x (w2 >> 3) offsets
+    const int w2l = w2 >> 3, h2l = h2 >> 3;
+    const __amdgpu_buffer_rsrc_t rl = level_rsrc(3);
+    const int x1l = x1 >> 3, y1l = y1 >> 3;
+    const int tyg = ty0 >> 3;
+    if (tyg < h2l) {
+      for (int dx = wave; dx < w2l; dx += 8) {
+        int dy = tyg - y1l;
+        dy += (dy < 0) ? h2l : 0;
+        int tx = x1l + dx;
+        tx -= (tx >= w2l) ? w2l : 0;
+        const _Float16 v = pool4(pooled2(0, 2 * tx), pooled2(0, 2 * tx + 1), pooled2(1, 2 * tx), pooled2(1, 2 * tx + 1));
+        const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, 0);
       }
-      *reinterpret_cast<H8 *>(L.vs[3] + ((eoff * h3l + dy) * 8 + dx) * (size_t)HW + (size_t)y1 * FW + sub * 8) = v;
     }
   }
+#endif
+  FB_STAMP(5);
+#ifdef FB_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FB_STAMP(6);
+#endif
 }
 
 // defined in corr_build.hip
@@ -207,7 +335,11 @@ using namespace dba;
 extern "C" {
 
 int dba_corr_volume_build_sheared_supported(int C, int h1, int w1, int h2, int w2, int num_levels) {
-  return (h1 == h2 && w1 == 64 && w2 == 64 && (h2 % 8) == 0 && (C % 16) == 0 && num_levels == 4) ? 1 : 0;
+  if (C <= 0 || (C % 16) != 0 || num_levels != 4 || h1 <= 0 || w1 <= 0) return 0;
+  if (w2 > 128 || (h2 >> 3) < 1 || (w2 >> 3) < 1) return 0;
+  if (C > 512) return 0;  // the strip's source operand (64 x C halves) is staged inside the level-0 tile
+  const size_t elems0 = (size_t)h2 * w2 * (size_t)dba_corr_sheared_plane_elems(h1, w1);
+  return (2 * elems0 < ((size_t)1 << 31)) ? 1 : 0;  // one edge-level is addressed through a 31-bit buffer range
 }
 
 int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *const *sheared_levels, int n, int C,
@@ -218,25 +350,63 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
   if (n == 0) return DBA_OK;
   if (!fmap1 || !fmap2 || !sheared_levels || !scratch) return DBA_ERR_ARG;
   if (scratch_bytes < dba_corr_volume_scratch_bytes(n, C, h1, w1, h2, w2)) return DBA_ERR_WORKSPACE;
-  const int HW = h1 * w1;
+  const int HW1 = h1 * w1, HW2 = h2 * w2;
+  const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
   hipStream_t s = (hipStream_t)stream;
   _Float16 *A = static_cast<_Float16 *>(scratch);
-  _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW * 2, 256));
-  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW);
-  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW);
+  _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
+  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1);
+  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2);
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
-  const size_t lds = sizeof(_Float16) * ((size_t)64 * T_PITCH);  // the pooled levels live inside the dead tile
+  const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
-  hipLaunchKernelGGL(corr_build_fused_kernel, dim3(h1, h2 / FT_ROWS, n), dim3(512), lds, s, A, Bm, L, C, h1);
+  const float inv_w1 = 1.0f / (float)w1;
+#ifdef FB_PROF
+  static unsigned long long *prof = nullptr;
+  if (!prof) { (void)hipMalloc(&prof, (size_t)64 << 20); }
+  (void)hipMemsetAsync(prof, 0, (size_t)grid.x * grid.y * grid.z * 8 * 8 * 8, s);
+#define FB_PROF_ARG , prof
+#else
+#define FB_PROF_ARG
+#endif
+  if (w2 <= 64) {
+    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * 64 + 4);  // the pooled levels live inside the dead tile
+    hipLaunchKernelGGL((corr_build_fused_kernel<2>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
+  } else {
+    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * 128 + 4);
+    hipLaunchKernelGGL((corr_build_fused_kernel<4>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
+  }
   DBA_LAUNCH_CHECK();
+#ifdef FB_PROF
+  {  // scratch builds: dump the phase timestamps of this launch (cycles of the 100 MHz constant clock)
+    (void)hipStreamSynchronize(s);
+    const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
+    unsigned long long *hp = (unsigned long long *)malloc(nw * 64);
+    (void)hipMemcpy(hp, prof, nw * 64, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nw; i++) {
+      const unsigned long long *r = hp + i * 8;
+      if (r[0] < t0) t0 = r[0];
+      if (r[6] > t1) t1 = r[6];
+      for (int k = 1; k < 7; k++) ph[k] += (double)(r[k] - r[k - 1]);
+    }
+    fprintf(stderr, "FB_PROF n=%d waves=%zu span=%.2f us | per wave (us): stageA %.2f mfma %.2f wait+Twrite %.2f level0 %.2f pooled %.2f drain %.2f\n",
+            n, nw, (t1 - t0) * 0.01, ph[1] / nw * 0.01, ph[2] / nw * 0.01, ph[3] / nw * 0.01, ph[4] / nw * 0.01, ph[5] / nw * 0.01,
+            ph[6] / nw * 0.01);
+    free(hp);
+  }
+#endif
   return DBA_OK;
 }
 

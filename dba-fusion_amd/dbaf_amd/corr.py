@@ -77,7 +77,8 @@ class CorrBlock:
 
     @staticmethod
     def build_sheared_fused(fmap1, fmap2, num_levels=4):
-        """one-pass MFMA build of the sheared pyramid (64-wide maps); None if the shape is not supported"""
+        """one-pass MFMA build of the sheared pyramid (any map up to 128 pixels wide); None if the shape is not
+        supported (then: build_pyramid + shear_pyramid)"""
         batch, num, dim, h1, w1 = fmap1.shape
         _, _, _, h2, w2 = fmap2.shape
         lib = _lib.load()
@@ -86,8 +87,8 @@ class CorrBlock:
         n = batch * num
         f1 = fmap1.reshape(n, dim, h1, w1).to(torch.float16).contiguous()
         f2 = fmap2.reshape(n, dim, h2, w2).to(torch.float16).contiguous()
-        assert lib.dba_corr_sheared_plane_elems(h1, w1) == h1 * w1   # the fused build takes unpadded planes only
-        levels = [torch.empty(n, h2 >> l, w2 >> l, h1 * w1, dtype=torch.float16, device=f1.device)
+        hw1p = lib.dba_corr_sheared_plane_elems(int(h1), int(w1))
+        levels = [torch.empty(n, h2 >> l, w2 >> l, hw1p, dtype=torch.float16, device=f1.device)
                   for l in range(num_levels)]
         sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, h2, w2)
         scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)

@@ -168,8 +168,8 @@ int dba_corr_sheared_plane_elems(int h1, int w1);
 int dba_corr_lookup_select(int kernel);
 /* Fused build of the sheared pyramid straight from the feature maps (csrc/corr_build_fused.hip): MFMA GEMM,
  * 2x2 pooling of the rounded levels and the flow-aligned store in one pass; every output byte is written once.
- * Supported when dba_corr_volume_build_sheared_supported(...) returns 1 (h1 == h2, w1 == w2 == 64, h2 % 8 == 0,
- * C % 16 == 0, 4 levels); sheared_levels[l] is [n, h2>>l, w2>>l, h1 * w1] f16 (no padding: h1 * w1 is a multiple of 64).  scratch as for
+ * Supported when dba_corr_volume_build_sheared_supported(...) returns 1 (w2 <= 128, C % 16 == 0, 4 levels, every
+ * level non-empty); sheared_levels[l] is [n, h2>>l, w2>>l, dba_corr_sheared_plane_elems(h1, w1)] f16.  scratch as for
  * dba_corr_volume_build. */
 int dba_corr_volume_build_sheared_supported(int C, int h1, int w1, int h2, int w2, int num_levels);
 int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *const *sheared_levels, int n, int C,
