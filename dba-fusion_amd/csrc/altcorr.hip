@@ -1,76 +1,191 @@
 // On-the-fly windowed correlation (no materialised volume), gfx950.
 //
-// Replaces altcorr_forward_kernel (/root/reference/src/altcorr_kernel.cu:27-149, launcher :290-319),
-// the op behind AltCorrBlock (/root/reference/dbaf/modules/corr.py:91-139).  The reference runs 32-thread
-// blocks that rely on NVIDIA warp-synchronous execution (no barrier between the shared-memory dot
-// product and the next tap's overwrite); on wave64 hardware that assumption does not hold, so the
-// kernel is organised differently: one lane owns one (batch, pixel) and keeps all (2r+1)^2 outputs of
-// one coordinate set in registers; channels are walked in the reference's chunks of 32 and every
-// chunk's tap dot-products are scattered with the four bilinear weights before the next chunk, so the
-// fp32 accumulation order matches the reference's chunk/tap order.
+// Replaces altcorr_forward_kernel (/root/reference/src/altcorr_kernel.cu:27-149, launcher :290-319: float and half),
+// the op behind AltCorrBlock (/root/reference/dbaf/modules/corr.py:91-139).  The reference runs 32-thread blocks that
+// rely on NVIDIA warp-synchronous execution (no barrier between the shared-memory dot product and the next tap's
+// overwrite); on wave64 hardware that assumption does not hold, and its per-tap re-staging of 32 x 32 scalars is all
+// latency.  Here:
+//   * a wave owns a 4 x 16 tile of source pixels of one (batch, coordinate set); a lane is a pixel;
+//   * the tile's windows overlap (coherent flow), so the UNION of the 64 windows of fmap2 -- (16 + 2r + 1 + spread) x
+//     (4 + 2r + 1 + spread) target pixels -- is staged in LDS in 32-byte channel slices (8 floats / 16 halves) with
+//     coalesced 16-byte loads: a target pixel's slice is fetched once per tile instead of once per tap and lane;
+//     pixel pitch 48 B makes the lanes' 16-byte LDS reads conflict-free (neighbouring lanes read neighbouring pixels);
+//   * every lane then walks its (2r+2)^2 taps: two 16-byte LDS reads + one multiply-add per channel into the tap's
+//     running dot product; after each 32-channel chunk the dot products are scattered with the four bilinear weights
+//     into the lane's (2r+1)^2 outputs -- the reference's chunk / tap / nw-ne-sw-se order exactly
+//     (altcorr_kernel.cu:58-147), so the half instantiation (c10::Half: every product and sum rounded to half) is
+//     bit-identical to it and the float one differs only by the fused multiply-add nvcc emits for `s += a * b`
+//     (-fmad=true is its default; this file uses __builtin_fmaf there);
+//   * tiles whose union does not fit the staging area (incoherent coordinates) read fmap2 per lane instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "common.h"
 
-// bit-exact parity with the reference arithmetic: no mul+add fusion anywhere in this file
+// bit-exact parity with the reference arithmetic: no implicit mul+add fusion anywhere in this file
 #pragma clang fp contract(off)
 
 namespace dba {
 
-template <int R>
-__global__ __launch_bounds__(256) void altcorr_forward_kernel(const float *__restrict__ fmap1,
-                                                              const float *__restrict__ fmap2,
-                                                              const float *__restrict__ coords,
-                                                              float *__restrict__ corr, int B, int S, int H1,
-                                                              int W1, int H2, int W2, int C) {
-  constexpr int RD = 2 * R + 1;
-  const int HW1 = H1 * W1;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)B * S * HW1) return;
-  const int pix = (int)(gid % HW1);
-  const int s = (int)((gid / HW1) % S);
-  const int b = (int)(gid / ((long)HW1 * S));
+typedef unsigned u4v_alt __attribute__((ext_vector_type(4)));
 
-  const float *cp = coords + (((size_t)b * S + s) * HW1 + pix) * 2;
+constexpr int ALT_TH = 4, ALT_TW = 16;   // tile of source pixels per wave
+constexpr int ALT_UMAX = 448;            // union pixels that fit the staging area (21 KB per wave at 48 B per pixel)
+constexpr int ALT_PITCH = 48;            // bytes per staged pixel: 32 of data + 16 of padding (bank spread)
+
+template <typename T>
+struct AltT;
+template <>
+struct AltT<float> {
+  static constexpr int KS = 8;  // channels per 32-byte slice
+  static __device__ __forceinline__ float mad(float s, float a, float b) { return __builtin_fmaf(a, b, s); }
+  static __device__ __forceinline__ float mul(float a, float b) { return a * b; }
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+  static __device__ __forceinline__ float from_float(float x) { return x; }
+};
+template <>
+struct AltT<_Float16> {
+  static constexpr int KS = 16;
+  // c10::Half: `s += a * b` is two roundings (product to half, sum to half); native half ops round identically
+  static __device__ __forceinline__ _Float16 mad(_Float16 s, _Float16 a, _Float16 b) { return s + a * b; }
+  static __device__ __forceinline__ _Float16 mul(_Float16 a, _Float16 b) { return a * b; }
+  static __device__ __forceinline__ _Float16 add(_Float16 a, _Float16 b) { return a + b; }
+  static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+};
+
+template <int R, typename T>
+__global__ __launch_bounds__(64) void altcorr_forward_kernel(const T *__restrict__ fmap1, const T *__restrict__ fmap2,
+                                                             const float *__restrict__ coords, T *__restrict__ corr,
+                                                             int B, int S, int H1, int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2, KS = AltT<T>::KS;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[ALT_UMAX * ALT_PITCH];
+  const int lane = threadIdx.x;
+  const int bs = blockIdx.z, b = bs / S;
+  const int h1 = blockIdx.y * ALT_TH + (lane >> 4), w1 = blockIdx.x * ALT_TW + (lane & 15);
+  const bool inb = (h1 < H1) && (w1 < W1);
+  const int HW1 = H1 * W1;
+  const int pix = min(h1, H1 - 1) * W1 + min(w1, W1 - 1);
+
+  const float *cp = coords + ((size_t)bs * HW1 + pix) * 2;
   const float x2 = cp[0], y2 = cp[1];
   const float fxf = floorf(x2), fyf = floorf(y2);
   const float dx = x2 - fxf, dy = y2 - fyf;
-  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
-  const int w0 = sane ? (int)fxf - R : -(1 << 20), h0 = sane ? (int)fyf - R : -(1 << 20);
-  const float wnw = dy * dx, wne = dy * (1 - dx), wsw = (1 - dy) * dx, wse = (1 - dy) * (1 - dx);
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);   // the reference's float -> int cast is undefined beyond
+  const int wx0 = sane ? (int)fxf - R : -(1 << 20), wy0 = sane ? (int)fyf - R : -(1 << 20);
+  // a window that misses the map entirely contributes exact zeros and must not stretch the staged union
+  const bool hits = inb && sane && (wx0 + WN > 0) && (wx0 < W2) && (wy0 + WN > 0) && (wy0 < H2);
+  // static_cast<scalar_t>(dy * dx) etc. (altcorr_kernel.cu:112-115): a FLOAT product, then one rounding to T.  The empty
+  // asm keeps the compiler from folding product and conversion into one mixed-precision instruction (v_fma_mix), which
+  // rounds once and differs from the reference where the float product lands on a half-way point of the half grid.
+  float pnw = dy * dx, pne = dy * (1 - dx), psw = (1 - dy) * dx, pse = (1 - dy) * (1 - dx);
+  asm volatile("" : "+v"(pnw), "+v"(pne), "+v"(psw), "+v"(pse));
+  const T wnw = AltT<T>::from_float(pnw), wne = AltT<T>::from_float(pne);
+  const T wsw = AltT<T>::from_float(psw), wse = AltT<T>::from_float(pse);
 
-  float acc[RD * RD];  // channel = iy + RD * ix
-#pragma unroll
-  for (int i = 0; i < RD * RD; i++) acc[i] = 0.f;
+  const int big = 1 << 28;
+  const bool any = __ballot(hits) != 0ull;
+  const int bx0 = wave_minmax<true>(hits ? wx0 : big), bx1 = wave_minmax<false>(hits ? wx0 : -big);
+  const int by0 = wave_minmax<true>(hits ? wy0 : big), by1 = wave_minmax<false>(hits ? wy0 : -big);
+  const int UW = bx1 - bx0 + WN, UH = by1 - by0 + WN;
+  const bool vec_ok = ((C * (int)sizeof(T)) % 16 == 0);  // 16-byte slices of a pixel's channels are aligned
+  const bool staged = any && vec_ok && (UW > 0) && (UH > 0) && ((long)UW * UH <= ALT_UMAX);
+  const unsigned tap0 = hits ? (unsigned)(((wy0 - by0) * UW + (wx0 - bx0)) * ALT_PITCH) : 0u;  // this lane's first tap
 
-  const float *f1 = fmap1 + ((size_t)b * HW1 + pix) * C;
-  for (int c = 0; c < C; c += 32) {
-    const int cn = min(32, C - c);
-    float a[32];
+  T acc[RD * RD];  // channel = iy + RD * ix
 #pragma unroll
-    for (int k = 0; k < 32; k++) a[k] = (k < cn) ? f1[c + k] : 0.f;
+  for (int i = 0; i < RD * RD; i++) acc[i] = AltT<T>::from_float(0.f);
+
+  const T *f1 = fmap1 + ((size_t)b * HW1 + pix) * C;
+  const T *f2b = fmap2 + (size_t)b * H2 * W2 * C;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    T sdot[WN * WN];
 #pragma unroll
-    for (int iy = 0; iy < RD + 1; iy++) {
+    for (int i = 0; i < WN * WN; i++) sdot[i] = AltT<T>::from_float(0.f);
+    for (int c = c0; c < min(c0 + 32, C); c += KS) {
+      const int cn = min(KS, C - c);
+      // this pixel's slice of fmap1
+      T a[KS];
+      if (vec_ok && cn == KS) {
+        u4v_alt r0 = *reinterpret_cast<const u4v_alt *>(f1 + c), r1 = *reinterpret_cast<const u4v_alt *>(f1 + c + KS / 2);
+        __builtin_memcpy(&a[0], &r0, 16);
+        __builtin_memcpy(&a[KS / 2], &r1, 16);
+      } else {
 #pragma unroll
-      for (int ix = 0; ix < RD + 1; ix++) {
-        const int h2 = h0 + iy, w2 = w0 + ix;
-        float sdot = 0.f;
-        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-          const float *f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C + c;
+        for (int k = 0; k < KS; k++) a[k] = (k < cn) ? f1[c + k] : AltT<T>::from_float(0.f);
+      }
+      if (staged) {
+        // ---- union of the tile's windows, this slice: coalesced 16-byte loads, zeros outside the map ----
+        const int total = UW * UH * 2;  // 16-byte pieces
+        for (int u = lane; u < total; u += 64) {
+          const int up = u >> 1, hf = u & 1;
+          const int uy = up / UW, ux = up - uy * UW;
+          const int h2 = by0 + uy, w2 = bx0 + ux;
+          u4v_alt v = {0u, 0u, 0u, 0u};
+          if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+            const T *src = f2b + ((size_t)h2 * W2 + w2) * C + c + hf * (KS / 2);
+            if (cn == KS) v = *reinterpret_cast<const u4v_alt *>(src);
+            else {
+              T tmp[KS / 2];
 #pragma unroll
-          for (int k = 0; k < 32; k++) sdot = __fadd_rn(sdot, __fmul_rn(a[k], (k < cn) ? f2[k] : 0.f));
+              for (int k = 0; k < KS / 2; k++) tmp[k] = (hf * (KS / 2) + k < cn) ? src[k] : AltT<T>::from_float(0.f);
+              __builtin_memcpy(&v, tmp, 16);
+            }
+          }
+          *reinterpret_cast<u4v_alt *>(stage + up * ALT_PITCH + hf * 16) = v;
         }
-        if (iy > 0 && ix > 0) acc[(iy - 1) + RD * (ix - 1)] = __fadd_rn(acc[(iy - 1) + RD * (ix - 1)], __fmul_rn(sdot, wnw));
-        if (iy > 0 && ix < RD) acc[(iy - 1) + RD * ix] = __fadd_rn(acc[(iy - 1) + RD * ix], __fmul_rn(sdot, wne));
-        if (iy < RD && ix > 0) acc[iy + RD * (ix - 1)] = __fadd_rn(acc[iy + RD * (ix - 1)], __fmul_rn(sdot, wsw));
-        if (iy < RD && ix < RD) acc[iy + RD * ix] = __fadd_rn(acc[iy + RD * ix], __fmul_rn(sdot, wse));
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in program order
+#pragma unroll
+        for (int iy = 0; iy < WN; iy++) {
+#pragma unroll
+          for (int ix = 0; ix < WN; ix++) {
+            const unsigned char *tp = stage + tap0 + (unsigned)((iy * UW + ix) * ALT_PITCH);
+            u4v_alt r0 = *reinterpret_cast<const u4v_alt *>(tp), r1 = *reinterpret_cast<const u4v_alt *>(tp + 16);
+            T v[KS];
+            __builtin_memcpy(&v[0], &r0, 16);
+            __builtin_memcpy(&v[KS / 2], &r1, 16);
+            T sd = sdot[iy * WN + ix];
+#pragma unroll
+            for (int k = 0; k < KS; k++) sd = AltT<T>::mad(sd, a[k], v[k]);  // ascending channels, like the reference
+            sdot[iy * WN + ix] = sd;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next slice overwrites the staging area
+      } else {
+        // ---- incoherent tile (or odd channel count): every lane reads its own taps ----
+#pragma unroll
+        for (int iy = 0; iy < WN; iy++) {
+#pragma unroll
+          for (int ix = 0; ix < WN; ix++) {
+            const int h2 = wy0 + iy, w2 = wx0 + ix;
+            if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+              const T *f2 = f2b + ((size_t)h2 * W2 + w2) * C + c;
+              T sd = sdot[iy * WN + ix];
+#pragma unroll
+              for (int k = 0; k < KS; k++) sd = AltT<T>::mad(sd, a[k], (k < cn) ? f2[k] : AltT<T>::from_float(0.f));
+              sdot[iy * WN + ix] = sd;
+            }
+          }
+        }
+      }
+    }
+    // ---- scatter the chunk's dot products: corr[iy-1][ix-1] += s * w, four updates per tap in the reference's order ----
+#pragma unroll
+    for (int iy = 0; iy < WN; iy++) {
+#pragma unroll
+      for (int ix = 0; ix < WN; ix++) {
+        const T sd = hits ? sdot[iy * WN + ix] : AltT<T>::from_float(0.f);
+        if (iy > 0 && ix > 0) acc[(iy - 1) + RD * (ix - 1)] = AltT<T>::add(acc[(iy - 1) + RD * (ix - 1)], AltT<T>::mul(sd, wnw));
+        if (iy > 0 && ix < RD) acc[(iy - 1) + RD * ix] = AltT<T>::add(acc[(iy - 1) + RD * ix], AltT<T>::mul(sd, wne));
+        if (iy < RD && ix > 0) acc[iy + RD * (ix - 1)] = AltT<T>::add(acc[iy + RD * (ix - 1)], AltT<T>::mul(sd, wsw));
+        if (iy < RD && ix < RD) acc[iy + RD * ix] = AltT<T>::add(acc[iy + RD * ix], AltT<T>::mul(sd, wse));
       }
     }
   }
-  float *o = corr + (((size_t)b * S + s) * RD * RD) * HW1 + pix;
+  if (inb) {
+    T *o = corr + ((size_t)bs * RD * RD) * HW1 + pix;
 #pragma unroll
-  for (int i = 0; i < RD * RD; i++) o[(size_t)i * HW1] = acc[i];
+    for (int i = 0; i < RD * RD; i++) o[(size_t)i * HW1] = acc[i];
+  }
 }
 
 // adjoint of the above wrt the feature maps (altcorr_backward_kernel, altcorr_kernel.cu:152-286; training only).
@@ -142,16 +257,13 @@ __global__ __launch_bounds__(256) void altcorr_backward_kernel(const float *__re
 
 using namespace dba;
 
-extern "C" int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr,
-                                   int B, int S, int H1, int W1, int H2, int W2, int C, int radius,
-                                   dba_stream_t stream) {
-  if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0) return DBA_ERR_ARG;
-  const long total = (long)B * S * H1 * W1;
-  if (total == 0) return DBA_OK;
-  dim3 grid((unsigned)((total + 255) / 256));
-#define LAUNCH_R(RR)                                                                                          \
-  hipLaunchKernelGGL((altcorr_forward_kernel<RR>), grid, dim3(256), 0, (hipStream_t)stream, fmap1, fmap2, coords, \
-                     corr, B, S, H1, W1, H2, W2, C)
+template <typename T>
+static int altcorr_forward_launch(const void *fmap1, const void *fmap2, const float *coords, void *corr, int B, int S, int H1,
+                                  int W1, int H2, int W2, int C, int radius, hipStream_t stream) {
+  dim3 grid((W1 + ALT_TW - 1) / ALT_TW, (H1 + ALT_TH - 1) / ALT_TH, B * S);
+#define LAUNCH_R(RR)                                                                                             \
+  hipLaunchKernelGGL((altcorr_forward_kernel<RR, T>), grid, dim3(64), 0, stream, static_cast<const T *>(fmap1),  \
+                     static_cast<const T *>(fmap2), coords, static_cast<T *>(corr), B, S, H1, W1, H2, W2, C)
   switch (radius) {
     case 1: LAUNCH_R(1); break;
     case 2: LAUNCH_R(2); break;
@@ -162,6 +274,26 @@ extern "C" int dba_altcorr_forward(const float *fmap1, const float *fmap2, const
 #undef LAUNCH_R
   DBA_LAUNCH_CHECK();
   return DBA_OK;
+}
+
+extern "C" int dba_altcorr_forward_t(const void *fmap1, const void *fmap2, const float *coords, void *corr, int B, int S,
+                                     int H1, int W1, int H2, int W2, int C, int radius, int dtype, dba_stream_t stream) {
+  if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0) return DBA_ERR_ARG;
+  if ((long)B * S == 0) return DBA_OK;
+  if ((long)B * S > 65535) return DBA_ERR_UNSUPPORTED;
+  if (!fmap1 || !fmap2 || !coords || !corr) return DBA_ERR_ARG;
+  if (dtype == DBA_F32)
+    return altcorr_forward_launch<float>(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius, (hipStream_t)stream);
+  if (dtype == DBA_F16)
+    return altcorr_forward_launch<_Float16>(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius,
+                                            (hipStream_t)stream);
+  return DBA_ERR_UNSUPPORTED;
+}
+
+extern "C" int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr,
+                                   int B, int S, int H1, int W1, int H2, int W2, int C, int radius,
+                                   dba_stream_t stream) {
+  return dba_altcorr_forward_t(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius, DBA_F32, stream);
 }
 
 extern "C" int dba_altcorr_backward(const float *fmap1, const float *fmap2, const float *coords,

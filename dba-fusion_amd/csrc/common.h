@@ -78,6 +78,32 @@ __device__ __forceinline__ float deposit_lane63(float dst, float reduced, int la
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// wave-wide / 8-lane-group integer min and max on the DPP network (fused into v_min/v_max: one VALU op per
+// step, no LDS traffic, no address arithmetic)
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ int dpp_minmax(int x) {
+  const int moved = __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);  // lanes without a source keep x
+  return IS_MIN ? min(x, moved) : max(x, moved);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_minmax(int x) {
+  x = dpp_minmax<0x111, 0xf, IS_MIN>(x);  // row_shr:1
+  x = dpp_minmax<0x112, 0xf, IS_MIN>(x);  // row_shr:2
+  x = dpp_minmax<0x114, 0xf, IS_MIN>(x);  // row_shr:4
+  x = dpp_minmax<0x118, 0xf, IS_MIN>(x);  // row_shr:8
+  x = dpp_minmax<0x142, 0xa, IS_MIN>(x);  // row_bcast:15
+  x = dpp_minmax<0x143, 0xc, IS_MIN>(x);  // row_bcast:31
+  return __builtin_amdgcn_readlane(x, 63);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ int group8_minmax(int x) {  // result in all 8 lanes of the group
+  x = dpp_minmax<0xB1, 0xf, IS_MIN>(x);   // quad_perm [1,0,3,2]
+  x = dpp_minmax<0x4E, 0xf, IS_MIN>(x);   // quad_perm [2,3,0,1]
+  x = dpp_minmax<0x141, 0xf, IS_MIN>(x);  // row_half_mirror: the other quad of the group
+  return x;
+}
+
+
 // ---- SE3 helpers on (t, q_xyzw) -----------------------------------------------------------
 struct Rot3 {
   float r[9];  // row-major

@@ -198,9 +198,8 @@ class CorrLayer(torch.autograd.Function):
         import droid_backends
         fmap1, fmap2, coords = ctx.saved_tensors
         grad_corr = grad_corr.contiguous()
-        fmap1_grad, fmap2_grad, coords_grad = droid_backends.altcorr_backward(
-            fmap1.float(), fmap2.float(), coords, grad_corr.float(), ctx.r)
-        return fmap1_grad.to(fmap1.dtype), fmap2_grad.to(fmap2.dtype), coords_grad, None
+        fmap1_grad, fmap2_grad, coords_grad = droid_backends.altcorr_backward(fmap1, fmap2, coords, grad_corr, ctx.r)
+        return fmap1_grad, fmap2_grad, coords_grad, None
 
 
 class AltCorrBlock:

@@ -337,29 +337,33 @@ def corr_index_backward(volume, coords, corr_grad, radius):
 
 
 def altcorr_forward(fmap1, fmap2, coords, radius):
-    """droid.cpp:254-264: fmap [B,H,W,C] channels-last, coords [B,S,H1,W1,2] -> [corr [B,S,rd*rd,H1,W1]]."""
+    """droid.cpp:254-264: fmap [B,H,W,C] channels-last (float or half, like the reference's
+    AT_DISPATCH_FLOATING_TYPES_AND_HALF), coords [B,S,H1,W1,2] f32 -> [corr [B,S,rd*rd,H1,W1]] of the maps' dtype."""
     _check(fmap1, "fmap1")
     _check(fmap2, "fmap2")
     _check(coords, "coords", torch.float32)
-    f1 = fmap1 if fmap1.dtype == torch.float32 else fmap1.float()
-    f2 = fmap2 if fmap2.dtype == torch.float32 else fmap2.float()
+    if fmap1.dtype != fmap2.dtype or fmap1.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("altcorr_forward: fmap1 / fmap2 must both be float32 or both float16")
     B, S, H1, W1, _ = coords.shape
-    _, H2, W2, C = f2.shape
+    _, H2, W2, C = fmap2.shape
     r = int(radius)
-    corr = torch.empty(B, S, (2 * r + 1) ** 2, H1, W1, dtype=torch.float32, device=coords.device)
-    _lib.check(_lib.load().dba_altcorr_forward(_ptr(f1), _ptr(f2), _ptr(coords), _ptr(corr), int(B), int(S),
-                                               int(H1), int(W1), int(H2), int(W2), int(C), r, _stream()),
-               "dba_altcorr_forward")
-    return [corr.to(fmap1.dtype)]
+    corr = torch.empty(B, S, (2 * r + 1) ** 2, H1, W1, dtype=fmap1.dtype, device=coords.device)
+    _lib.check(_lib.load().dba_altcorr_forward_t(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr), int(B), int(S),
+                                                 int(H1), int(W1), int(H2), int(W2), int(C), r, _vol_dtype(fmap1),
+                                                 _stream()), "dba_altcorr_forward")
+    return [corr]
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     """droid.cpp:266-278 (training only; dead in the DBA-Fusion runtime).  Returns
     [fmap1_grad, fmap2_grad, coords_grad]; coords_grad is all zeros like the reference's (never written)."""
-    _check(fmap1, "fmap1", torch.float32)
-    _check(fmap2, "fmap2", torch.float32)
+    _check(fmap1, "fmap1")
+    _check(fmap2, "fmap2")
     _check(coords, "coords", torch.float32)
-    _check(corr_grad, "corr_grad", torch.float32)
+    _check(corr_grad, "corr_grad")
+    dt = fmap1.dtype   # half inputs (the reference dispatches them too): the adjoint runs in float, results are cast back
+    if dt != torch.float32:
+        fmap1, fmap2, corr_grad = fmap1.float(), fmap2.float(), corr_grad.float()
     B, S, H1, W1, _ = coords.shape
     _, H2, W2, C = fmap2.shape
     g1 = torch.zeros(B, H1, W1, C, dtype=torch.float32, device=fmap1.device)
@@ -368,4 +372,4 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     _lib.check(_lib.load().dba_altcorr_backward(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr_grad), _ptr(g1),
                                                 _ptr(g2), int(B), int(S), int(H1), int(W1), int(H2), int(W2),
                                                 int(C), int(radius), _stream()), "dba_altcorr_backward")
-    return [g1, g2, gc]
+    return [g1.to(dt), g2.to(dt), gc]

@@ -200,6 +200,11 @@ int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *lev
  * coords [B,S,H1,W1,2] f32 -> corr [B,S,(2r+1)^2,H1,W1] f32, channel = y_offset + (2r+1)*x_offset. */
 int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr, int B,
                         int S, int H1, int W1, int H2, int W2, int C, int radius, dba_stream_t stream);
+/* the same with the element type of fmap1, fmap2 and corr selectable (the reference dispatches
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF, src/altcorr_kernel.cu:304): dtype = DBA_F32 or DBA_F16; coords stay f32.
+ * The half instantiation rounds every product and sum to half like c10::Half and is bit-identical to the reference. */
+int dba_altcorr_forward_t(const void *fmap1, const void *fmap2, const float *coords, void *corr, int B, int S,
+                          int H1, int W1, int H2, int W2, int C, int radius, int dtype, dba_stream_t stream);
 
 /* altcorr_backward (src/droid.cpp:266-278, src/altcorr_kernel.cu:152-286,321-356; training only):
  * gradients wrt the feature maps; fmap1_grad [B,H1,W1,C], fmap2_grad [B,H2,W2,C] must be zero-initialised

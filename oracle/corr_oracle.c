@@ -217,6 +217,51 @@ void oracle_altcorr_forward_f32(const float *fmap1, const float *fmap2, const fl
           }
 }
 
+/* the half instantiation of the same kernel (AT_DISPATCH_FLOATING_TYPES_AND_HALF, altcorr_kernel.cu:304): scalar_t =
+ * c10::Half, i.e. every product and every sum is computed in float and rounded to half (`s += f1 * f2` :102-103, the
+ * four weighted terms :112-115 with static_cast<scalar_t>(dy * dx), the read-modify-writes of corr :131-141);
+ * x2s, y2s, dx, dy stay float (:45-46, :70-71). */
+void oracle_altcorr_forward_f16(const uint16_t *fmap1, const uint16_t *fmap2, const float *coords, uint16_t *corr,
+                                int B, int S, int H1, int W1, int H2, int W2, int C, int r) {
+  const int rd = 2 * r + 1;
+  const size_t HW1 = (size_t)H1 * W1;
+  memset(corr, 0, sizeof(uint16_t) * (size_t)B * S * rd * rd * HW1);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; b++)
+    for (int h1 = 0; h1 < H1; h1++)
+      for (int w1 = 0; w1 < W1; w1++)
+        for (int c = 0; c < C; c += 32)
+          for (int s = 0; s < S; s++) {
+            const float *cp = coords + ((((size_t)b * S + s) * H1 + h1) * W1 + w1) * 2;
+            const float x2 = cp[0], y2 = cp[1];
+            const float dx = x2 - floorf(x2), dy = y2 - floorf(y2);
+            const uint16_t *f1 = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c;
+            uint16_t *cr = corr + (((size_t)b * S + s) * rd * rd) * HW1 + (size_t)h1 * W1 + w1;
+            const uint16_t wnw = float_to_half(dy * dx), wne = float_to_half(dy * (1 - dx));
+            const uint16_t wsw = float_to_half((1 - dy) * dx), wse = float_to_half((1 - dy) * (1 - dx));
+            for (int iy = 0; iy < rd + 1; iy++)
+              for (int ix = 0; ix < rd + 1; ix++) {
+                const int h2 = (int)floorf(y2) - r + iy, w2 = (int)floorf(x2) - r + ix;
+                uint16_t sdot = 0;
+                if (within_bounds(h2, w2, H2, W2)) {
+                  const uint16_t *f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C + c;
+                  for (int k = 0; k < 32 && c + k < C; k++) {
+                    const uint16_t prod = float_to_half(half_to_float(f1[k]) * half_to_float(f2[k]));
+                    sdot = float_to_half(half_to_float(sdot) + half_to_float(prod));
+                  }
+                }
+#define HMUL_(a, b) float_to_half(half_to_float(a) * half_to_float(b))
+#define HACC_(dst, v) (dst) = float_to_half(half_to_float(dst) + half_to_float(v))
+                if (iy > 0 && ix > 0) HACC_(cr[(size_t)((iy - 1) + rd * (ix - 1)) * HW1], HMUL_(sdot, wnw));
+                if (iy > 0 && ix < rd) HACC_(cr[(size_t)((iy - 1) + rd * ix) * HW1], HMUL_(sdot, wne));
+                if (iy < rd && ix > 0) HACC_(cr[(size_t)(iy + rd * (ix - 1)) * HW1], HMUL_(sdot, wsw));
+                if (iy < rd && ix < rd) HACC_(cr[(size_t)(iy + rd * ix) * HW1], HMUL_(sdot, wse));
+#undef HMUL_
+#undef HACC_
+              }
+          }
+}
+
 /* ---- altcorr_backward_kernel, altcorr_kernel.cu:152-286 (float; launcher :321-356) ---------------
  * fmap1_grad [B][H1][W1][C], fmap2_grad [B][H2][W2][C] (zero-initialised here like the launcher does);
  * coords_grad is allocated but never written by the reference (stays zero). */

@@ -313,7 +313,20 @@ def corr_lookup_pyramid(pyr, coords, radius):
 
 
 def altcorr_forward(fmap1, fmap2, coords, radius):
-    """altcorr_forward_kernel (altcorr_kernel.cu:27-149), float32."""
+    """altcorr_forward_kernel (altcorr_kernel.cu:27-149): float32, or c10::Half arithmetic when the maps are float16."""
+    if _is_half(fmap1):
+        f1 = np.ascontiguousarray(fmap1).view(np.uint16)
+        f2 = np.ascontiguousarray(fmap2, np.float16).view(np.uint16)
+        coords = _c(coords, np.float32)
+        B, H1, W1, C = f1.shape
+        _, H2, W2, _ = f2.shape
+        S = coords.shape[1]
+        rd = 2 * radius + 1
+        out = np.zeros((B, S, rd * rd, H1, W1), np.uint16)
+        lib().oracle_altcorr_forward_f16(_p(f1), _p(f2), _p(coords), _p(out), ctypes.c_int(B), ctypes.c_int(S),
+                                         ctypes.c_int(H1), ctypes.c_int(W1), ctypes.c_int(H2), ctypes.c_int(W2),
+                                         ctypes.c_int(C), ctypes.c_int(radius))
+        return out.view(np.float16)
     fmap1, fmap2, coords = _c(fmap1, np.float32), _c(fmap2, np.float32), _c(coords, np.float32)
     B, H1, W1, C = fmap1.shape
     _, H2, W2, _ = fmap2.shape

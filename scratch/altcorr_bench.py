@@ -1,0 +1,47 @@
+"""AltCorrBlock (on-the-fly correlation, no volume) on the bench window: 96 edges, 64x64 maps, 128 channels, 4 levels.
+python scratch/altcorr_bench.py   (prints us per call and per edge-level for float and half maps)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dba-fusion_amd"))
+from dbaf_amd import synthetic as syn  # noqa: E402
+from dbaf_amd import projective_ops as pops  # noqa: E402
+import droid_backends  # noqa: E402
+
+W = syn.window_25_96(0)
+dev = "cuda"
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+fm = t(syn.make_fmaps(W.B, 128, W.h, W.w, 1000)).float() / 4.0
+ii, jj = t(W.ii), t(W.jj)
+K = t(W.intrinsics)[None, None].expand(1, W.B, 4).contiguous()
+coords, _ = pops.projective_transform(t(W.poses)[None], t(W.disps)[None], K, ii, jj)   # [1, N, h, w, 2]
+pyr = []
+f = fm
+for lvl in range(4):
+    pyr.append(f.permute(0, 2, 3, 1).contiguous())
+    f = torch.nn.functional.avg_pool2d(f, 2, stride=2)
+for dt in (torch.float32, torch.float16):
+    f1 = pyr[0][ii].to(dt).contiguous()
+    tot = 0.0
+    for lvl in range(4):
+        f2 = pyr[lvl][jj].to(dt).contiguous()
+        c = (coords[0] / 2 ** lvl)[:, None].contiguous()
+        for _ in range(2):
+            droid_backends.altcorr_forward(f1, f2, c, 3)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            droid_backends.altcorr_forward(f1, f2, c, 3)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 5
+        tot += us
+        flops = 2.0 * W.N * W.h * W.w * 64 * 128
+        print("%s level %d: %.1f us for %d edges (%.2f us/edge, %.1f TFLOP/s of window dot products)" % (
+            str(dt).split(".")[1], lvl, us, W.N, us / W.N, flops / us / 1e6), flush=True)
+    print("%s 4 levels: %.1f us (the volume lookup of the same window: ~95 us + 24 us/edge once for the volume)" % (
+        str(dt).split(".")[1], tot), flush=True)

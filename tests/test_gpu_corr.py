@@ -199,22 +199,88 @@ def test_corr_volume_build_matches_oracle(shape):
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
 
 
-def test_altcorr_forward_matches_oracle():
-    import droid_backends
-    orc = _oracle()
-    rng = np.random.default_rng(9)
-    B, S, H1, W1, H2, W2, C, r = 2, 2, 9, 12, 5, 7, 64, 3
+def _alt_case(rng, B, S, H1, W1, H2, W2, C, coherent):
     f1 = rng.standard_normal((B, H1, W1, C)).astype(np.float32)
     f2 = rng.standard_normal((B, H2, W2, C)).astype(np.float32)
-    coords = np.stack([rng.uniform(-2, W2 + 1, size=(B, S, H1, W1)), rng.uniform(-2, H2 + 1, size=(B, S, H1, W1))],
-                      -1).astype(np.float32)
+    if coherent:   # smooth flow: the tile's windows overlap, the LDS-staged path runs
+        yy, xx = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
+        coords = np.zeros((B, S, H1, W1, 2), np.float32)
+        for b in range(B):
+            for s in range(S):
+                coords[b, s, ..., 0] = xx * (W2 / W1) + rng.uniform(-3, 3) + 0.4 * np.sin(0.3 * yy + s)
+                coords[b, s, ..., 1] = yy * (H2 / H1) + rng.uniform(-3, 3) + 0.4 * np.cos(0.2 * xx + b)
+        wild = rng.uniform(size=(B, S, H1, W1)) < 0.02
+        coords[wild] += rng.uniform(-200, 200, size=(int(wild.sum()), 2)).astype(np.float32)
+    else:          # incoherent: every lane reads its own taps
+        coords = np.stack([rng.uniform(-2, W2 + 1, size=(B, S, H1, W1)), rng.uniform(-2, H2 + 1, size=(B, S, H1, W1))],
+                          -1).astype(np.float32)
+    coords[0, 0, 0, 0] = (2.0, 1.0)              # integer coordinates
+    coords[0, 0, 0, 1] = (-0.5, H2 - 0.5)        # straddles two borders
+    return f1, f2, coords
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("case", [
+    # B, S, H1, W1, H2, W2, C, radius, coherent
+    (2, 2, 9, 12, 5, 7, 64, 3, False),
+    (2, 1, 24, 40, 24, 40, 128, 3, True),      # the AltCorrBlock call shape: level 0, 128 channels
+    (1, 2, 24, 40, 12, 20, 128, 3, True),      # level 1 (pooled fmap2)
+    (1, 1, 13, 21, 13, 21, 32, 1, True),
+    (1, 1, 13, 21, 13, 21, 32, 2, True),
+    (1, 1, 10, 18, 10, 18, 32, 4, True),
+    (1, 1, 7, 9, 6, 5, 96, 2, False),
+    (1, 1, 8, 16, 8, 16, 36, 3, True),         # channel count that is not a multiple of a slice
+], ids=lambda c: "B%dS%d_%dx%d_from_%dx%d_C%d_r%d_%s" % (c[:8] + ("coh" if c[8] else "inc",)))
+def test_altcorr_forward_matches_oracle(case, dtype):
+    """float: the oracle accumulates with separate multiply and add, the kernel with the fused multiply-add nvcc emits for
+    the reference's `s += a * b` -> a few float32 ulps; half: c10::Half arithmetic on both sides -> bit-exact"""
+    import droid_backends
+    orc = _oracle()
+    B, S, H1, W1, H2, W2, C, r, coherent = case
+    rng = np.random.default_rng(9)
+    f1, f2, coords = _alt_case(rng, B, S, H1, W1, H2, W2, C, coherent)
+    f1, f2 = f1.astype(dtype), f2.astype(dtype)
     ref = orc.altcorr_forward(f1, f2, coords, r)
     out, = droid_backends.altcorr_forward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
                                           torch.from_numpy(coords).cuda(), r)
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    if dtype == np.float16:
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), \
+            (float((got != ref).mean()), float(np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()))
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.sqrt(C / 64))
 
 
-def test_corr_index_backward_matches_oracle():
+def test_altcorrblock_mirror_matches_per_level_oracle():
+    """dbaf_amd.corr.AltCorrBlock (mirror of modules/corr.py:91-139) == per-level altcorr on the pooled channels-last
+    pyramid, concatenated; and it agrees with the volume-based CorrBlock lookup to rounding (same quantity, no volume)"""
+    from dbaf_amd.corr import AltCorrBlock, CorrBlock
+    orc = _oracle()
+    rng = np.random.default_rng(19)
+    B, N, C, H, W = 1, 3, 128, 24, 32
+    fmaps = (0.5 * rng.standard_normal((B, N, C, H, W))).astype(np.float32)
+    ii, jj = np.array([0, 1, 2, 0]), np.array([1, 2, 0, 2])
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    coords = np.stack([xx[None] + rng.uniform(-2, 2, size=(4, 1, 1)), yy[None] + rng.uniform(-2, 2, size=(4, 1, 1))],
+                      -1).astype(np.float32)[None]                                    # [1, 4, H, W, 2]
+    t = torch.from_numpy(fmaps).cuda()
+    blk = AltCorrBlock(t, num_levels=4, radius=3)
+    out = blk(torch.from_numpy(coords).cuda(), torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda())
+    assert out.shape == (1, 4, 196, H, W)
+    got = out.cpu().numpy()[0]
+    pyr = [p.cpu().numpy()[0] for p in blk.pyramid]                                   # [N, H>>l, W>>l, C] pre-divided by 4
+    for lvl in range(4):
+        ref = orc.altcorr_forward(pyr[0][ii], pyr[lvl][jj], (coords[0] / 2 ** lvl)[:, None], 3)[:, 0]   # [4, 49, H, W]
+        np.testing.assert_allclose(got[:, 49 * lvl:49 * lvl + 49], ref, rtol=2e-5, atol=2e-5)
+    # against the materialised volume (half GEMM + half lookup): same quantity to half precision
+    cb = CorrBlock(t[:, ii].half(), t[:, jj].half(), num_levels=4, radius=3)
+    vol = cb(torch.from_numpy(coords).cuda()).float().cpu().numpy()[0]
+    np.testing.assert_allclose(got, vol, rtol=0, atol=0.02 * np.abs(vol).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_corr_index_backward_matches_oracle(dtype):
     import droid_backends
     orc = _oracle()
     rng = np.random.default_rng(10)
@@ -222,12 +288,19 @@ def test_corr_index_backward_matches_oracle():
     coords = _coords(rng, n, h1, w1, h2, w2)
     cg = rng.standard_normal((n, 7, 7, h1, w1)).astype(np.float32)
     ref = orc.corr_index_backward((n, h1, w1, h2, w2), coords, cg, r)
-    vol = torch.zeros(n, h1, w1, h2, w2, device="cuda")
-    out, = droid_backends.corr_index_backward(vol, torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda(), r)
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    if dtype == torch.float16:
+        cg = cg.astype(np.float16).astype(np.float32)
+        ref = orc.corr_index_backward((n, h1, w1, h2, w2), coords, cg, r)
+    vol = torch.zeros(n, h1, w1, h2, w2, device="cuda", dtype=dtype)   # half volume: the gradient comes back as half
+    out, = droid_backends.corr_index_backward(vol, torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda().to(dtype), r)
+    assert out.dtype == dtype
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, **tol)
 
 
-def test_altcorr_backward_matches_oracle():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_altcorr_backward_matches_oracle(dtype):
+    """half maps (the reference dispatches them too, altcorr_kernel.cu:337): the adjoint runs in float and is cast back"""
     import droid_backends
     orc = _oracle()
     rng = np.random.default_rng(11)
@@ -237,11 +310,15 @@ def test_altcorr_backward_matches_oracle():
     coords = np.stack([rng.uniform(-2, W2 + 1, size=(B, S, H1, W1)), rng.uniform(-2, H2 + 1, size=(B, S, H1, W1))],
                       -1).astype(np.float32)
     cg = rng.standard_normal((B, S, 49, H1, W1)).astype(np.float32)
+    if dtype == torch.float16:
+        f1, f2, cg = (a.astype(np.float16).astype(np.float32) for a in (f1, f2, cg))
     r1, r2 = orc.altcorr_backward(f1, f2, coords, cg, r)
-    g1, g2, gc = droid_backends.altcorr_backward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
-                                                 torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda(), r)
-    np.testing.assert_allclose(g1.cpu().numpy(), r1, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-4)
+    g1, g2, gc = droid_backends.altcorr_backward(torch.from_numpy(f1).cuda().to(dtype), torch.from_numpy(f2).cuda().to(dtype),
+                                                 torch.from_numpy(coords).cuda(), torch.from_numpy(cg).cuda().to(dtype), r)
+    assert g1.dtype == dtype and g2.dtype == dtype
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(g1.float().cpu().numpy(), r1, **tol)
+    np.testing.assert_allclose(g2.float().cpu().numpy(), r2, **tol)
     assert float(gc.abs().max()) == 0.0
 
 
