@@ -308,6 +308,22 @@ def main():
                         **extras}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, fmaps, ii, jj)
+            # the "ATE vs reference" half of the metric on the synthetic window (no dataset exists here): evo-style APE
+            # (translation part, SE3-aligned, RMSE; evaluation_scripts/evaluate_tumvi.py:132-135) of the keyframe
+            # trajectory after one dba_update, device vs the CPU oracle, and each against the ground truth
+            from dbaf_amd import ate
+            from oracle import oracle as orc
+            state.copy_(state0)
+            droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep, False)
+            torch.cuda.synchronize()
+            dev_p = poses.cpu().numpy()[:W.num_kf]
+            ref = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1,
+                         2, W.lm, W.ep, False, 0.05, np.float32)["poses"][:W.num_kf]
+            out["extra"]["ate_vs_oracle_m"] = float("%.3e" % ate.ate(ref, dev_p))
+            out["extra"]["ate_vs_ground_truth_m"] = {"device": float("%.4e" % ate.ate(W.poses_gt[:W.num_kf], dev_p)),
+                                                     "oracle": float("%.4e" % ate.ate(W.poses_gt[:W.num_kf], ref)),
+                                                     "before": float("%.4e" % ate.ate(W.poses_gt[:W.num_kf],
+                                                                                      W.poses[:W.num_kf]))}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
