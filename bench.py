@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r02_pmc_lookup.json")
+PMC_FILE = os.path.join("profiles", "r02_pmc_lookup%s.json")   # % "" for the default window, "_<window>" otherwise
 LOOKUP_SOURCES = ("dba-fusion_amd/csrc/corr_sheared.hip",)
 
 
@@ -269,8 +269,9 @@ def main():
                        "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
                        "pyramid_copies": ncopies},
             "roofline": {
-                "kernel": "corr_lookup_sheared_kernel<3> (fused 4-level r=3 lookup, f16, %d edges on rank 0, "
-                          "%s)" % (n_loc, "MALL-cold: rotating pyramid copies and output buffers" if ncopies > 1
+                "kernel": "%s (fused 4-level r=3 lookup, f16, %d edges on rank 0, "
+                          "%s)" % ("corr_lookup_sheared_kernel<3>" if w % 64 == 0 else "corr_lookup_resident_kernel<3>", n_loc,
+                                   "MALL-cold: rotating pyramid copies and output buffers" if ncopies > 1
                                    else "MALL-warm: one pyramid copy replayed"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
@@ -282,7 +283,8 @@ def main():
                 "avg_launch_ms": round(lookup_ms, 5) if lookup_ms == lookup_ms else None,
             },
         }
-        pmc = os.path.join(ROOT, PMC_FILE)
+        pmc_rel = PMC_FILE % ("" if args.window == "25_96" else "_" + args.window)
+        pmc = os.path.join(ROOT, pmc_rel)
         if os.path.exists(pmc) and world == 1:
             # HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of THIS command
             # (tools/profile_round.sh; FETCH_SIZE / WRITE_SIZE with the gfx950 corrections, see profiles/README.md).
@@ -292,7 +294,7 @@ def main():
             cur = source_hash(LOOKUP_SOURCES)
             if rec.get("workload") == args.window and rec.get("copies", 1) == ncopies:
                 out["roofline"]["traffic"] = int(rec["traffic_bytes_per_launch"])
-                out["roofline"]["traffic_source"] = PMC_FILE
+                out["roofline"]["traffic_source"] = pmc_rel
                 out["roofline"]["traffic_kernel_source_sha"] = rec.get("kernel_source_sha")
                 out["roofline"]["traffic_stale"] = rec.get("kernel_source_sha") != cur
         # both units of work, and the spread of the per-step device times (events on the launch stream)
