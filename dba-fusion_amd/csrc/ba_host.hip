@@ -239,6 +239,25 @@ int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *
                           nullptr, ws, ws_bytes, stream);
 }
 
+int dba_ba_shard_front(const float *poses, const float *disps, const float *intrinsics, const float *disps_sens,
+                       const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+                       const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                       float alpha, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  const int rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj,
+                                  frame_owned, N, B, ht, wd, t0, t1, alpha, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  return dba_ba_reduce(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, ws, ws_bytes, stream);
+}
+
+int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
+                      int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps, void *ws,
+                      size_t ws_bytes, dba_stream_t stream) {
+  const int rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  return dba_ba_update(poses, disps, ii, jj, frame_owned, N, B, ht, wd, t0, t1, 1, update_disps, nullptr, ws, ws_bytes,
+                       stream);
+}
+
 int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
            const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
            const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,

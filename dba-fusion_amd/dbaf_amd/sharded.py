@@ -82,11 +82,14 @@ class ShardedWindow:
         if dist is None:
             return
         d = self._on(disps.device)
-        send = disps.new_zeros((self.kmax,) + tuple(disps.shape[1:]))
+        key = ("merge", tuple(disps.shape[1:]), disps.dtype)
+        if key not in d:   # staging buffers live as long as the window object (one allocation, not one per call)
+            d[key] = (disps.new_zeros((self.kmax,) + tuple(disps.shape[1:])),
+                      disps.new_empty((self.world * self.kmax,) + tuple(disps.shape[1:])))
+        send, recv = d[key]
         n_mine = int(d["my_rows"].numel())
         if n_mine:
-            send[:n_mine] = disps.index_select(0, d["my_rows"])
-        recv = disps.new_empty((self.world * self.kmax,) + tuple(disps.shape[1:]))
+            torch.index_select(disps, 0, d["my_rows"], out=send[:n_mine])
         dist.all_gather_into_tensor(recv, send)
         disps.index_copy_(0, d["all_rows"], recv.index_select(0, d["all_slots"]))
 
@@ -96,7 +99,9 @@ class ShardedWindow:
         [|kx|,h,w] (or [1,h,w]) damping; poses/disps are replicated and stay coherent on return."""
         d = self._on(poses.device)
         if stages is None:
-            stages = HipStages()
+            if getattr(self, "_hip_stages", None) is None:
+                self._hip_stages = HipStages()
+            stages = self._hip_stages
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         n6 = 6 * (self.t1 - self.t0)
@@ -114,8 +119,11 @@ class ShardedWindow:
                 if dist is not None:
                     dist.all_reduce(hb)                     # (gloo in the CPU tests)
                 stages.set_system(ctx, hb)
-            stages.solve(ctx, lm, ep)
-            stages.update(ctx, update_disps=not motion_only)
+            if hasattr(stages, "solve_update"):
+                stages.solve_update(ctx, lm, ep, update_disps=not motion_only)
+            else:
+                stages.solve(ctx, lm, ep)
+                stages.update(ctx, update_disps=not motion_only)
         # Between iterations a rank only reads the depths of the frames it owns (the source frames of its own
         # edges), so the replicas are made coherent ONCE per call: every rank sends the rows it owns.
         if not motion_only:
@@ -196,29 +204,36 @@ class ShardedBACore:
 class HipStages:
     """Stage executor over the C ABI (include/dba_hip.h): dba_ba_prepare / linearize / reduce / solve / update."""
 
+    def __init__(self):
+        self._cache = {}   # (dims, device) -> workspace, layout and views: one allocation per window shape, not per call
+
     def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
         lib = _lib.load()
         B, ht, wd = disps.shape
         N = int(ii.shape[0])
         dims = (N, int(B), int(ht), int(wd), int(t0), int(t1))
-        nbytes = lib.dba_ba_workspace_bytes(*dims)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=poses.device)
-        lay = _lib.BaLayout()
-        _lib.check(lib.dba_ba_get_layout(*dims, ctypes.byref(lay)), "dba_ba_get_layout")
-        ctx = dict(lib=lib, dims=dims, ws=ws, nbytes=nbytes, lay=lay, poses=poses, disps=disps, intr=intrinsics,
+        key = (dims, str(poses.device))
+        base = self._cache.get(key)
+        if base is None:
+            nbytes = lib.dba_ba_workspace_bytes(*dims)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=poses.device)
+            lay = _lib.BaLayout()
+            _lib.check(lib.dba_ba_get_layout(*dims, ctypes.byref(lay)), "dba_ba_get_layout")
+            n = 6 * (int(t1) - int(t0))
+            base = dict(ws=ws, nbytes=nbytes, lay=lay, H=ws[lay.H:lay.H + 8 * n * n].view(torch.float64),
+                        b=ws[lay.b:lay.b + 8 * n].view(torch.float64))
+            # H and b are neighbours in the workspace: one in-place all-reduce covers both (the alignment gap is zeroed
+            # once so that it sums to zero; no kernel writes there)
+            if lay.b >= lay.H + 8 * n * n and (lay.b - lay.H) % 8 == 0 and lay.b - (lay.H + 8 * n * n) <= 4096:
+                ws[lay.H + 8 * n * n:lay.b].zero_()
+                base["hb"] = ws[lay.H:lay.b + 8 * n].view(torch.float64)
+            self._cache = {key: base}   # (one shape at a time: a new window shape replaces the old workspace)
+        ctx = dict(base, lib=lib, dims=dims, poses=poses, disps=disps, intr=intrinsics,
                    dsens=disps_sens, targets=targets, weights=weights, eta=eta.contiguous(), ii=ii, jj=jj,
                    owned=owned.contiguous(), alpha=float(alpha),
                    eta_rows=int(eta.reshape(-1, ht * wd).shape[0]))
-        _lib.check(lib.dba_ba_prepare(self._p(ii), self._p(jj), *dims, self._p(ws), nbytes, self._s()),
+        _lib.check(lib.dba_ba_prepare(self._p(ii), self._p(jj), *dims, self._p(ctx["ws"]), ctx["nbytes"], self._s()),
                    "dba_ba_prepare")
-        n = 6 * (int(t1) - int(t0))
-        ctx["H"] = ws[lay.H:lay.H + 8 * n * n].view(torch.float64)
-        ctx["b"] = ws[lay.b:lay.b + 8 * n].view(torch.float64)
-        # H and b are neighbours in the workspace: one in-place all-reduce covers both (the alignment gap is zeroed
-        # once so that it sums to zero)
-        if lay.b >= lay.H + 8 * n * n and (lay.b - lay.H) % 8 == 0 and lay.b - (lay.H + 8 * n * n) <= 4096:
-            ws[lay.H + 8 * n * n:lay.b].zero_()
-            ctx["hb"] = ws[lay.H:lay.b + 8 * n].view(torch.float64)
         return ctx
 
     @staticmethod
@@ -231,12 +246,16 @@ class HipStages:
 
     def linearize_reduce(self, c, motion_only):
         lib, p = c["lib"], self._p
-        _lib.check(lib.dba_ba_linearize(p(c["poses"]), p(c["disps"]), p(c["intr"]), p(c["dsens"]), p(c["targets"]),
-                                        p(c["weights"]), p(c["eta"]), c["eta_rows"], p(c["ii"]), p(c["jj"]),
-                                        p(c["owned"]), *c["dims"], c["alpha"], p(c["ws"]), c["nbytes"], self._s()),
-                   "dba_ba_linearize")
-        _lib.check(lib.dba_ba_reduce(p(c["ii"]), p(c["jj"]), p(c["owned"]), *c["dims"], int(bool(motion_only)),
-                                     p(c["ws"]), c["nbytes"], self._s()), "dba_ba_reduce")
+        _lib.check(lib.dba_ba_shard_front(p(c["poses"]), p(c["disps"]), p(c["intr"]), p(c["dsens"]), p(c["targets"]),
+                                          p(c["weights"]), p(c["eta"]), c["eta_rows"], p(c["ii"]), p(c["jj"]),
+                                          p(c["owned"]), *c["dims"], c["alpha"], int(bool(motion_only)), p(c["ws"]),
+                                          c["nbytes"], self._s()), "dba_ba_shard_front")
+
+    def solve_update(self, c, lm, ep, update_disps=True):
+        p = self._p
+        _lib.check(c["lib"].dba_ba_shard_back(p(c["poses"]), p(c["disps"]), p(c["ii"]), p(c["jj"]), p(c["owned"]),
+                                              *c["dims"], float(lm), float(ep), int(bool(update_disps)), p(c["ws"]),
+                                              c["nbytes"], self._s()), "dba_ba_shard_back")
 
     def system_view(self, c):
         return c["hb"] if "hb" in c else None

@@ -108,6 +108,18 @@ int dba_ba_update(float *poses, float *disps, const int64_t *ii, const int64_t *
                   int update_poses, int update_disps, float *dz_out, void *ws, size_t ws_bytes,
                   dba_stream_t stream);
 
+/* The two halves of one Gauss-Newton iteration of a rank of the edge-sharded driver (dbaf_amd/sharded.py), one call
+ * each: front = stages 1 + 2 on the rank's edges (its partial [H | b] is then summed over the ranks by the caller: one
+ * RCCL all-reduce), back = stages 3 + 4 on the summed system (every rank solves it redundantly, retracts all poses and
+ * back-substitutes the depths of the frames it owns). */
+int dba_ba_shard_front(const float *poses, const float *disps, const float *intrinsics, const float *disps_sens,
+                       const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+                       const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                       float alpha, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream);
+int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
+                      int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps, void *ws,
+                      size_t ws_bytes, dba_stream_t stream);
+
 /* droid_backends.ba: `iterations` x (stage 1..4), all enqueued on `stream` with no host sync.
  * dx_out [P,6] and dz_out [>=|kx|, ht*wd] receive the last iteration's update (either may be NULL). */
 int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,

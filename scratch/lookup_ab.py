@@ -49,7 +49,15 @@ for name, mk in CASES.items():
 
     corrs = [build("sheared") for _ in range(ncopies)]
     K = t(W.intrinsics)[None, None].expand(1, W.B, 4).contiguous()
-    coords, _ = pops.projective_transform(t(W.poses)[None], t(W.disps)[None], K, ii, jj)
+    disps_dev = t(W.disps)
+    if os.environ.get("LOOKUP_AB_SMOOTH"):
+        # piecewise-smooth depth (what a real scene gives) instead of SURVEY 8(d)'s box-filtered noise: a tilted plane plus
+        # a low-frequency ripple per frame, same range of inverse depth
+        yy, xx = np.meshgrid(np.linspace(-1, 1, h, dtype=np.float32), np.linspace(-1, 1, w, dtype=np.float32), indexing="ij")
+        sm = np.stack([1.1 + 0.5 * xx * np.cos(0.7 * k) + 0.3 * yy * np.sin(0.9 * k) + 0.1 * np.sin(3 * xx + k) * np.cos(2 * yy)
+                       for k in range(W.B)]).astype(np.float32)
+        disps_dev = t(sm)
+    coords, _ = pops.projective_transform(t(W.poses)[None], disps_dev[None], K, ii, jj)
     # correctness vs the reference-layout lookup on a slice of edges (bit-exact)
     ne = min(N, 24)
     ref = CorrBlock(fm[ii[:ne]][None], fm[jj[:ne]][None], layout="reference")(coords[:, :ne])
