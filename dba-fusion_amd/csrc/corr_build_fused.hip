@@ -19,9 +19,9 @@
 //     consecutive pixels of one of four (dy, dx) lines and stores 8 bytes (four 2-byte stores for a quad that spans a row
 //     end); levels 2, 3: a lane is one pixel.  The barriers synchronise LDS only (`s_waitcnt lgkmcnt(0); s_barrier`): a
 //     `__syncthreads()` would drain every outstanding store first;
-//   * levels 1..3: 2x2 averages of the ROUNDED level below (== F.avg_pool2d on half, floor sizes), each element pooled
-//     straight from the level-0 tile by the lane that stores it (the rounded intermediate levels are recomputed in
-//     registers), so the tile is the only LDS buffer and there is no barrier after it is complete;
+//   * levels 1..3: 2x2 averages of the ROUNDED level below (== F.avg_pool2d on half, floor sizes): each thread pools one
+//     8 x 8 block of the tile down to its 4 x 4 + 2 x 2 + 1 values in registers, which then take the dead tile's place in
+//     LDS (two barriers) for the sheared store loops;
 //   * the strip's source operand (16 KB at C = 128) is staged ONCE per workgroup in the LDS the tile will take, and the
 //     target fragments are requested two k-steps ahead.
 // Where the time goes (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges, per workgroup of 42.7 k cycles): source operand
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)e * elems), 0, (int)(2 * elems), 0x00020000);
   };
   const unsigned plane_bytes = 2u * (unsigned)HW1p;
-  const _Float16 *mine = T + lane * PITCH;  // this pixel's [8][W2P] targets
 
   // Levels 0 and 1 carry 94 % of the bytes.  A 2-byte-per-lane store instruction costs the vector memory pipe as much as
   // an 8-byte one (~13 cycles per wave instruction: 10 B/clk/CU, which capped the store phases), so there a lane owns
@@ -248,11 +247,61 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
       }
     }
   }
+  // ---- levels 1..3.  Each thread pools ONE 8 x 8 block of one source pixel's tile into its 4 x 4 level-1, 2 x 2 level-2
+  // and 1 level-3 values (from the ROUNDED level below each time), all in registers; after one barrier (every read of
+  // the tile, the level-0 stores included, is done) the values take the tile's place in LDS, after a second one the
+  // three sheared store loops read them.  (Pooling every element in the lane that stores it needs no barrier at all
+  // but 2.4x the arithmetic -- the kernel is bound by VALU issue, 1935 instructions per wave before, see the header.)
+  _Float16 *P1 = T;                                // [64][4][W2P / 2]
+  _Float16 *P2 = P1 + 64 * 4 * (W2P / 2);          // [64][2][W2P / 4]
+  _Float16 *P3 = P2 + 64 * 2 * (W2P / 4);          // [64][W2P / 8]
+  constexpr int NBLK = W2P / 8;                    // 8-column blocks per pixel
+  constexpr int PER = 64 * NBLK / 512;             // blocks per thread (1 for 64-wide tiles, 2 for 128-wide)
+  _Float16 q1[PER][4][4], q2[PER][2][2], q3[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int blk = tid + 512 * u, src = blk / NBLK, cb = blk - src * NBLK;
+    const _Float16 *tb = T + src * PITCH + 8 * cb;
+    _Float16 t8[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const half4 lo = *reinterpret_cast<const half4 *>(tb + r * W2P), hi = *reinterpret_cast<const half4 *>(tb + r * W2P + 4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) t8[r][c] = lo[c], t8[r][4 + c] = hi[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) q1[u][r][c] = pool4(t8[2 * r][2 * c], t8[2 * r][2 * c + 1], t8[2 * r + 1][2 * c], t8[2 * r + 1][2 * c + 1]);
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        q2[u][r][c] = pool4(q1[u][2 * r][2 * c], q1[u][2 * r][2 * c + 1], q1[u][2 * r + 1][2 * c], q1[u][2 * r + 1][2 * c + 1]);
+    q3[u] = pool4(q2[u][0][0], q2[u][0][1], q2[u][1][0], q2[u][1][1]);
+  }
+  lds_barrier();  // every read of the level-0 tile is done (its sheared store above included)
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int blk = tid + 512 * u, src = blk / NBLK, cb = blk - src * NBLK;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      half4 v;
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = q1[u][r][c];
+      *reinterpret_cast<half4 *>(P1 + (src * 4 + r) * (W2P / 2) + 4 * cb) = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      half2v v;
+      v.x = q2[u][r][0], v.y = q2[u][r][1];
+      *reinterpret_cast<half2v *>(P2 + (src * 2 + r) * (W2P / 4) + 2 * cb) = v;
+    }
+    P3[src * (W2P / 8) + cb] = q3[u];
+  }
+  lds_barrier();
   FB_STAMP(4);
 #ifndef FB_ABLATE_POOLSTORE
-  // ---- levels 1..3: every element is pooled straight from the level-0 tile by the lane that stores it (the rounded
-  // intermediate levels are recomputed in registers: 4, 16, 64 tile reads per element, as 4-byte LDS reads), so no
-  // further barrier and no staging of the pooled levels is needed; (ty_l, dx) segments are dealt to the waves ----
   {  // level 1: 4 rows x (w2 >> 1) offsets, four lines per store instruction
     const int w2l = w2 >> 1, h2l = h2 >> 1;
     const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
@@ -267,56 +316,31 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
         int tx = (qx[i] >> 1) + dx;
         tx -= (tx >= w2l) ? w2l : 0;
         tx = min(tx, w2l - 1);
-        const _Float16 *s = quad + i * PITCH + (2 * tyl) * W2P + 2 * tx;
-        const half2v r0v = *reinterpret_cast<const half2v *>(s), r1v = *reinterpret_cast<const half2v *>(s + W2P);
-        v[i] = pool4(r0v.x, r0v.y, r1v.x, r1v.y);
+        v[i] = P1[((q4 + i) * 4 + tyl) * (W2P / 2) + tx];
       }
       store_quad(rl, 1, tyg, dx, h2l, w2l, v[0], v[1], v[2], v[3], dx < w2l);
     }
   }
-  auto pooled1 = [&](int ty1, int tx1) {  // rounded level-1 value of this pixel
-    const _Float16 *s = mine + (2 * ty1) * W2P + 2 * tx1;
-    const half2v r0v = *reinterpret_cast<const half2v *>(s), r1v = *reinterpret_cast<const half2v *>(s + W2P);
-    return pool4(r0v.x, r0v.y, r1v.x, r1v.y);
-  };
-  auto pooled2 = [&](int ty2, int tx2) {  // rounded level-2 value: 2x2 of rounded level-1 values
-    return pool4(pooled1(2 * ty2, 2 * tx2), pooled1(2 * ty2, 2 * tx2 + 1), pooled1(2 * ty2 + 1, 2 * tx2),
-                 pooled1(2 * ty2 + 1, 2 * tx2 + 1));
-  };
-  {  // level 2: 2 rows x (w2 >> 2) offsets
-    const int w2l = w2 >> 2, h2l = h2 >> 2;
-    const __amdgpu_buffer_rsrc_t rl = level_rsrc(2);
-    const int x1l = x1 >> 2, y1l = y1 >> 2;
-    for (int seg = wave; seg < 2 * w2l; seg += 8) {
+  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
+  auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
+    const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+    const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
+    const int x1l = x1 >> lvl, y1l = y1 >> lvl;
+    for (int seg = wave; seg < rows * w2l; seg += 8) {  // (wave-uniform)
       const int tyl = seg / w2l, dx = seg - tyl * w2l;
-      const int tyg = (ty0 >> 2) + tyl;
+      const int tyg = (ty0 >> lvl) + tyl;
       if (tyg >= h2l) continue;
       int dy = tyg - y1l;
       dy += (dy < 0) ? h2l : 0;
       int tx = x1l + dx;
       tx -= (tx >= w2l) ? w2l : 0;
-      const _Float16 v = pooled2(tyl, tx);
+      const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
       const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
       __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, 0);
     }
-  }
-  {  // level 3: 1 row x (w2 >> 3) offsets
-    const int w2l = w2 >> 3, h2l = h2 >> 3;
-    const __amdgpu_buffer_rsrc_t rl = level_rsrc(3);
-    const int x1l = x1 >> 3, y1l = y1 >> 3;
-    const int tyg = ty0 >> 3;
-    if (tyg < h2l) {
-      for (int dx = wave; dx < w2l; dx += 8) {
-        int dy = tyg - y1l;
-        dy += (dy < 0) ? h2l : 0;
-        int tx = x1l + dx;
-        tx -= (tx >= w2l) ? w2l : 0;
-        const _Float16 v = pool4(pooled2(0, 2 * tx), pooled2(0, 2 * tx + 1), pooled2(1, 2 * tx), pooled2(1, 2 * tx + 1));
-        const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, 0);
-      }
-    }
-  }
+  };
+  store_level(2, P2, 2, W2P / 4);
+  store_level(3, P3, 1, W2P / 8);
 #endif
   FB_STAMP(5);
 #ifdef FB_PROF
