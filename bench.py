@@ -139,6 +139,8 @@ def main():
 
     total = args.steps + args.warmup
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * total)]   # lookup: [4i, 4i+1]; ba (untimed loop): [4i+2, 4i+3]
+    for e_ in ev:
+        e_.record()   # (creates the underlying hipEvent_t; the lookup's pair is re-recorded by the kernel dispatch itself)
     ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
     keep = [None] * ncopies  # the last outputs stay alive: the allocator hands out other lines for the next ones
 
@@ -147,9 +149,15 @@ def main():
             ev_step[i].record()
         state.copy_(state0)
         coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
-        ev[4 * i].record()   # the roofline kernel is timed live, on its launch stream, in every timed step
-        c = (lookup(coords1) if lookup is not None else corr_of(i)(coords1)) if corrs else None
-        ev[4 * i + 1].record()
+        # the roofline kernel is timed live, in every timed step, with two HIP events ATTACHED TO ITS DISPATCH on the launch
+        # stream (hipExtLaunchKernelGGL through dba_corr_lookup_arm_timing): the dispatch's own start / end timestamps;
+        # event.record() around the call would put two marker packets (~5 us of idle each) into every step
+        if lookup is not None:
+            ev[4 * i].record()
+            c = lookup(coords1)
+            ev[4 * i + 1].record()
+        else:
+            c = corr_of(i)(coords1, timing=(ev[4 * i], ev[4 * i + 1])) if corrs else None
         keep[i % ncopies] = c
         if time_ba:
             ev[4 * i + 2].record()

@@ -16,6 +16,7 @@
 // from which every lane then picks its own 64 taps.  The arithmetic after that is the reference's
 // (correlation_kernels.cu:55-65), bit for bit.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "common.h"
@@ -795,7 +796,16 @@ static std::atomic<int> g_lookup_select{[] {
   return (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : 0;
 }()};
 
+// events armed for the next lookup launch of this thread (dba_corr_lookup_arm_timing)
+static thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
 extern "C" {
+
+int dba_corr_lookup_arm_timing(void *start_event, void *stop_event) {
+  g_time_start = (hipEvent_t)start_event;
+  g_time_stop = (hipEvent_t)stop_event;
+  return DBA_OK;
+}
 
 int dba_corr_lookup_select(int kernel) {
   if (kernel < 0 || kernel > 2) return DBA_ERR_ARG;
@@ -848,9 +858,11 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
     const int xtiles = (w1 + 63) / 64;
     const long rows = (long)n * h1 * xtiles;
     dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), num_levels);
-    hipLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, L,
-                       reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                       num_levels);
+    hipEvent_t e0 = g_time_start, e1 = g_time_stop;
+    g_time_start = g_time_stop = nullptr;
+    hipExtLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, e0, e1, 0, L,
+                          reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                          num_levels);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
@@ -865,9 +877,11 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
       attr_once.done();
     }
   }
-  hipLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, L,
-                     reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                     num_levels, HW1p, 1.0f / (float)w1);
+  hipEvent_t e0 = g_time_start, e1 = g_time_stop;
+  g_time_start = g_time_stop = nullptr;
+  hipExtLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, e0, e1, 0, L,
+                        reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                        num_levels, HW1p, 1.0f / (float)w1);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -120,7 +120,10 @@ class CorrBlock:
         lvl0 = CorrBlock.build_pyramid(fmap1, fmap2, 1)[0]
         return lvl0.view(batch, num, ht, wd, fmap2.shape[-2], fmap2.shape[-1])
 
-    def __call__(self, coords):
+    def __call__(self, coords, timing=None):
+        """timing = (start, stop): two torch.cuda.Event(enable_timing=True) that have been recorded once (so that they
+        exist); they are attached to the lookup kernel's dispatch (sheared layout only), start.elapsed_time(stop) is
+        then the kernel's duration -- a measurement hook for bench.py, without marker packets in the stream"""
         batch, num, ht, wd, _ = coords.shape
         n = batch * num
         vol0 = self.corr_pyramid[0]
@@ -135,6 +138,8 @@ class CorrBlock:
         ptrs = (ctypes.c_void_p * self.num_levels)(*[v.data_ptr() for v in vols])
         if self.layout == "sheared":
             assert (ht, wd) == (self.h1, self.w1), "coords / volume map size mismatch"
+            if timing is not None:
+                lib.dba_corr_lookup_arm_timing(ctypes.c_void_p(timing[0].cuda_event), ctypes.c_void_p(timing[1].cuda_event))
             _lib.check(lib.dba_corr_lookup_pyramid_sheared(ptrs, _ptr(c), _ptr(out), n, ht, wd, self.h2, self.w2,
                                                            self.num_levels, self.radius, _stream()),
                        "dba_corr_lookup_pyramid_sheared")

@@ -178,6 +178,11 @@ int dba_corr_sheared_plane_elems(int h1, int w1);
 /* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 1 = streaming
  * (64-pixel-wide rows only, falls back to resident otherwise), 2 = resident.  Process-wide; results are bit-identical. */
 int dba_corr_lookup_select(int kernel);
+/* Measurement hook: the next dba_corr_lookup_pyramid_sheared call of this thread attaches the two hipEvent_t to its
+ * kernel dispatch (hipExtLaunchKernelGGL: the dispatch's own start / end timestamps, no marker packets in the stream),
+ * then disarms.  hipEventElapsedTime(start, stop) is the kernel's duration; bench.py times the roofline kernel this
+ * way in every timed step.  NULL, NULL disarms. */
+int dba_corr_lookup_arm_timing(void *start_event, void *stop_event);
 /* Fused build of the sheared pyramid straight from the feature maps (csrc/corr_build_fused.hip): MFMA GEMM,
  * 2x2 pooling of the rounded levels and the flow-aligned store in one pass; every output byte is written once.
  * Supported when dba_corr_volume_build_sheared_supported(...) returns 1 (w2 <= 128, C % 16 == 0, 4 levels, every

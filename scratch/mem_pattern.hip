@@ -12,6 +12,8 @@ __device__ __forceinline__ unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7f
 
 // RMODE 0: none, 1: [dy][dx][strip] (line stride 8 KB), 2: [dy][strip][dx] (lines of a row contiguous)
 // WMODE 0: none, 1: 49 lines x 2 B/lane, 2: 4 B/lane to two planes, 3: wave = 2 strips, 4 B/lane (256 B per plane), 4: linear
+// aux bit 0: nt loads; bit 1: the window origin depends on a value loaded first (the lookup's coords -> address chain);
+// bit 2: per-lane predicates trim ~25 % of the 16-byte pieces (the lookup's per-group trimming)
 template <int RMODE, int WMODE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k(const char* __restrict__ vol, char* __restrict__ out, int E, unsigned* sink, int aux) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,8 +29,13 @@ __global__ __launch_bounds__(WAVES * 64) void k(const char* __restrict__ vol, ch
   const char* vb = vol + ((size_t)lvl * E + e) * EDGE;
   unsigned acc = 0;
   if (RMODE) {
-    const unsigned h = hash32(sid * 4 + lvl);
+    unsigned h = hash32(sid * 4 + lvl);
+    if (aux & 2) {  // dependent chain: 8 bytes per lane from a coords-like array, the origin comes out of it
+      const unsigned long long c = ((const unsigned long long*)out)[(size_t)(sid % (E * 64)) * 64 + lane];
+      h += (unsigned)__builtin_amdgcn_readfirstlane((int)(c & 3));
+    }
     const int dy0 = h % 50, dx0 = (h >> 8) % 50;
+    const bool trim = (aux & 4) != 0;
     for (int ss = 0; ss < strips_per_wave; ss++) {
       u4v v[NY * 2];
 #pragma unroll
@@ -39,7 +46,8 @@ __global__ __launch_bounds__(WAVES * 64) void k(const char* __restrict__ vol, ch
           size_t off;
           if (RMODE == 1) off = ((size_t)(dy0 + r) * 64 + dx0 + jx) * 8192 + (size_t)(s + ss) * 128 + sub * 16;
           else off = (((size_t)(dy0 + r) * 64 + (s + ss)) * 64 + dx0 + jx) * 128 + sub * 16;
-          v[r * 2 + t] = (jx < NX) ? (aux ? __builtin_nontemporal_load((const u4v*)(vb + off)) : *(const u4v*)(vb + off)) : u4v{0, 0, 0, 0};
+          const bool need = (jx < NX) && !(trim && ((hash32(lane * 31 + r * 7 + t) & 3) == 0));
+          v[r * 2 + t] = need ? ((aux & 1) ? __builtin_nontemporal_load((const u4v*)(vb + off)) : *(const u4v*)(vb + off)) : u4v{0, 0, 0, 0};
         }
 #pragma unroll
       for (int i = 0; i < NY * 2; i++) acc += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
@@ -98,5 +106,10 @@ int main(int argc, char** argv) {
   RUN("read [dy][strip][dx] + write 2 B/lane", 2, 1, 4, 0);
   RUN("read [dy][strip][dx] + write 2 strips", 2, 3, 4, 0);
   RUN("read [dy][strip][dx] + write linear", 2, 4, 4, 0);
+  RUN("read [dy][dx][strip] + write 2 B/lane, origin from a loaded value", 1, 1, 4, 2);
+  RUN("read [dy][dx][strip] + write 2 B/lane, 25 % of the pieces trimmed", 1, 1, 4, 4);
+  RUN("read [dy][dx][strip] + write 2 B/lane, both", 1, 1, 4, 6);
+  RUN("read [dy][dx][strip] + write 2 B/lane, both, 8 waves / workgroup", 1, 1, 8, 6);
+  RUN("read [dy][dx][strip] + write 2 B/lane, both, 1 wave / workgroup", 1, 1, 1, 6);
   return 0;
 }
