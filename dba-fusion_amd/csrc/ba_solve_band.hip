@@ -71,8 +71,8 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
 #endif
                                                                    ) {
 #ifdef PROFILE_SOLVE
-#define BPROF(slot) do { if (threadIdx.x == 0) { long long t_ = wall_clock64(); prof[slot] += t_ - tprev_; tprev_ = t_; } } while (0)
-  long long tprev_ = wall_clock64();
+#define BPROF(slot) do { if (threadIdx.x == 0) { long long t_ = wall_clock64(), c_ = clock64(); prof[slot] += t_ - tprev_; prof[8 + slot] += c_ - cprev_; tprev_ = t_; cprev_ = c_; } } while (0)
+  long long tprev_ = wall_clock64(), cprev_ = clock64();
 #else
 #define BPROF(slot)
 #endif
@@ -162,20 +162,21 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       flags[1] = (SLOTS == 1 && 2 * total <= nt) ? 2 : 4;
       if (total > nt * SLOTS) flags[2] = 1;
     }
-  } else if (wave == 1) {  // panels: rows 4K .. 4 hiK[K] + 3 of the banded part, then the 4 rows of the last tile (+2: skew)
+  } else if (wave == 1) {  // panels: rows 4K .. 4 hiK[K] + 3 of the banded part, two zero rows (what the substitution
+                           // reads for pivots below the panel), then the 4 rows of the last tile (+2: skew)
     int c[3], tot = 0;    // npairs <= 192: three per lane
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int sp = 3 * lane + q;
       const int Kq = min(sp >> 1, KT - 1);
-      c[q] = (sp < npairs) ? 2 * (4 * (min(hiK[Kq], Tl - 1) - Kq + 1) + 4) + 2 : 0;
+      c[q] = (sp < npairs) ? 2 * (4 * (min(hiK[Kq], Tl - 1) - Kq + 1) + 2 + 4) + 2 : 0;
       tot += c[q];
     }
     int big = max(c[0], max(c[1], c[2]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) big = max(big, __shfl_xor(big, off, 64));
     const int incl = bd_wave_scan(tot, lane);
-    int run = 2 + incl - tot;  // C[0..1] stay zero: the substitution reads them for coefficients outside the skyline
+    int run = 2 + incl - tot;  // (C[0..1] stay zero)
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int sp = 3 * lane + q;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       if (valid[q] && I[q] == 0 && K[q] == 0 && (W == 4 || hh == 0)) publish_pinv(0, a[q][0][0], a[q][1][0], a[q][1][1]);
     // panel offset and the slot of the last row tile are read one step ahead (they sit on the chain otherwise)
     int pcur = poff[0], pnxt = 0;
-    int last0 = 4 * (min(hiK[0], Tl - 1) - 0 + 1), lastn = 0;  // panel slot of the first row of the last row tile
+    int last0 = 4 * (min(hiK[0], Tl - 1) - 0 + 1) + 2, lastn = 0;  // panel slot of the first row of the last row tile
     for (int Ks = 0; Ks < KT; Ks++) {
       auto step = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         }
         __syncthreads();
         pnxt = poff[min(s + 1, npairs)];
-        if (h == 0) lastn = 4 * (min(hiK[min(Ks + 1, KT - 1)], Tl - 1) - (Ks + 1) + 1);
+        if (h == 0) lastn = 4 * (min(hiK[min(Ks + 1, KT - 1)], Tl - 1) - (Ks + 1) + 1) + 2;
         const bool later = (W == 4) ? (h == 0) : (hh == 1 && h == 0);  // columns right of the pair inside column tile Ks
         const bd2 pv = *(const bd2 *)(pinv + 4 * s);
         const double p00 = pv.x, p01 = pv.y, p11 = pinv[4 * s + 2];
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   constexpr int RMAX = BD_MAX_N / 64;
   double t[RMAX], xo[RMAX];
   int cb[RMAX], cl[RMAX];  // C(i, j) = C[cb + 2 i] for banded rows i, C[cl + 2 i] for rows of the last tile
+  int cap[RMAX];           // pair index of the two zero rows behind the banded rows of column j's panel
   const int Rn = (n + 63) >> 6;
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -368,7 +370,9 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     const int jc = (j < n) ? j : 0;
     const int Kc = jc >> 2;
     cb[r] = poff[jc >> 1] - 8 * Kc + (jc & 1);
-    cl[r] = poff[jc >> 1] + 8 * (min(hiK[Kc], Tl - 1) - Kc + 1) - 8 * Tl + (jc & 1);
+    const int hi = min(hiK[Kc], Tl - 1);
+    cl[r] = poff[jc >> 1] + 8 * (hi - Kc + 1) + 4 - 8 * Tl + (jc & 1);
+    cap[r] = 2 * hi + 2;
     t[r] = (j < n) ? Cs[cl[r] + 2 * n] : 0.0;
     xo[r] = 0.0;
   }
@@ -376,17 +380,19 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     constexpr int r0 = decltype(rc)::value;
     const int shi = min(npairs, 32 * (r0 + 1)) - 1, slo = 32 * r0;
     struct Ops { double l0[r0 + 1], l1[r0 + 1], p[3]; };
+    // Operands of pivot pair s for the lane's columns: a pivot below the banded rows of a column's panel reads the two
+    // zero rows kept behind them (slots inside the panel but outside the pivot row's own skyline were zero-filled and
+    // never written).  Columns right of the pivot are solved: what they read (some other panel) lands in a t nobody
+    // looks at again.  Two VALU instructions per column group: the substitution is bound by the instruction issue of
+    // its single wave, and masks / a skyline look-up per step cost more than the step's arithmetic.
     auto fetch = [&](int s, Ops &o) {
-      const int sc = max(s, 0), Is = sc >> 1;  // row tile of the pivot rows 2 sc, 2 sc + 1
-      const int jlo = 4 * first[Is];           // columns left of it that the rows can touch
+      const int sc = max(s, 0);
+      const bool lastrow = ((sc >> 1) == Tl);  // pivot rows inside the last row tile: every panel has them
 #pragma unroll
       for (int r = 0; r <= r0; r++) {
-        const int j = lane + 64 * r;
-        const bool in = (j >= jlo) && (j < 2 * sc);
-        const int base = (Is == Tl) ? cl[r] : cb[r];
-        const double *q = Cs + (in ? base + 4 * sc : 0);  // outside the skyline: the zero pair at the start
-        o.l0[r] = q[0];
-        o.l1[r] = in ? q[2] : 0.0;
+        const int at = lastrow ? cl[r] + 4 * sc : cb[r] + 4 * min(sc, cap[r]);
+        o.l0[r] = Cs[at];
+        o.l1[r] = Cs[at + 2];
       }
       o.p[0] = pinv[4 * sc], o.p[1] = pinv[4 * sc + 1], o.p[2] = pinv[4 * sc + 2];
     };

@@ -42,7 +42,7 @@ int run(int n, int band, bool spd, bool timeit) {
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("%s n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", use_tile ? "tile" : "band", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
   if (getenv("HARNESS_DUMP") && n <= 64) { for (int i = 0; i < n; i++) printf("    x[%2d] dev % .6e ref % .6e%s\n", i, x[i], ok ? xr[i] : 0.0, fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6 ? "  <--" : ""); }
-  if (timeit) { long long hp[12]; hipMemcpy(hp, dba::g_band_prof, 96, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld\n", hp[0],hp[1],hp[2],hp[3],hp[4]); }
+  if (timeit) { long long hp[16]; hipMemcpy(hp, dba::g_band_prof, 128, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld   shader cycles: factor %lld backsub %lld (%.2f GHz)\n", hp[0],hp[1],hp[2],hp[3],hp[4], hp[11], hp[12], hp[3] ? hp[11] / (hp[3] * 10.0) : 0.0); }
   hipMemset(dba::g_band_prof, 0, 128);
   if (timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
