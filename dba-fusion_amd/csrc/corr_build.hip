@@ -26,9 +26,11 @@ namespace dba {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-// [n][C][HW] -> [n][C/16][HW][16], value / 4 rounded to half (corr.py:67-68); C is a multiple of 16
+// [n][C][HW] -> [n][C/kb][HW][kb] (kb = 16 everywhere today; blocks of 8 for the target map, so that a half wave's
+// fragment loads are 512 contiguous bytes, were measured and change nothing), value / 4 rounded to half
+// (corr.py:67-68); C is a multiple of 16
 __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
-                                                               _Float16 *__restrict__ out, int C, int HW) {
+                                                               _Float16 *__restrict__ out, int C, int HW, int kb) {
   __shared__ _Float16 tile[64][66];
   const int e = blockIdx.z;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *_
   __syncthreads();
   for (int r = threadIdx.x >> 6; r < 64; r += 4) {  // r: pixel within tile, lane: channel
     const int p = p0 + r, c = c0 + (threadIdx.x & 63);
-    if (p < HW && c < C) dst[((size_t)(c >> 4) * HW + p) * 16 + (c & 15)] = tile[threadIdx.x & 63][r];
+    if (p < HW && c < C) dst[((size_t)(c / kb) * HW + p) * kb + (c % kb)] = tile[threadIdx.x & 63][r];
   }
 }
 
@@ -142,9 +144,9 @@ int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *lev
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1);
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16);
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2);
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16);
   hipLaunchKernelGGL(corr_gemm_kernel, dim3((HW2 + 127) / 128, (HW1 + 127) / 128, n), dim3(256), 0, s, A, Bm,
                      static_cast<_Float16 *>(levels[0]), C, HW1, HW2);
   DBA_LAUNCH_CHECK();

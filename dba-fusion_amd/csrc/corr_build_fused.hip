@@ -24,12 +24,20 @@
 //     LDS (two barriers) for the sheared store loops;
 //   * the strip's source operand (16 KB at C = 128) is staged ONCE per workgroup in the LDS the tile will take, and the
 //     target fragments are requested two k-steps ahead.
-// Where the time goes (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges, per workgroup of 42.7 k cycles): source operand
-// 4.6 k, MFMA phase 15.4 k (of which the target-fragment loads 12.7 k: 16 KB per wave out of L2 at ~20 B/clk/CU; the 32
-// MFMAs per wave alone 6.6 k), tile write 2.3 k, level-0 stores 8.3-9.7 k, pooled levels 8.8-9.7 k (the CU's store path
-// takes ~10 B/clk whatever the store width).  All of these share the CU's vector memory pipe, so they add up: 24 us per
-// edge = 1.9 TB/s of output, 0.24 of the HBM peak.  Running the two co-resident workgroups out of phase (staggered
-// start) changes nothing; halving the fragment traffic needs a 128-pixel tile (132 KB of LDS, one workgroup per CU).
+// Where the time goes (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges; a workgroup lives 47 k cycles, two per CU):
+// source operand 9 %, MFMA phase 43 % (the 32 MFMAs per wave need a third of it; the rest is the target fragments,
+// 16 KB per wave out of L2 at ~20 B/clk/CU), tile write 6 %, level-0 stores 25 %, pooled levels 13 %, drain 3 %.
+// 19.8 us per edge = 2.36 TB/s of output, 0.295 of the HBM peak (round 1: 23.3 us; before the store loops below were
+// cut from ~70 to ~10 VALU instructions per 8-byte store: 22.6 us, 1935 VALU instructions per wave, VALU busy 64 %).
+// What was measured and did not help (scratch/cu_rates.hip, scratch/lds_rates.hip, scratch/corr_build_pipe_experiment.hip):
+//   * one CU alone stores 28 B/clk, the whole chip 5.4-5.6 TB/s = 9 B/clk/CU: in the store phases, which all
+//     workgroups enter together, the chip is at HBM's write ceiling, in the MFMA phases HBM idles.  A persistent,
+//     wave-specialised form (8 compute + 8 store waves, tile double-buffered in LDS, stores of tile i - 1 issued while
+//     tile i is multiplied) was built and is bit-exact, but runs at 20.5-21.5 us/edge: its waves wait 63 % of their
+//     cycles at the three barriers that couple the roles (VALU busy 28 %, LDS busy 17 %);
+//   * target map in blocks of 8 channels (a half wave's fragment load = 512 contiguous bytes): no change;
+//   * staggered start of the two co-resident workgroups, 4-deep fragment prefetch: no change.
+// Halving the fragment traffic needs a 128-pixel tile (132 KB of LDS, one workgroup per CU).
 // Shapes: w2 <= 128, C % 16 == 0, 4 levels, h2 >> 3 >= 1, w2 >> 3 >= 1; anything else takes the unfused path of
 // corr_build.hip + corr_shear_kernel.
 #include <hip/hip_runtime.h>
@@ -76,8 +84,8 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
 #endif
   FB_STAMP(0);
   constexpr int W2P = 32 * NT;               // tile columns (targets beyond w2 are computed and never read)
-  constexpr int PITCH = FT_ROWS * W2P + 4;   // halves per source pixel (+4: the 32 lanes of an 8-byte accumulator write
-                                             // land in 32 different bank pairs)
+  constexpr int RP = W2P + 4;                // tile row: the w2 columns, then columns 0..3 once more (level-0 store loop)
+  constexpr int PITCH = FT_ROWS * RP + 4;    // halves per source pixel
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   _Float16 *T = smem;                              // [64][PITCH]  level 0, rounded; before that: the strip's A operand
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -163,8 +171,18 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
         half4 v;
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = (_Float16)acc[i][j][4 * rq + q];
-        *reinterpret_cast<half4 *>(T + src * PITCH + wave * W2P + tx) = v;
+        *reinterpret_cast<half4 *>(T + src * PITCH + wave * RP + tx) = v;
       }
+  // columns 0..3 once more behind column w2 - 1 (after the row's own writes: for w2 < W2P those put unused targets
+  // there): a store lane's four diagonal reads then never wrap inside a quad
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      _Float16 *wr = T + (i * 32 + l31) * PITCH + wave * RP + w2;
+#pragma unroll
+      for (int q = 0; q < 4; q++) wr[q] = (_Float16)acc[i][0][q];
+    }
+  }
   lds_barrier();  // the last barrier: everything below reads the tile only
   FB_STAMP(3);
 
@@ -223,7 +241,10 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     }
   };
 
-  // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's own target row ----
+  // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's own target row.  A lane's
+  // quad of pixels reads the tile along a diagonal (pixel + 1, column + 1); with columns 0..3 replicated behind the row
+  // only the first column wraps, once per line, and the store offset just advances by four planes: ~10 VALU
+  // instructions per 8-byte store where the general form (kept for quads that span a row end) needs ~70 ----
   {
     const int ty = ty0 + wave;
 #ifdef FB_ABLATE_L0STORE
@@ -232,18 +253,48 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     if (ty < h2) {  // (wave-uniform)
 #endif
       const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
-      const _Float16 *row = quad + wave * W2P;
-      for (int dx0 = 0; dx0 < w2; dx0 += 4) {
-        const int dx = dx0 + g;
-        _Float16 v[4];
+      if (quad_regular) {
+        int t = qx[0] + g;
+        t -= (t >= w2) ? w2 : 0;
+        int dy = ty - qy[0];
+        dy += (dy < 0) ? h2 : 0;
+        unsigned voff = ((unsigned)dy * (unsigned)w2 + (unsigned)g) * plane_bytes + 2u * (unsigned)(p0 + q4);
+        const _Float16 *lb = T + q4 * PITCH + wave * RP;
+        for (int dx0 = 0; dx0 < w2; dx0 += 16) {  // four lines per batch: their 16 LDS reads are in flight together
+          unsigned short a[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          int tx = qx[i] + dx;
-          tx -= (tx >= w2) ? w2 : 0;
-          tx = min(tx, w2 - 1);  // (dx beyond the map in the last group of four: read something valid, store nothing)
-          v[i] = row[i * PITCH + tx];
+          for (int b = 0; b < 4; b++) {
+            const _Float16 *pp = lb + t;
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
+            t += 4;
+            t -= (t >= w2) ? w2 : 0;
+          }
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            u2v d;
+            d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
+            d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r0, (dx0 + 4 * b + g < w2) ? voff : OOR, 0, 0);
+            voff += 4u * plane_bytes;
+          }
         }
-        store_quad(r0, 0, ty, dx, h2, w2, v[0], v[1], v[2], v[3], dx < w2);
+      }
+      if (!quad_regular) {
+        const _Float16 *row = quad + wave * RP;
+        for (int dx0 = 0; dx0 < w2; dx0 += 4) {
+          const int dx = dx0 + g;
+          _Float16 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            int tx = qx[i] + dx;
+            tx -= (tx >= w2) ? w2 : 0;
+            tx = min(tx, w2 - 1);  // (dx beyond the map in the last group of four: read something valid, store nothing)
+            v[i] = row[i * PITCH + tx];
+          }
+          store_quad(r0, 0, ty, dx, h2, w2, v[0], v[1], v[2], v[3], dx < w2);
+        }
       }
     }
   }
@@ -252,8 +303,9 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
   // the tile, the level-0 stores included, is done) the values take the tile's place in LDS, after a second one the
   // three sheared store loops read them.  (Pooling every element in the lane that stores it needs no barrier at all
   // but 2.4x the arithmetic -- the kernel is bound by VALU issue, 1935 instructions per wave before, see the header.)
-  _Float16 *P1 = T;                                // [64][4][W2P / 2]
-  _Float16 *P2 = P1 + 64 * 4 * (W2P / 2);          // [64][2][W2P / 4]
+  constexpr int RP1 = W2P / 2 + 4;                 // level-1 row: w2 >> 1 columns, then columns 0..3 once more
+  _Float16 *P1 = T;                                // [64][4][RP1]
+  _Float16 *P2 = P1 + 64 * 4 * RP1;                // [64][2][W2P / 4]
   _Float16 *P3 = P2 + 64 * 2 * (W2P / 4);          // [64][W2P / 8]
   constexpr int NBLK = W2P / 8;                    // 8-column blocks per pixel
   constexpr int PER = 64 * NBLK / 512;             // blocks per thread (1 for 64-wide tiles, 2 for 128-wide)
@@ -265,7 +317,7 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     _Float16 t8[8][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const half4 lo = *reinterpret_cast<const half4 *>(tb + r * W2P), hi = *reinterpret_cast<const half4 *>(tb + r * W2P + 4);
+      const half4 lo = *reinterpret_cast<const half4 *>(tb + r * RP), hi = *reinterpret_cast<const half4 *>(tb + r * RP + 4);
 #pragma unroll
       for (int c = 0; c < 4; c++) t8[r][c] = lo[c], t8[r][4 + c] = hi[c];
     }
@@ -289,7 +341,18 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
       half4 v;
 #pragma unroll
       for (int c = 0; c < 4; c++) v[c] = q1[u][r][c];
-      *reinterpret_cast<half4 *>(P1 + (src * 4 + r) * (W2P / 2) + 4 * cb) = v;
+      _Float16 *row1 = P1 + (src * 4 + r) * RP1;
+      if (4 * cb + 4 <= (w2 >> 1)) {
+        *reinterpret_cast<half4 *>(row1 + 4 * cb) = v;
+      } else {  // the block that holds column (w2 >> 1) - 1: the columns behind it belong to the copy of block 0
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          if (4 * cb + c < (w2 >> 1)) row1[4 * cb + c] = q1[u][r][c];
+      }
+      if (cb == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) row1[(w2 >> 1) + c] = q1[u][r][c];
+      }
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -302,23 +365,51 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
   lds_barrier();
   FB_STAMP(4);
 #ifndef FB_ABLATE_POOLSTORE
-  {  // level 1: 4 rows x (w2 >> 1) offsets, four lines per store instruction
+  {  // level 1: 4 rows x (w2 >> 1) offsets, four lines per store instruction; wave w takes row w & 3 and every other
+     // group of four offsets.  The quad's columns (x >> 1) - (x0 >> 1) are 0, 0|1, 1, 1|2: lane constants
     const int w2l = w2 >> 1, h2l = h2 >> 1;
     const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
-    const int groups = (w2l + 3) >> 2;  // groups of four dx per row
-    for (int sg = wave; sg < 4 * groups; sg += 8) {
-      const int tyl = sg / groups, dx = (sg - tyl * groups) * 4 + g;
-      const int tyg = (ty0 >> 1) + tyl;
-      if (tyg >= h2l) continue;  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
-      _Float16 v[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        int tx = (qx[i] >> 1) + dx;
-        tx -= (tx >= w2l) ? w2l : 0;
-        tx = min(tx, w2l - 1);
-        v[i] = P1[((q4 + i) * 4 + tyl) * (W2P / 2) + tx];
+    const int tyl = wave & 3, tyg = (ty0 >> 1) + tyl;
+    if (tyg < h2l) {  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
+      if (quad_regular) {
+        const int xh = qx[0] >> 1;
+        const int o1 = (qx[1] >> 1) - xh, o2 = (qx[2] >> 1) - xh, o3 = (qx[3] >> 1) - xh;
+        int t = xh + 4 * (wave >> 2) + g;
+        t -= (t >= w2l) ? w2l : 0;
+        t -= (t >= w2l) ? w2l : 0;  // (maps down to 8 columns: twice)
+        int dy = tyg - (qy[0] >> 1);
+        dy += (dy < 0) ? h2l : 0;
+        unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * (wave >> 2) + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+        const _Float16 *lb = P1 + (q4 * 4 + tyl) * RP1;
+        for (int dx0 = 4 * (wave >> 2); dx0 < w2l; dx0 += 8) {
+          const _Float16 *pp = lb + t;
+          const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
+          const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          u2v d;
+          d.x = (unsigned)a0 | ((unsigned)a1 << 16);
+          d.y = (unsigned)a2 | ((unsigned)a3 << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(d, rl, (dx0 + g < w2l) ? voff : OOR, 0, 0);
+          voff += 8u * plane_bytes;
+          t += 8;
+          t -= (t >= w2l) ? w2l : 0;
+          t -= (t >= w2l) ? w2l : 0;
+        }
       }
-      store_quad(rl, 1, tyg, dx, h2l, w2l, v[0], v[1], v[2], v[3], dx < w2l);
+      if (!quad_regular) {
+        for (int dx0 = 4 * (wave >> 2); dx0 < w2l; dx0 += 8) {
+          const int dx = dx0 + g;
+          _Float16 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            int tx = (qx[i] >> 1) + dx;
+            tx -= (tx >= w2l) ? w2l : 0;
+            tx = min(tx, w2l - 1);
+            v[i] = P1[((q4 + i) * 4 + tyl) * RP1 + tx];
+          }
+          store_quad(rl, 1, tyg, dx, h2l, w2l, v[0], v[1], v[2], v[3], dx < w2l);
+        }
+      }
     }
   }
   // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
@@ -350,7 +441,7 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
 }
 
 // defined in corr_build.hip
-__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW);
+__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb);
 
 }  // namespace dba
 
@@ -380,9 +471,9 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1);
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16);
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2);
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16);
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
   const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
@@ -404,10 +495,10 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
 #define FB_PROF_ARG
 #endif
   if (w2 <= 64) {
-    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * 64 + 4);  // the pooled levels live inside the dead tile
+    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
     hipLaunchKernelGGL((corr_build_fused_kernel<2>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
   } else {
-    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * 128 + 4);
+    const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
     hipLaunchKernelGGL((corr_build_fused_kernel<4>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
