@@ -166,17 +166,17 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
   // than kx can have entries cannot be right (the exact |kx| is only known on the device: see droid_backends._ba_args)
   if (eta_rows > 1 && eta_rows > plan.T.Mmax) return DBA_ERR_ARG;
   if (N > 0 && (!targets || !weights || !jj)) return DBA_ERR_ARG;
-  dim3 grid(plan.nchunks, plan.T.Mmax + 1);
-#define LAUNCH_LIN(PPL, MF)                                                                                   \
-  hipLaunchKernelGGL((ba_linearize_kernel<PPL, MF>), grid, dim3(256), 0, (hipStream_t)stream, poses, disps,    \
-                     intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, plan.HW, wd, \
-                     t0, plan.P, alpha, plan.T, plan.W)
+  // (EW waves share a pixel slice and split the frame's edges: EW times as many workgroups of four waves)
+#define LAUNCH_LIN(PPL, MF, EW)                                                                                \
+  hipLaunchKernelGGL((ba_linearize_kernel<PPL, MF, EW>), dim3(plan.nchunks * EW, plan.T.Mmax + 1), dim3(256), 0, \
+                     (hipStream_t)stream, poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, \
+                     frame_owned, N, plan.HW, wd, t0, plan.P, alpha, plan.T, plan.W)
   // one pixel per lane: the per-edge sums run on the matrix cores (DBA_LINEARIZE_MFMA=0 keeps the LDS transpose-reduce)
   static const bool no_mfma = [] { const char *e = getenv("DBA_LINEARIZE_MFMA"); return e && e[0] == '0'; }();
-  if (plan.W.ppl == 4) LAUNCH_LIN(4, false);
-  else if (plan.W.ppl == 2) LAUNCH_LIN(2, false);
-  else if (no_mfma) LAUNCH_LIN(1, false);
-  else LAUNCH_LIN(1, true);
+  if (plan.W.ppl == 4) LAUNCH_LIN(4, false, 1);
+  else if (plan.W.ppl == 2) LAUNCH_LIN(2, false, 1);
+  else if (no_mfma) LAUNCH_LIN(1, false, 1);
+  else LAUNCH_LIN(1, true, 2);
 #undef LAUNCH_LIN
   DBA_LAUNCH_CHECK();
   return DBA_OK;

@@ -59,7 +59,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
 // kernels (ba_kernels.hip / ba_solve.hip)
 __global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1,
                                   BaTables T);
-template <int PPL, bool MF>
+template <int PPL, bool MF, int EW>
 __global__ void ba_linearize_kernel(const float *poses, const float *disps, const float *intrinsics,
                                     const float *disps_sens, const float *targets, const float *weights,
                                     const float *eta, int eta_rows, const int64_t *jj,

@@ -18,6 +18,9 @@
 //     LDS-resident blocked Cholesky in float64.
 #include "ba_kernels.h"
 
+#include <cstdio>
+#include <cstring>
+
 namespace dba {
 
 // ---------------------------------------------------------------------------------------------
@@ -372,13 +375,28 @@ constexpr int MFS_P = 36;                      // row pitch in floats: the 16 ro
 constexpr int MFS_VALS = 4 * 16 * MFS_P;       // staged [k][i][t]
 constexpr int MFS_FLOATS = MFS_VALS + 4 * MFS_P;  // + weights [k][t]
 
-template <int PPL, bool MF>
+#ifdef LIN_PROF
+__device__ unsigned long long g_lin_prof[16];
+__device__ unsigned long long g_lin_span[2 * 8192];
+#define LP(k) do { if (threadIdx.x == 0 && blockIdx.x == 3) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_lin_prof[k], t_ - lp_); lp_ = t_; } } while (0)
+#else
+#define LP(k) (void)0
+#endif
+// EW: waves that share one pixel slice and split the frame's out-edges among them (1 or 2).  A wave spends ~7 k cycles
+// per edge, nearly all of it dependent latency, and the kernel lasts as long as the busiest frame's edge walk: with two
+// waves per slice that walk is half as long and twice as many waves hide each other's latency; their per-frame sums
+// (C, w, Ei, Hii, vi) meet in LDS at the end.
+template <int PPL, bool MF, int EW>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const float *__restrict__ poses, const float *__restrict__ disps, const float *__restrict__ intrinsics,
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
     const float *__restrict__ weights, const float *__restrict__ eta, int eta_rows,
     const int64_t *__restrict__ jj, const uint8_t *__restrict__ frame_owned, int N, int HW, int wd,
     int t0, int P, float alpha, BaTables T, BaBuffers W) {
+#ifdef LIN_PROF
+  unsigned long long lp_ = wall_clock64();
+  const unsigned long long lp_start_ = lp_;
+#endif
   const int m = blockIdx.y;
   if (m == T.Mmax) {  // extra row of workgroups: clear the reduced camera system for stage 2
     const int n6 = 6 * P;
@@ -395,7 +413,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
   if (frame_owned && !frame_owned[frame]) return;
 
   const int lane = lane_id();
-  const int wave_global = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);  // pixel slice id
+  const int wv = threadIdx.x >> 6, ew = wv % EW;  // ew: which share of the edges this wave takes
+  const int wave_global = blockIdx.x * (4 / EW) + wv / EW;  // pixel slice id
   const int kbase = wave_global * (WAVE * PPL) + lane;  // pixels kbase + 64 q: each q is a coalesced segment
   const int nparts = W.nparts;
 
@@ -425,21 +444,25 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #pragma unroll
   for (int i = 0; i < 27; i++) fsum[i] = 0.f;
 
-  // The out-edges of the frame are resolved in batches of up to 64 by the first wave, one edge per lane
+  // The out-edges of the frame are resolved in batches of up to EB by the first wave, one edge per lane
   // (elist -> jj -> poses is a chain of three dependent global loads: paid once per batch, not per edge);
   // the per-edge relative pose then comes out of LDS, and the next edge's targets/weights are in flight
   // while the current edge is being reduced.
-  __shared__ float s_pose[64][12];  // tij[3], R[9]
-  __shared__ int s_edge[64][2];     // edge id, target frame
+  constexpr int EB = 16;            // (16, not 64: with the staging tiles below the workgroup then needs 40 KB of LDS and
+                                    // four of them fit a CU: every workgroup of a 25-keyframe window is resident at once)
+  __shared__ float s_pose[EB][12];  // tij[3], R[9]
+  __shared__ int s_edge[EB][2];     // edge id, target frame
   constexpr int RED_FLOATS = MF ? MFS_FLOATS : 64 * RED_PITCH;
   __shared__ __attribute__((aligned(16))) float s_red[4][RED_FLOATS];  // per-wave transpose tiles / MFMA staging
-  float *red_wave = s_red[threadIdx.x >> 6];
+  float *red_wave = s_red[wv];
   float *red_lane = red_wave + lane;
   lin_f4 facc = {0.f, 0.f, 0.f, 0.f};  // MF: rows 0..5 of the block (frame sums), accumulated over the edges
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
-  for (int batch = e0; batch < e1; batch += 64) {
-    const int cnt = min(64, e1 - batch);
+  LP(0);
+  for (int batch = e0; batch < e1; batch += EB) {
+    const int cnt = min(EB, e1 - batch);
     __syncthreads();
+    LP(1);
     if ((int)threadIdx.x < cnt) {
       const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * (batch + threadIdx.x));
       const int n = ei.x, jx = ei.y;
@@ -454,9 +477,10 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
       for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = R.r[c];
     }
     __syncthreads();
+    LP(2);
     float nx_t[PPL][2], nx_w[PPL][2];  // prefetched targets / weights of the next edge
     {
-      const int n = s_edge[0][0];
+      const int n = s_edge[min(ew, cnt - 1)][0];
 #pragma unroll
       for (int q = 0; q < PPL; q++) {
         const size_t tb = (size_t)n * 2 * HW + kc[q];
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
         nx_w[q][1] = weights[tb + HW];
       }
     }
-    for (int i = 0; i < cnt; i++) {
+    for (int i = ew; i < cnt; i += EW) {
       const int n = s_edge[i][0];
       const int jx = s_edge[i][1];
       float tij[3];
@@ -481,8 +505,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
         cu_t[q][0] = nx_t[q][0]; cu_t[q][1] = nx_t[q][1];
         cu_w[q][0] = nx_w[q][0]; cu_w[q][1] = nx_w[q][1];
       }
-      if (i + 1 < cnt) {
-        const int nn = s_edge[i + 1][0];
+      if (i + EW < cnt) {
+        const int nn = s_edge[i + EW][0];
 #pragma unroll
         for (int q = 0; q < PPL; q++) {
           const size_t tb = (size_t)nn * 2 * HW + kc[q];
@@ -599,6 +623,50 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
 #endif
       }
       W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
+      LP(3);
+    }
+  }
+  LP(4);
+  if constexpr (EW > 1) {
+    // the other waves of the slice hand their per-frame sums over through their (now idle) staging tiles
+    constexpr int NV = 8 * PPL + (MF ? 4 : 27);
+    __syncthreads();
+    if (ew != 0) {
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        red_lane[(8 * q + 0) * 64] = Csum[q];
+        red_lane[(8 * q + 1) * 64] = wsum[q];
+#pragma unroll
+        for (int c = 0; c < 6; c++) red_lane[(8 * q + 2 + c) * 64] = Ei[q][c];
+      }
+      if constexpr (MF) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red_lane[(8 * PPL + r) * 64] = facc[r];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 27; i++) red_lane[(8 * PPL + i) * 64] = fsum[i];
+      }
+    }
+    __syncthreads();
+    if (ew != 0) return;
+    static_assert(NV * 64 <= RED_FLOATS, "hand-over does not fit the staging tile");
+#pragma unroll
+    for (int o = 1; o < EW; o++) {
+      const float *src = s_red[wv + o] + lane;
+#pragma unroll
+      for (int q = 0; q < PPL; q++) {
+        Csum[q] += src[(8 * q + 0) * 64];
+        wsum[q] += src[(8 * q + 1) * 64];
+#pragma unroll
+        for (int c = 0; c < 6; c++) Ei[q][c] += src[(8 * q + 2 + c) * 64];
+      }
+      if constexpr (MF) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) facc[r] += src[(8 * PPL + r) * 64];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 27; i++) fsum[i] += src[(8 * PPL + i) * 64];
+      }
     }
   }
   if constexpr (MF) {
@@ -641,18 +709,50 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
       for (int c = 0; c < 6; c++) Er[(size_t)c * HW] = Ei[q][c];
     }
   }
+  LP(5);
+#ifdef LIN_PROF
+  if ((threadIdx.x & 63) == 0) {
+    const int slot = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & 8191;
+    g_lin_span[2 * slot] = lp_start_;
+    g_lin_span[2 * slot + 1] = wall_clock64();
+  }
+#endif
 }
 
-template __global__ void ba_linearize_kernel<1, true>(const float *, const float *, const float *, const float *,
+#ifdef LIN_PROF
+extern "C" void dba_lin_prof_dump() {
+  unsigned long long h[16];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lin_prof), sizeof(h));
+  static unsigned long long sp[2 * 8192];
+  (void)hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_lin_span), sizeof(sp));
+  unsigned long long lo = ~0ull, hi = 0, sum = 0, cnt = 0, maxlife = 0, laststart = 0;
+  for (int i = 0; i < 8192; i++)
+    if (sp[2 * i]) {
+      lo = sp[2 * i] < lo ? sp[2 * i] : lo, hi = sp[2 * i + 1] > hi ? sp[2 * i + 1] : hi;
+      laststart = sp[2 * i] > laststart ? sp[2 * i] : laststart;
+      const unsigned long long life = sp[2 * i + 1] - sp[2 * i];
+      sum += life, cnt++, maxlife = life > maxlife ? life : maxlife;
+    }
+  fprintf(stderr, "LIN_PROF (10 ns ticks, wave 0 of slice-block 3, summed over frames): prologue %llu, sync %llu, resolve %llu, edges %llu, tail-of-loop %llu, epilogue %llu | last launch: %llu waves, first start -> last end %llu ticks, last start at +%llu, mean life %.1f, longest %llu\n",
+          h[0], h[1], h[2], h[3], h[4], h[5], cnt, hi - lo, laststart - lo, cnt ? (double)sum / cnt : 0.0, maxlife);
+  memset(h, 0, sizeof(h));
+  memset(sp, 0, sizeof(sp));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lin_span), sp, sizeof(sp));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lin_prof), h, sizeof(h));
+}
+#endif
+
+template __global__ void ba_linearize_kernel<1, true, 2>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
-template __global__ void ba_linearize_kernel<1, false>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<1, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
-template __global__ void ba_linearize_kernel<2, false>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<2, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
-template __global__ void ba_linearize_kernel<4, false>(const float *, const float *, const float *, const float *,
+template __global__ void ba_linearize_kernel<4, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
 
