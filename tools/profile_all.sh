@@ -33,7 +33,7 @@ timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SQ
 python - > $OUT/${TAG}_sq_counters.txt <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
-names = ("corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur", "ba_solve_tile", "ba_update")
+names = ("corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur", "ba_solve_tile", "ba_solve_band", "ba_update")
 for f in glob.glob("$SQ/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
@@ -50,4 +50,10 @@ cp $(ls -t $(find $OUT/${TAG}_alt_trace -name "*kernel_stats.csv") | head -1) $O
 # ceilings
 python $REPO/scratch/hbm_ceiling.py > $OUT/${TAG}_hbm_ceiling.txt 2>&1
 [ -x $REPO/scratch/bin/mem_pattern ] && $REPO/scratch/bin/mem_pattern 96 > $OUT/${TAG}_mem_pattern_96.txt 2>&1 && $REPO/scratch/bin/mem_pattern 384 > $OUT/${TAG}_mem_pattern_384.txt 2>&1
+# per-CU rates of the vector memory pipe and of LDS, dependent-chain latencies of the solver's f64 ops, solver stage times
+[ -x $REPO/scratch/bin/cu_rates ] && $REPO/scratch/bin/cu_rates > $OUT/${TAG}_cu_rates.txt 2>&1
+[ -x $REPO/scratch/bin/lds_rates ] && $REPO/scratch/bin/lds_rates > $OUT/${TAG}_lds_rates.txt 2>&1
+[ -x $REPO/scratch/bin/f64_latency ] && $REPO/scratch/bin/f64_latency > $OUT/${TAG}_f64_latency.txt 2>&1
+[ -x $REPO/scratch/bin/solve_prof ] && (HARNESS_BAND=1 $REPO/scratch/bin/solve_prof; $REPO/scratch/bin/solve_prof) 2>&1 | grep -A3 "n=144 band= 24 spd=1\|n=186\|n=378 band= 36" > $OUT/${TAG}_solver_stages.txt
+timeout 120 python $REPO/scratch/build_ab.py $TAG > $OUT/${TAG}_build_shapes.txt 2>&1
 ls -la $OUT | grep ${TAG}_ | head -50
