@@ -96,6 +96,9 @@ def main():
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()
+    # the exchange step of the sharded BA: RCCL, or (DBA_PEER_ALLREDUCE=1) the one-shot peer-read all-reduce
+    from dbaf_amd.peer import PeerDist
+    ba_dist = PeerDist.wrap(dist)
 
     # ---- workload (synthetic) -----------------------------------------------------------
     W = {"25_96": syn.window_25_96, "32_122": syn.window_32_122, "64_512": syn.window_64_512}[args.window](args.seed)
@@ -165,7 +168,7 @@ def main():
             droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep,
                               False)
         else:
-            shard.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, dist)
+            shard.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, ba_dist)
         if time_ba:
             ev[4 * i + 3].record()
         disps.clamp_(min=0.001)  # depth_video.py:560
@@ -281,7 +284,7 @@ def main():
             "config": {"workload": "synthetic TUM-VI-shape 512x512 -> %dx%d maps, %d-KF window, %d edges, "
                                    "reproject + 4-level r=3 lookup + ba(itrs=2) per step; lookups rotate over %d disjoint "
                                    "pyramid copies (MALL-cold)" % (h, w, W.num_kf, N, ncopies),
-                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
+                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world, "exchange": "peer-read" if ba_dist is not dist else "rccl",
                        "pyramid_copies": ncopies},
             "roofline": {
                 "kernel": "%s (fused 4-level r=3 lookup, f16, %d edges on rank 0, "

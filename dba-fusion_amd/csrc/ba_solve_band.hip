@@ -27,7 +27,6 @@ constexpr int BD_BIG_THREADS = 512;    // the many-tile variant: 256 VGPRs per t
 constexpr int BD_BIG_SLOTS = 3;
 constexpr int BD_INTS = 2048;          // first[100] pre[100] hiK[100] poff[196] tinfo[1536] flags[16]
 constexpr int BD_PINV = 4 * (BD_MAX_N / 2);
-constexpr int BD_CAP = (SOLVE_MAX_LDS_BYTES - BD_INTS * 4 - BD_PINV * 8) / 8;  // doubles left for the panels
 
 typedef double bd2 __attribute__((ext_vector_type(2)));
 

@@ -59,6 +59,11 @@ SYMBOLS = {
     "dba_projmap": (c_int, [_P] * 5 + [c_int] * 3 + [_P, _P, _P]),
     "dba_iproj": (c_int, [_P] * 3 + [c_int] * 3 + [_P, _P]),
     "dba_depth_filter": (c_int, [_P] * 5 + [c_int] * 4 + [_P, _P]),
+    "dba_peer_exchange_bytes": (c_size_t, [c_size_t]),
+    "dba_peer_exchange_create": (c_int, [c_size_t, ctypes.POINTER(_P), _P]),
+    "dba_peer_exchange_open": (c_int, [_P, ctypes.POINTER(_P)]),
+    "dba_peer_exchange_close": (c_int, [_P, c_int]),
+    "dba_peer_allreduce_f64": (c_int, [_P, c_size_t, _P, c_int, c_int, ctypes.c_uint, c_size_t, _P, _P]),
 }
 
 _lib = None

@@ -262,6 +262,27 @@ int dba_depth_filter(const float *poses, const float *disps, const float *intrin
                      const int64_t *inds, const float *thresh, int num, int nbuf, int ht, int wd,
                      float *counter, dba_stream_t stream);
 
+/* ---- optional exchange step of the edge-sharded driver: one-shot all-reduce by direct peer reads ------------------
+ * The reference is single-GPU (nothing to replace); SURVEY.md 8(e) asks for the float64 sum of the reduced camera
+ * system [H | b] over the ranks, which dbaf_amd/sharded.py does with RCCL by default.  These entry points are the
+ * latency-oriented alternative for one node (csrc/peer_allreduce.hip): every rank owns an exchange region that its
+ * peers map through hipIpc and sums the world's contributions itself, in rank order (bit-identical replicas).
+ *   bytes   = dba_peer_exchange_bytes(max_doubles)
+ *   create  : hipMalloc + zero + IPC handle (64 bytes) of this rank's region
+ *   open    : map a PEER process' region from its handle (not the creator's own: use the pointer `create` returned)
+ *   close   : opened != 0 -> hipIpcCloseMemHandle, else hipFree
+ *   allreduce: buf[0..n) += everybody else's, in place, enqueued on `stream`; `regions[world]` are device pointers (own
+ *             region at index `rank`), `epoch` = 1, 2, 3, ... identical on all ranks and increasing by one per call,
+ *             `status` a device int the kernel sets to DBA_PEER_TIMEOUT if a peer's contribution did not arrive within
+ *             ~2 s (buf is left untouched then). */
+#define DBA_PEER_TIMEOUT 1
+size_t dba_peer_exchange_bytes(size_t max_doubles);
+int dba_peer_exchange_create(size_t bytes, void **region, unsigned char *handle64);
+int dba_peer_exchange_open(const unsigned char *handle64, void **region);
+int dba_peer_exchange_close(void *region, int opened);
+int dba_peer_allreduce_f64(double *buf, size_t n, void *const *regions, int rank, int world, unsigned epoch,
+                           size_t max_doubles, int *status, dba_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
