@@ -104,7 +104,15 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     for (int idx = tid; idx < kblocks * 128; idx += 512) {  // 16-byte pieces: [kblock][pixel][half of the 16 channels]
       const int kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
       const half8 v = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(p0 + px, HW1 - 1)) * 16 + hf * 8);
-      *reinterpret_cast<half8 *>(T + (kbk * 64 + px) * 16 + hf * 8) = v;
+      // LDS layout [k-step][q][32-pixel block][k-half][pixel][4 halves]: a wave's fragment read is then TWO ds_read_b64 of
+      // 512 consecutive bytes each (3.4 cycles of the LDS pipe per instruction; the one ds_read_b128 at a 32-byte pitch
+      // this replaces takes 32: scratch/lds_rates.hip)
+      const int fa = ((((kbk * 2 + 0) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4;
+      half4 lo, hi;
+#pragma unroll
+      for (int c = 0; c < 4; c++) lo[c] = v[c], hi[c] = v[4 + c];
+      *reinterpret_cast<half4 *>(T + fa) = lo;
+      *reinterpret_cast<half4 *>(T + fa + 2 * 2 * 32 * 4) = hi;
     }
   }
 #endif
@@ -143,7 +151,12 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
       for (int t = 0; t < NT; t++) b2[t] = *reinterpret_cast<const half8 *>(bp[t] + (size_t)kn * 16 * kb);
       half8 a[2];
 #pragma unroll
-      for (int t = 0; t < 2; t++) a[t] = *reinterpret_cast<const half8 *>(T + (ks * 64 + t * 32 + l31) * 16 + kh);
+      for (int t = 0; t < 2; t++) {
+        const _Float16 *fp = T + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
+        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
+      }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
