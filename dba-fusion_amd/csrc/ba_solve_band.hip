@@ -12,10 +12,21 @@
 //     are 4 x 2 (half the dependent work per thread and step: 25-KF windows), otherwise 4 x 4;
 //   * a column pair's panel keeps only the rows that can be non-zero below it, so the panels of a 64-KF window
 //     (n = 378, half-bandwidth ~36) fit in LDS (133 KB) where the dense lower triangle (575 KB) does not.
+// Two workgroups (the one-tile-per-thread variant, when the band allows it): the elimination is a chain of n / 2
+// dependent steps whatever the width of the band, so the chain is cut instead.  A separator S of whole tiles in the
+// middle (wide enough that no row below it reaches a column above it) splits the unknowns into top | S | bottom;
+// workgroup 0 eliminates the top block, workgroup 1 the bottom block in REVERSED order (its local system is the
+// bottom block mirrored, then S), each on its own CU with its own panels.  When both have reached S they add each
+// other's Schur-complement contribution to their S x S tiles and right-hand side (through global memory, one flag
+// handshake), factor the - now identical - separator redundantly and back-substitute their own block: the same kernel
+// body on a permuted local system of ~n / 2 + |S| unknowns, (n - |S|) / 4 + |S| / 2 steps instead of n / 2, and half the
+// tiles per workgroup, so a 64-pose window fits the one-tile-per-thread variant with its panels in LDS.
 // A sliding-window system is block-banded, so n up to 384 runs here; a system whose skyline does not fit
 // (1024 tiles, 148 KB of panels) is left untouched, meta[3] stays 0 and the general kernel (ba_solve.hip) takes it.
 #include "ba_kernels.h"
 
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace dba {
@@ -61,16 +72,16 @@ __device__ __forceinline__ int bd_wave_scan(int v, int lane) {
 template <int THREADS, int SLOTS, bool GP>
 __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__restrict__ H,
                                                                 const double *__restrict__ bvec,
-                                                                const int *__restrict__ fpose, int n,
+                                                                const int *__restrict__ fpose, int ng,
                                                                 double lm, double ep, float *__restrict__ dx,
                                                                 int *__restrict__ meta, double *__restrict__ G,
-                                                                int gcap
+                                                                int gcap, unsigned gen
 #ifdef PROFILE_SOLVE
                                                                    , long long *__restrict__ prof
 #endif
                                                                    ) {
 #ifdef PROFILE_SOLVE
-#define BPROF(slot) do { if (threadIdx.x == 0) { long long t_ = wall_clock64(), c_ = clock64(); prof[slot] += t_ - tprev_; prof[8 + slot] += c_ - cprev_; tprev_ = t_; cprev_ = c_; } } while (0)
+#define BPROF(slot) do { if (threadIdx.x == 0) { long long t_ = wall_clock64(), c_ = clock64(); prof[16 * blockIdx.x + slot] += t_ - tprev_; prof[16 * blockIdx.x + 8 + slot] += c_ - cprev_; tprev_ = t_; cprev_ = c_; } } while (0)
   long long tprev_ = wall_clock64(), cprev_ = clock64();
 #else
 #define BPROF(slot)
@@ -89,26 +100,20 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   double *pinv = smem + NINTS / 2;
   double *C = pinv + BD_PINV;
 
-  const int T = (n + 1 + 3) >> 2, KT = (n + 3) >> 2, npairs = n >> 1, Tl = T - 1;
   const int tid = threadIdx.x, nt = blockDim.x;
   if (GP && meta[3] != 0) return;  // queued behind the one-tile-per-thread variant, which solved the system
   const int wave = tid >> 6, lane = tid & 63;
+  constexpr bool SPLIT = (SLOTS == 1 && !GP);
+  const int role = SPLIT ? (int)blockIdx.x : 0;  // 1: the workgroup of the bottom block (only launched with SPLIT)
 
-  // ---- skyline: every candidate tile of the lower triangle is looked at once
-  if (tid < T) first[tid] = (tid == Tl) ? 0 : min(tid, KT - 1);
-  if (tid < KT) hiK[tid] = tid;
-  if (tid < 16) flags[tid] = 0;
-  __syncthreads();
-  if (fpose) {  // skyline from the graph (ba_prepare_kernel): rows 4I .. 4I+3 belong to at most two poses
-    if (tid < Tl) {
-      const int P = n / 6;
-      const int p0 = (4 * tid) / 6, p1 = min((4 * tid + 3) / 6, P - 1);
-      const int fp = max(0, min(fpose[p0], fpose[p1]));
-      first[tid] = min(first[tid], (6 * fp) >> 2);
-    }
-  } else {      // measured: a wave reads four matrix rows of a tile row at a time, 64 columns per load
-    for (int I = wave; I < Tl; I += nt >> 6) {
-      const int ncol = min(4 * I + 4, n);
+  // ---- skyline of the whole system at tile level (first non-zero column tile of every row tile)
+  // local index -> index in H / b / dx.  mode 0: identity; mode 1 (bottom workgroup): own block mirrored, then S
+  int pmode = 0, p_own = 0, p_ua = 0;
+  auto gidx = [&](int i) { return pmode == 0 ? i : (i < p_own ? ng - 1 - i : p_ua + (i - p_own)); };
+  auto measure = [&](int nloc) {  // a wave reads four matrix rows of a tile row at a time, 64 columns per load
+    const int Tlm = ((nloc + 1 + 3) >> 2) - 1;
+    for (int I = wave; I < Tlm; I += nt >> 6) {
+      const int ncol = min(4 * I + 4, nloc);
       unsigned long long seen[6];
 #pragma unroll
       for (int ch = 0; ch < 6; ch++) {
@@ -118,8 +123,10 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int i = 4 * I + r;  // (upper entries inside the diagonal tile mirror the lower ones)
-            const double v = (col < ncol && i < n) ? H[(size_t)max(i, col) * n + min(i, col)] : 0.0;
-            nz |= (v != 0.0);
+            if (col < ncol && i < nloc) {
+              const int gi = gidx(i), gk = gidx(col);
+              nz |= (H[(size_t)max(gi, gk) * ng + min(gi, gk)] != 0.0);
+            }
           }
         }
         seen[ch] = __ballot(nz);
@@ -130,7 +137,137 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         if (seen[ch]) fc = 64 * ch + (int)__builtin_ctzll(seen[ch]);
       if (lane == 0) first[I] = min(first[I], fc >> 2);
     }
+  };
+  {
+    const int Tg = (ng + 1 + 3) >> 2, KTg = (ng + 3) >> 2, Tlg = Tg - 1;
+    if (tid < Tg) first[tid] = (tid == Tlg) ? 0 : min(tid, KTg - 1);
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();
+    if (fpose) {  // skyline from the graph (ba_prepare_kernel): rows 4I .. 4I+3 belong to at most two poses
+      if (tid < Tlg) {
+        const int P = ng / 6;
+        const int p0 = (4 * tid) / 6, p1 = min((4 * tid + 3) / 6, P - 1);
+        const int fp = max(0, min(fpose[p0], fpose[p1]));
+        first[tid] = min(first[tid], (6 * fp) >> 2);
+      }
+    } else {
+      measure(ng);
+    }
+    // ng % 4 == 2: the last two matrix rows share the (dense) tile row of the right-hand side; the split below needs
+    // their true first column tile
+    if ((ng & 2) && wave == 1) {
+      int fl = KTg - 1;
+      if (fpose) {
+        fl = (6 * max(0, fpose[ng / 6 - 1])) >> 2;
+      } else {
+        int fc = ng;
+        for (int c0_ = 0; c0_ < ng - 2; c0_ += 64) {
+          const int col = c0_ + lane;
+          const bool nz = col < ng - 2 && (H[(size_t)(ng - 2) * ng + col] != 0.0 || H[(size_t)(ng - 1) * ng + col] != 0.0);
+          const unsigned long long b = __ballot(nz);
+          if (b) { fc = c0_ + (int)__builtin_ctzll(b); break; }
+        }
+        fl = min(fc, ng - 2) >> 2;
+      }
+      if (lane == 0) flags[11] = fl;
+    } else if (!(ng & 2) && tid == 0) {
+      flags[11] = KTg - 1;
+    }
+    __syncthreads();
   }
+  // ---- two workgroups?  top = tiles [0, Ta), bottom = the last kb 4-blocks, S in between.  Needed: no row from the
+  // bottom block on reaches a column tile < Ta (suffix minimum of `first`), |S| <= XS_MAX, blocks worth the handshake.
+  constexpr int XS_MAX = 64, XROWS = XS_MAX + 8;                 // exchange: (|S| + right-hand side + tile padding) x |S|
+  constexpr int XNEED = 8 + 2 * XROWS * XS_MAX;                  // doubles: 16 ints of flags, two contributions
+  int *xflag = (int *)G;
+  double *X = G + 8;
+  if (SPLIT) {
+    if (wave == 0) {
+      const int KTg = (ng + 3) >> 2, Tlg = ((ng + 1 + 3) >> 2) - 1;
+      int best = 0, bTa = 0, bkb = 0;
+      if (gridDim.x == 2 && G != nullptr && gcap >= XNEED && ng >= 96) {
+        // sm[I] = min over I' >= I of first[I'] (and of the last two rows' when ng % 4 == 2): suffix minimum over the
+        // <= 128 row tiles, two per lane (pre[] as scratch)
+        const int i0 = 2 * lane, i1 = 2 * lane + 1;
+        const int f1 = (i1 < Tlg) ? first[i1] : KTg, f0 = min((i0 < Tlg) ? first[i0] : KTg, f1);
+        int run = min(f0, flags[11]);  // suffix minimum over the lanes >= this one
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_down(run, off, 64);
+          if (lane + off < 64) run = min(run, o);
+        }
+        const int above = __shfl_down(run, 1, 64);  // minimum over the lanes > this one
+        const int tail = (lane < 63) ? min(above, flags[11]) : flags[11];
+        if (i1 < Tlg) pre[i1] = min(f1, tail);
+        if (i0 < Tlg) pre[i0] = min(f0, tail);
+        __builtin_amdgcn_wave_barrier();
+        // candidates: a bottom block of kb 4-blocks (rows from ub = ng - 4 kb on) allows top blocks up to sm[ub >> 2]
+        // column tiles; the largest one leaves the smallest S
+        for (int kb = 1 + lane; 4 * kb + 8 <= ng; kb += 64) {
+          const int ub = ng - 4 * kb;
+          const int Ta = min(pre[min(ub >> 2, Tlg - 1)], (ub - 4) >> 2);
+          const int ws = ub - 4 * Ta;
+          const int score = (Ta > 0 && ws >= 4 && ws <= XS_MAX) ? min(Ta, kb) : 0;
+          if (score > best || (score == best && score > 0 && Ta < bTa)) best = score, bTa = Ta, bkb = kb;
+        }
+        // best over the lanes (ties: smallest Ta)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const int ob = __shfl_xor(best, off, 64), oT = __shfl_xor(bTa, off, 64), ok = __shfl_xor(bkb, off, 64);
+          if (ob > best || (ob == best && ob > 0 && oT < bTa)) best = ob, bTa = oT, bkb = ok;
+        }
+      }
+      if (lane == 0) {
+        const bool go = best >= 6;  // at least 6 column tiles (12 steps) saved per workgroup
+        flags[8] = go ? 1 : 0, flags[9] = bTa, flags[10] = bkb;
+      }
+    }
+    __syncthreads();
+  }
+  const bool split = SPLIT && flags[8] != 0;
+  // (for the tests and the profiling harness: which split was taken; meta[4..6] have no other use)
+  if (SPLIT && tid == 0 && role == 0) meta[4] = flags[8], meta[5] = flags[9], meta[6] = flags[10];
+  if (!split && role != 0) return;
+  const int ua = split ? 4 * flags[9] : 0, ub = split ? ng - 4 * flags[10] : ng;
+  const int n = split ? (role == 0 ? ub : ng - ua) : ng;         // size of this workgroup's (local) system
+  const int nown = split ? (role == 0 ? ua : ng - ub) : n;       // its own block comes first, S behind it
+  const int Kown = nown >> 2;                                    // (nown is a multiple of 4: the exchange sits between tiles)
+  if (split && role == 1) pmode = 1, p_own = nown, p_ua = ua;
+  const int T = (n + 1 + 3) >> 2, KT = (n + 3) >> 2, npairs = n >> 1, Tl = T - 1;
+  if (split) {
+    __syncthreads();
+    if (role == 1) {
+      // the mirrored system's skyline out of the global one: local row i is global row g = gidx(i); what it has left
+      // of its diagonal are the entries of COLUMN g below the diagonal, which end at the last row tile whose skyline
+      // reaches column tile g >> 2
+      const int KTg = (ng + 3) >> 2, Tlg = ((ng + 1 + 3) >> 2) - 1;
+      if (tid < KTg) hiK[tid] = tid;
+      __syncthreads();
+      if (tid < Tlg) {
+        for (int Kq = first[tid]; Kq <= min(tid, KTg - 1); Kq++) atomicMax(&hiK[Kq], tid);
+      } else if (tid == Tlg && (ng & 2)) {
+        for (int Kq = flags[11]; Kq < KTg; Kq++) atomicMax(&hiK[Kq], Tlg);  // the two rows next to the right-hand side
+      }
+      __syncthreads();
+      int fl = 0;
+      if (tid < Tl) {
+        int cmax = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = min(4 * tid + r, n - 1), g = gidx(i);
+          cmax = max(cmax, min(4 * hiK[g >> 2] + 3, ng - 1));
+        }
+        fl = max(0, min(tid, (ng - 1 - cmax) >> 2));  // (global row c is local column ng - 1 - c of the own block)
+      }
+      __syncthreads();
+      if (tid < T) first[tid] = min(fl, KT - 1);
+      __syncthreads();
+    }
+    // S x S is taken as dense in both workgroups (they must factor the same tiles), the right-hand side row is dense
+    if (tid < T) first[tid] = (tid == Tl) ? 0 : ((tid >= Kown) ? min(first[tid], Kown) : first[tid]);
+  }
+  __syncthreads();
+  if (tid < KT) hiK[tid] = tid;
   __syncthreads();
   BPROF(0);
   // hiK[K] = last banded row tile whose skyline reaches column tile K
@@ -192,7 +329,14 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   for (int e = tid; e < NTILES; e += nt) tinfo[e] = 0;
   __syncthreads();
   if (flags[2]) {  // skyline too large for one workgroup: the general kernel takes the system
-    if (tid == 0) meta[3] = 0;
+    if (tid == 0) {
+      meta[3] = 0;
+      if (split) {  // the partner learns it at the exchange and leaves as well
+        xflag[2 + role] = 2;
+        __threadfence();
+        __hip_atomic_store(xflag + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
   const int TW = flags[1], halves = 4 / TW;
@@ -236,7 +380,10 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         for (int c = 0; c < 4; c++) {
           const int i = 4 * I[q] + r, k = 4 * K[q] + c0 + c;
           okm[q][r][c] = valid[q] && (c < TW) && k < n && i <= n;
-          const double *src_ = (i == n) ? bvec + k : H + (size_t)max(i, k) * n + min(i, k);  // mirrored upper half on the diagonal
+          // the bottom workgroup starts S x S and S's right-hand side from zero: the top one brings the original values
+          if (split && role == 1 && k >= nown && i >= nown) okm[q][r][c] = false;
+          const int gi = gidx(min(i, n - 1)), gk = gidx(min(k, n - 1));
+          const double *src_ = (i == n) ? bvec + gk : H + (size_t)max(gi, gk) * ng + min(gi, gk);  // mirrored upper half on the diagonal
           src[q][r][c] = okm[q][r][c] ? src_ : H;
         }
     }
@@ -253,7 +400,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           double v = okm[q][r][c] ? a[q][r][c] : 0.0;
-          if (4 * I[q] + r == 4 * K[q] + c0 + c && 4 * I[q] + r < n) v += ep + lm * v;  // damping (:1252-1253)
+          if (4 * I[q] + r == 4 * K[q] + c0 + c && 4 * I[q] + r < n && okm[q][r][c]) v += ep + lm * v;  // damping (:1252-1253)
           a[q][r][c] = v;
         }
 #pragma unroll
@@ -287,6 +434,65 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     int pcur = poff[0], pnxt = 0;
     int last0 = 4 * (min(hiK[0], Tl - 1) - 0 + 1) + 2, lastn = 0;  // panel slot of the first row of the last row tile
     for (int Ks = 0; Ks < KT; Ks++) {
+      if (SPLIT && split && Ks == Kown) {
+        // ---- both blocks are eliminated: the workgroups swap their contributions to S x S and S's right-hand side
+        BPROF(5);
+        double *Xm = X + role * (XROWS * XS_MAX);
+        const double *Xp = X + (1 - role) * (XROWS * XS_MAX);
+        if (valid[0] && K[0] >= Kown) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+              const int si = 4 * I[0] + r - nown, sk = 4 * K[0] + c0 + c - nown;
+              if (si < XROWS && sk < XS_MAX) Xm[si * XS_MAX + sk] = a[0][r][c];
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+          xflag[2 + role] = (*fail != 0) ? 1 : 0;  // (a non-SPD pivot in either block fails the whole solve)
+          __threadfence();
+          __hip_atomic_store(xflag + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          const long long t0 = wall_clock64();
+          int st = 0;
+          while (__hip_atomic_load(xflag + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int)gen) {
+            if (wall_clock64() - t0 > 100000000ll) {  // ~1 s: the partner never came; leave the system to the next kernel
+              st = 2;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+          if (st == 0) st = __hip_atomic_load(xflag + 2 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          flags[12] = st;
+        }
+        __syncthreads();
+        const int st = flags[12];
+        if (st == 2) {  // partner unsupported / absent: nothing has been written yet, the queue behind takes over
+          if (tid == 0) meta[3] = 0;
+          __builtin_amdgcn_endpgm();
+        }
+        if (st == 1 && tid == 0) *fail = 1;
+        // (every wave drops what its caches may hold of the partner's buffer, then the loads go out together)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (valid[0] && K[0] >= Kown) {
+          double xv[4][W];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+              const int si = 4 * I[0] + r - nown, sk = 4 * K[0] + c0 + c - nown;
+              xv[r][c] = (si < XROWS && sk < XS_MAX) ? __builtin_nontemporal_load(Xp + si * XS_MAX + sk) : 0.0;
+            }
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < W; c++) a[0][r][c] += xv[r][c];
+        }
+        // the first pivot of S belongs to the summed block (its inverse was published from this workgroup's share)
+        if (valid[0] && I[0] == Kown && K[0] == Kown && (W == 4 || hh == 0)) publish_pinv(2 * Kown, a[0][0][0], a[0][1][0], a[0][1][1]);
+        BPROF(6);
+      }
       auto step = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         const int s = 2 * Ks + h;
@@ -337,7 +543,9 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         const int Kn = (h == 0) ? Ks : Ks + 1;
 #pragma unroll
         for (int q = 0; q < SLOTS; q++) {
-          if (valid[q] && I[q] == Kn && K[q] == Kn && 2 * (s + 1) < n && (W == 4 || hh == hn)) {
+          // (with two workgroups the first pivot of S is published after the exchange, from the summed block)
+          if (valid[q] && I[q] == Kn && K[q] == Kn && 2 * (s + 1) < n && (W == 4 || hh == hn) &&
+              !(SPLIT && split && s + 1 == 2 * Kown)) {
             constexpr int pc0 = (W == 4) ? 2 * hn : 0;
             publish_pinv(s + 1, a[q][2 * hn][pc0], a[q][2 * hn + 1][pc0], a[q][2 * hn + 1][pc0 + 1]);
           }
@@ -436,14 +644,33 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
 #pragma unroll
   for (int r = 0; r < RMAX; r++)
     if (lane + 64 * r < n && !isfinite(xo[r])) bad = true;
-  const int failed = (*fail != 0) || (__ballot(bad) != 0ull);
+  int failed = (*fail != 0) || (__ballot(bad) != 0ull);
+  if (SPLIT && split) {  // one verdict for both blocks
+    int other = 0;
+    if (lane == 0) {
+      xflag[6 + role] = failed;
+      __threadfence();
+      __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();
+      other = 1;  // (a partner that never reports counts as failed)
+      while (wall_clock64() - t0 < 100000000ll) {
+        if (__hip_atomic_load(xflag + 4 + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gen) {
+          other = __hip_atomic_load(xflag + 6 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    failed |= __builtin_amdgcn_readfirstlane(other);
+  }
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
     const int j = lane + 64 * r;
-    if (j < n) dx[j] = failed ? 0.f : (float)xo[r];
+    // the top workgroup stores its block and S, the bottom one its block only
+    if (j < n && (role == 0 || j < nown)) dx[gidx(j)] = failed ? 0.f : (float)xo[r];
   }
   BPROF(4);
-  if (lane == 0) {
+  if (lane == 0 && role == 0) {
     meta[1] = failed;
     meta[3] = 1;  // solved here: the general kernel queued behind this one returns at once
   }
@@ -474,16 +701,22 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
     attr_once.done();
   }
   if (!big) {
-    hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
-                       H, b, fpose, n, lm, ep, dx, meta, (double *)nullptr, 0 BD_PROF_ARG);
+    // two workgroups: the second one only works when the band lets the system be split (decided on the device)
+    static std::atomic<unsigned> generation{1};
+    const unsigned gen = generation.fetch_add(1) | 0x40000000u;
+    const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
+    static const bool one_wg = [] { const char *e = getenv("DBA_SOLVE_SPLIT"); return e && e[0] == '0'; }();
+    hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3((scratch && !one_wg) ? 2 : 1), dim3(BD_THREADS),
+                       SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, scratch ? gcap : 0,
+                       gen BD_PROF_ARG);
   } else {
     if (!scratch) return DBA_ERR_WORKSPACE;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
     // two tiles per thread on 1024 threads first (a step costs what one wave's tiles cost), three on 512 for what is left
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 2, true>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
-                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap BD_PROF_ARG);
+                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
-                       SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap BD_PROF_ARG);
+                       SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

@@ -36,19 +36,19 @@ int run(int n, int band, bool spd, bool timeit) {
   hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64);
   hipMemcpy(dH, H.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
   const bool use_tile = dba::ba_solve_tile_supported(n) && !getenv("HARNESS_BAND");
-  if (use_tile) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); }
+  if (use_tile) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, getenv("HARNESS_ONE_WG") ? nullptr : gscratch, getenv("HARNESS_ONE_WG") ? 0 : ((size_t)1 << 20), false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); }
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("n=%d launch error %s\n", n, hipGetErrorString(e)); return 1; }
-  std::vector<float> x(n); int hm[4]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
+  std::vector<float> x(n); int hm[8]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 32, hipMemcpyDeviceToHost); if (!use_tile && hm[4]) printf("   split: top %d unknowns | S %d | bottom %d\n", 4*hm[5], n - 4*hm[5] - 4*hm[6], 4*hm[6]);
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("%s n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", use_tile ? "tile" : "band", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
   if (getenv("HARNESS_DUMP") && n <= 64) { for (int i = 0; i < n; i++) printf("    x[%2d] dev % .6e ref % .6e%s\n", i, x[i], ok ? xr[i] : 0.0, fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6 ? "  <--" : ""); }
-  if (timeit) { long long hp[16]; hipMemcpy(hp, dba::g_band_prof, 128, hipMemcpyDeviceToHost); printf("   ticks(10ns): scan %lld alloc %lld load %lld factor %lld backsub %lld   shader cycles: factor %lld backsub %lld (%.2f GHz)\n", hp[0],hp[1],hp[2],hp[3],hp[4], hp[11], hp[12], hp[3] ? hp[11] / (hp[3] * 10.0) : 0.0); }
-  hipMemset(dba::g_band_prof, 0, 128);
+  if (timeit) { long long hp[32]; hipMemcpy(hp, dba::g_band_prof, 256, hipMemcpyDeviceToHost); for (int w = 0; w < 2; w++) if (hp[16 * w + 3]) printf("   workgroup %d ticks(10ns): scan %lld alloc %lld load %lld factor(own) %lld exchange %lld factor(S or all) %lld backsub %lld\n", w, hp[16*w+0],hp[16*w+1],hp[16*w+2],hp[16*w+5],hp[16*w+6],hp[16*w+3],hp[16*w+4]); }
+  hipMemset(dba::g_band_prof, 0, 256);
   if (timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 3; mode++) {
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, nullptr, 0, false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); } else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, getenv("HARNESS_ONE_WG") ? nullptr : gscratch, getenv("HARNESS_ONE_WG") ? 0 : ((size_t)1 << 20), false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); } else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "band " : mode == 2 ? "tile " : "block", ms*1000/200);
       if (mode == 2) { long long hp[8]; hipMemcpy(hp, dba::g_tile_prof, 64, hipMemcpyDeviceToHost); printf("   tile stages us: setup %.2f factor %.2f backsub %.2f\n", hp[0]/200.0/100, hp[1]/200.0/100, hp[3]/200.0/100); hipMemset(dba::g_tile_prof, 0, 2048); }
@@ -58,7 +58,7 @@ int run(int n, int band, bool spd, bool timeit) {
   return 0;
 }
 int main() {
-  hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 128); hipMemset(dba::g_band_prof, 0, 128);
+  hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048); hipMalloc(&dba::g_mfma_prof, 128); hipMemset(dba::g_mfma_prof, 0, 128); hipMalloc(&dba::g_band_prof, 256); hipMemset(dba::g_band_prof, 0, 256);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dba::ba_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
   run(144, 24, true, true); run(144, 144, true, true); run(144, 18, false, false);
   run(6, 6, true, false); run(12, 12, true, false); run(18, 7, true, false); run(138, 30, true, true); run(168, 40, true, true); run(186, 36, true, true); run(240, 36, true, true); run(378, 36, true, true); run(378, 56, true, true); run(168, 168, true, false); run(66, 20, true, false); run(90, 90, true, false); run(144, 1, true, false); run(144, 3, true, false); run(60, 5, true, false);

@@ -39,7 +39,9 @@ def _solve_on_device(H, b, P, lm, ep):
     _lib.check(lib.dba_ba_solve(*dims, lm, ep, ctypes.c_void_p(ws.data_ptr()), nbytes, stream), "dba_ba_solve")
     torch.cuda.synchronize()
     dx = ws[lay.dx:lay.dx + 4 * n].view(torch.float32).cpu().numpy().copy()
-    failed = int(ws[lay.meta:lay.meta + 8].view(torch.int32)[1].item())
+    meta = ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()
+    failed = int(meta[1])
+    _solve_on_device.split = (int(meta[4]), 4 * int(meta[5]), 4 * int(meta[6]))   # (taken?, top unknowns, bottom unknowns)
     return dx, failed
 
 
@@ -110,3 +112,57 @@ def test_a_failing_pivot_in_either_front_gives_a_zero_update(P, where):
     H[where, where] = -1.0
     dx, failed = _solve_on_device(H, b, P, 1e-4, 0.1)
     assert failed == 1 and np.all(dx == 0.0)
+
+
+# The skyline kernel (30 - 64 poses) cuts banded systems at a separator and runs the two halves on two workgroups
+# (csrc/ba_solve_band.hip): odd and even pose counts (n % 4 == 2 and 0), bands from one pose to the separator limit
+# (64 unknowns; wider bands and arrows keep one workgroup), sparse right-hand sides, long couplings on either side of
+# and across the separator, failing pivots in the top block, the bottom block and the separator.
+@pytest.mark.parametrize("P,band", [(30, 6), (30, 36), (31, 36), (31, 13), (32, 48), (33, 61), (35, 70), (40, 36), (41, 30),
+                                     (47, 24), (50, 36), (63, 36), (63, 60), (64, 36), (64, 12), (64, 66)])
+def test_two_workgroup_skyline_solve(P, band):
+    rng = np.random.default_rng(11 * P + band)
+    H, b = _system(rng, P, band)
+    _check(H, b, P)
+    taken, top, bottom = _solve_on_device.split
+    n = 6 * P
+    if band <= 60:   # a separator of at most 64 unknowns exists: both workgroups must have worked, on balanced halves
+        assert taken == 1 and min(top, bottom) >= 24 and abs(top - bottom) <= 8 and band - 4 <= n - top - bottom <= 64
+    elif band >= 70:
+        assert taken == 0
+
+
+@pytest.mark.parametrize("P,band,i,j", [(40, 24, 100, 20), (40, 24, 230, 150), (40, 24, 140, 100), (40, 24, 239, 0),
+                                         (63, 36, 377, 300), (63, 36, 60, 2), (63, 36, 200, 170), (31, 18, 185, 150)])
+def test_two_workgroup_skyline_solve_with_a_long_coupling(P, band, i, j):
+    rng = np.random.default_rng(P + band + i)
+    H, b = _system(rng, P, band)
+    H[i, j] = H[j, i] = 0.37
+    _check(H, b, P)
+
+
+def test_two_workgroup_skyline_solve_with_sparse_right_hand_sides():
+    rng = np.random.default_rng(9)
+    H, _ = _system(rng, 40, 30)
+    for lo, hi in ((236, 240), (0, 4), (118, 124), (60, 64), (180, 240)):
+        b = np.zeros(240)
+        b[lo:hi] = 1.0 + np.arange(hi - lo)
+        _check(H, b, 40)
+
+
+@pytest.mark.parametrize("P,where", [(40, 3), (40, 236), (40, 120), (40, 70), (40, 170), (31, 184), (63, 190), (63, 377)])
+def test_two_workgroup_skyline_failing_pivot_gives_a_zero_update(P, where):
+    rng = np.random.default_rng(P + where)
+    H, b = _system(rng, P, 18)
+    H[where, where] = -1.0
+    dx, failed = _solve_on_device(H, b, P, 1e-4, 0.1)
+    assert failed == 1 and np.all(dx == 0.0)
+
+
+def test_two_workgroup_skyline_solve_repeated_calls_share_the_exchange_buffer():
+    # the handshake flags carry a per-launch generation: back-to-back solves on one workspace must not see each other's
+    rng = np.random.default_rng(3)
+    for P, band in ((40, 24), (40, 30), (63, 36), (40, 24)):
+        H, b = _system(rng, P, band)
+        for _ in range(3):
+            _check(H, b, P)
