@@ -67,9 +67,9 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   L.b = take(sizeof(double) * (size_t)(n6 > 0 ? n6 : 1));
   size_t o_lscratch = 0;
   const bool lds_fits = ba_solve_fits_lds(n6);
-  // systems the skyline solver may take (30 - 64 poses) always get the scratch: its two workgroups exchange their
+  // systems the skyline solver may split (16 - 64 poses) always get the scratch: its two workgroups exchange their
   // contributions to the separator block through it (ba_solve_band.hip)
-  const bool want_scratch = !lds_fits || (ba_solve_band_supported(n6) && !ba_solve_tile_supported(n6));
+  const bool want_scratch = !lds_fits || (ba_solve_band_supported(n6) && n6 >= 96);
   if (want_scratch) o_lscratch = take(sizeof(double) * ba_solve_scratch_doubles(n6));
   L.P = P;
   L.Mmax = Mmax;

@@ -674,6 +674,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     meta[1] = failed;
     meta[3] = 1;  // solved here: the general kernel queued behind this one returns at once
   }
+  BPROF(7);
 }
 
 bool ba_solve_band_supported(int n) { return n > 0 && !(n & 1) && n <= BD_MAX_N; }

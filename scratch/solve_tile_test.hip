@@ -42,7 +42,6 @@ int run(int n, int band, bool spd, bool timeit) {
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("%s n=%3d band=%3d spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", use_tile ? "tile" : "band", n, band, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
   if (getenv("HARNESS_DUMP") && n <= 64) { for (int i = 0; i < n; i++) printf("    x[%2d] dev % .6e ref % .6e%s\n", i, x[i], ok ? xr[i] : 0.0, fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6 ? "  <--" : ""); }
-  if (timeit) { long long hp[32]; hipMemcpy(hp, dba::g_band_prof, 256, hipMemcpyDeviceToHost); for (int w = 0; w < 2; w++) if (hp[16 * w + 3]) printf("   workgroup %d ticks(10ns): scan %lld alloc %lld load %lld factor(own) %lld exchange %lld factor(S or all) %lld backsub %lld\n", w, hp[16*w+0],hp[16*w+1],hp[16*w+2],hp[16*w+5],hp[16*w+6],hp[16*w+3],hp[16*w+4]); }
   hipMemset(dba::g_band_prof, 0, 256);
   if (timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -51,6 +50,7 @@ int run(int n, int band, bool spd, bool timeit) {
       for (int it = 0; it < 200; it++) { if (mode == 0) { dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, getenv("HARNESS_ONE_WG") ? nullptr : gscratch, getenv("HARNESS_ONE_WG") ? 0 : ((size_t)1 << 20), false, 0); if (n > 300) dba::launch_ba_solve_band(dH, db, nullptr, n, lm, ep, dx, meta, gscratch, (size_t)1 << 20, true, 0); } else if (mode == 2) dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); else hipLaunchKernelGGL(dba::ba_solve_kernel<true>, dim3(1), dim3(512), (size_t)(n+1)*(n+2)/2*8 + dba::solve_small_bytes(n), 0, dH, db, n, lm, ep, dx, meta, nullptr, nullptr, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "band " : mode == 2 ? "tile " : "block", ms*1000/200);
+      if (mode == 0) { long long hp[32]; hipMemcpy(hp, dba::g_band_prof, 256, hipMemcpyDeviceToHost); for (int w = 0; w < 2; w++) if (hp[16 * w + 3]) printf("   workgroup %d, us per solve: skyline %.1f alloc %.1f load %.1f own block %.1f exchange %.1f separator (or whole system) %.1f substitution %.1f verdict+store %.1f\n", w, hp[16*w+0]/2e4, hp[16*w+1]/2e4, hp[16*w+2]/2e4, hp[16*w+5]/2e4, hp[16*w+6]/2e4, hp[16*w+3]/2e4, hp[16*w+4]/2e4, hp[16*w+7]/2e4); hipMemset(dba::g_band_prof, 0, 256); }
       if (mode == 2) { long long hp[8]; hipMemcpy(hp, dba::g_tile_prof, 64, hipMemcpyDeviceToHost); printf("   tile stages us: setup %.2f factor %.2f backsub %.2f\n", hp[0]/200.0/100, hp[1]/200.0/100, hp[3]/200.0/100); hipMemset(dba::g_tile_prof, 0, 2048); }
 
     }
