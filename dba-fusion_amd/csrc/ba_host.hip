@@ -207,13 +207,16 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
 // graph_skyline: the caller guarantees that H only has the structure of THIS workspace's graph (edges + Schur fill),
 // so the solver may take the skyline from the prepare kernel's table instead of measuring it.  False for systems
 // that were summed over ranks or that came from the host (BACore.optimize: GTSAM priors can couple any two poses).
+// graph_fpose: a caller-supplied pose-level skyline (device, P ints) for a system summed over ranks whose combined graph
+// the caller knows (the sharded driver); overrides the workspace's table.
 static int ba_solve_stage(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
-                          dba_stream_t stream, bool graph_skyline) {
+                          dba_stream_t stream, bool graph_skyline, const int *graph_fpose = nullptr) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  return launch_ba_solve(plan.W.H, plan.W.b, graph_skyline ? plan.T.fpose : nullptr, 6 * plan.P, (double)lm, (double)ep,
-                         plan.W.dx, plan.T.meta, plan.W.Lscratch, (hipStream_t)stream);
+  const int *fpose = graph_fpose ? graph_fpose : (graph_skyline ? plan.T.fpose : nullptr);
+  return launch_ba_solve(plan.W.H, plan.W.b, fpose, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
+                         plan.W.Lscratch, (hipStream_t)stream);
 }
 
 int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
@@ -253,9 +256,9 @@ int dba_ba_shard_front(const float *poses, const float *disps, const float *intr
 }
 
 int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
-                      int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps, void *ws,
-                      size_t ws_bytes, dba_stream_t stream) {
-  const int rc = dba_ba_solve(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream);
+                      int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps,
+                      const int32_t *window_fpose, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  const int rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false, window_fpose);
   if (rc != DBA_OK) return rc;
   return dba_ba_update(poses, disps, ii, jj, frame_owned, N, B, ht, wd, t0, t1, 1, update_disps, nullptr, ws, ws_bytes,
                        stream);

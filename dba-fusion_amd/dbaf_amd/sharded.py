@@ -43,6 +43,35 @@ def partition_source_frames(ii, jj, t0, t1, world):
     return kx, owner
 
 
+def window_fpose(ii, jj, t0, t1):
+    """Pose-level skyline of the reduced camera system of the COMPLETE graph (what ba_prepare_kernel builds on the device
+    for one rank's edges, csrc/ba_kernels.hip): the window poses in S_i = {targets of the edges leaving frame i} U {i}
+    are mutually coupled (pose blocks, and the Schur products of frame i), so fpose[a] = min over the sets containing a
+    of min S_i.  int32 [t1 - t0], pose indices relative to t0."""
+    ii = np.asarray(ii, np.int64)
+    jj = np.asarray(jj, np.int64)
+    P = int(t1) - int(t0)
+    big = np.iinfo(np.int32).max
+    mins = {}
+    for f in np.unique(ii):
+        p = int(f) - t0
+        mins[int(f)] = p if 0 <= p < P else big
+    for f, g in zip(ii, jj):
+        tg = int(g) - t0
+        if 0 <= tg < P:
+            mins[int(f)] = min(mins[int(f)], tg)
+    fp = np.arange(P, dtype=np.int64)
+    for f, g in zip(ii, jj):
+        tg = int(g) - t0
+        if 0 <= tg < P:
+            fp[tg] = min(fp[tg], mins[int(f)])
+    for f, m in mins.items():
+        p = f - t0
+        if 0 <= p < P:
+            fp[p] = min(fp[p], m)
+    return fp.astype(np.int32)
+
+
 class ShardedWindow:
     def __init__(self, ii, jj, t0, t1, B, world, rank):
         self.ii_all = np.asarray(ii, np.int64)
@@ -62,6 +91,7 @@ class ShardedWindow:
         # depth exchange: rank r contributes the rows (frames) it owns, padded to the largest share
         self.rows_of = [np.array(sorted(k for k, r in self.owner.items() if r == q), np.int64) for q in range(world)]
         self.kmax = max(1, max(len(r) for r in self.rows_of))
+        self.fpose = window_fpose(self.ii_all, self.jj_all, self.t0, self.t1)
         self._dev = {}
 
     def _on(self, device):
@@ -71,6 +101,7 @@ class ShardedWindow:
             self._dev[key] = dict(owned=torch.from_numpy(self.owned).to(device),
                                   eta_rows=torch.from_numpy(self.eta_rows).to(device),
                                   kx=torch.from_numpy(self.kx_global).to(device),
+                                  fpose=torch.from_numpy(self.fpose).to(device),
                                   my_rows=torch.from_numpy(self.rows_of[self.rank]).to(device),
                                   all_rows=torch.from_numpy(flat[flat >= 0]).to(device),        # frames, rank-major
                                   all_slots=torch.from_numpy(np.nonzero(flat >= 0)[0]).to(device))  # their gather slots
@@ -107,6 +138,8 @@ class ShardedWindow:
         n6 = 6 * (self.t1 - self.t0)
         ctx = stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
                            self.t0, self.t1, alpha)
+        if isinstance(ctx, dict):
+            ctx["fpose"] = d["fpose"]      # the complete graph's skyline for the solver (the summed system has it)
         inplace = getattr(stages, "system_view", None)
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
@@ -254,8 +287,9 @@ class HipStages:
     def solve_update(self, c, lm, ep, update_disps=True):
         p = self._p
         _lib.check(c["lib"].dba_ba_shard_back(p(c["poses"]), p(c["disps"]), p(c["ii"]), p(c["jj"]), p(c["owned"]),
-                                              *c["dims"], float(lm), float(ep), int(bool(update_disps)), p(c["ws"]),
-                                              c["nbytes"], self._s()), "dba_ba_shard_back")
+                                              *c["dims"], float(lm), float(ep), int(bool(update_disps)),
+                                              p(c.get("fpose")), p(c["ws"]), c["nbytes"], self._s()),
+                   "dba_ba_shard_back")
 
     def system_view(self, c):
         return c["hb"] if "hb" in c else None

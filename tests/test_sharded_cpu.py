@@ -188,3 +188,29 @@ def test_sharded_bacore_matches_unsharded_world2(tmp_path):
         core.retract(np.linalg.solve(H + np.diag(W.ep + W.lm * np.diag(H)), v))
     np.testing.assert_allclose(got["poses"], core.poses, rtol=0, atol=1e-9)
     np.testing.assert_allclose(got["disps"], core.disps, rtol=1e-8, atol=1e-9)
+
+
+def test_window_fpose_is_the_first_coupled_pose_of_the_complete_graph():
+    """the skyline table the sharded driver hands to the solver: brute force over the coupling sets
+    S_i = {targets of the edges leaving i} U {i} (window poses), on random graphs incl. edges that leave the window"""
+    from dbaf_amd.sharded import window_fpose
+    rng = np.random.default_rng(4)
+    for trial in range(30):
+        B = int(rng.integers(6, 40))
+        t0 = int(rng.integers(0, 3))
+        t1 = int(rng.integers(t0 + 2, B + 1))
+        N = int(rng.integers(1, 120))
+        ii = rng.integers(0, B, N)
+        jj = np.clip(ii + rng.integers(-6, 7, N), 0, B - 1)
+        P = t1 - t0
+        coupled = np.eye(P, dtype=bool)
+        for f in np.unique(ii):
+            S = set(int(g) - t0 for g in jj[ii == f] if t0 <= g < t1)
+            if t0 <= f < t1:
+                S.add(int(f) - t0)
+            for a in S:
+                for b in S:
+                    coupled[a, b] = True
+        want = np.array([int(np.nonzero(coupled[a])[0].min()) for a in range(P)], np.int32)
+        got = window_fpose(ii, jj, t0, t1)
+        assert np.array_equal(got, want), (trial, got, want)
