@@ -48,7 +48,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   };
   dba_ba_layout L;
   memset(&L, 0, sizeof(L));
-  L.meta = take(sizeof(int) * 8);
+  L.meta = take(sizeof(int) * 16);  // [8..15]: handshake flags of the solver's two workgroups (nothing else writes there)
   L.kx = take(sizeof(int) * (size_t)(Mmax > 0 ? Mmax : 1));
   const size_t o_fslot = take(sizeof(int) * (size_t)B);
   const size_t o_eoff = take(sizeof(int) * (size_t)(Mmax + 1));

@@ -17,7 +17,8 @@ constexpr int SCHUR_CH = SCHUR_CH_CFG;     // pixel chunks of the Schur grid
 
 // device index tables (all int32, inside the workspace)
 struct BaTables {
-  int *meta;        // [0] = |kx|, [1] = last solve failed, [2] = kx overflowed Mmax (cannot happen)
+  int *meta;        // [0] = |kx|, [1] = last solve failed, [2] = kx overflowed Mmax (cannot happen), [3] = solved by the
+                    // skyline kernel, [4..6] = its split, [8..15] = handshake flags of its two workgroups (16 ints)
   int *kx;          // [Mmax]   frame id of slot m (sorted unique of arange(t0,t1) U ii)
   int *frame_slot;  // [B]      slot of frame f, -1 if absent
   int *eoff;        // [Mmax+1] CSR offsets of the out-edges of slot m

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   // ---- two workgroups?  top = tiles [0, Ta), bottom = the last kb 4-blocks, S in between.  Needed: no row from the
   // bottom block on reaches a column tile < Ta (suffix minimum of `first`), |S| <= XS_MAX, blocks worth the handshake.
   constexpr int XS_MAX = 64, XROWS = XS_MAX + 8;                 // exchange: (|S| + right-hand side + tile padding) x |S|
-  constexpr int XNEED = 8 + 2 * XROWS * XS_MAX;                  // doubles: 16 ints of flags, two contributions
-  int *xflag = (int *)G;
-  double *X = G + 8;
+  constexpr int XNEED = 2 * XROWS * XS_MAX;                      // doubles: the two contributions
+  // the handshake flags live in meta[8..15], which no other kernel writes (the scratch is reused for panels and packed
+  // triangles by the kernels queued behind: a stale double there could look like this launch's generation number)
+  int *xflag = meta + 8;
+  double *X = G;
   if (SPLIT) {
     if (wave == 0) {
       const int KTg = (ng + 3) >> 2, Tlg = ((ng + 1 + 3) >> 2) - 1;
