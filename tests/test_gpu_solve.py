@@ -166,3 +166,46 @@ def test_two_workgroup_skyline_solve_repeated_calls_share_the_exchange_buffer():
         H, b = _system(rng, P, band)
         for _ in range(3):
             _check(H, b, P)
+
+
+def test_random_window_structures_against_numpy():
+    """80 random reduced systems at pose level (16-64 poses, bands of 1-7 poses, up to two extra couplings anywhere,
+    sparse right-hand sides, a negative pivot now and then): whatever solver path takes them, the result is numpy's or,
+    for a system that is not positive definite, a zero update"""
+    rng = np.random.default_rng(2026)
+    paths = {"two workgroups": 0, "one workgroup": 0, "not SPD": 0}
+    for _ in range(80):
+        P = int(rng.integers(16, 65))
+        n = 6 * P
+        bandp = int(rng.integers(1, 8))
+        A = np.zeros((n, n))
+        for p in range(P):
+            for q in range(max(0, p - bandp), p + 1):
+                A[6 * p:6 * p + 6, 6 * q:6 * q + 6] = rng.uniform(-1, 1, (6, 6)) / (1 + 3 * (p - q))
+        for _k in range(int(rng.integers(0, 3))):
+            p, q = sorted(rng.integers(0, P, 2))
+            A[6 * q:6 * q + 6, 6 * p:6 * p + 6] += rng.uniform(-.3, .3, (6, 6))
+        H = np.tril(A) + np.tril(A, -1).T
+        H[np.diag_indices(n)] = 8.0 + rng.uniform(0, 2, n) + np.abs(H).sum(1) * 0.5
+        b = np.sin(1.3 * np.arange(n))
+        if rng.random() < 0.2:
+            b[:] = 0
+            lo = int(rng.integers(0, n - 4))
+            b[lo:lo + 4] = 1 + np.arange(4)
+        if rng.random() < 0.1:
+            w = int(rng.integers(0, n))
+            H[w, w] = -abs(H[w, w])
+        lm, ep = 1e-4, 0.1
+        Hd = H.copy()
+        Hd[np.diag_indices(n)] += ep + lm * np.diag(H)
+        dx, failed = _solve_on_device(H, b, P, lm, ep)
+        if not np.all(np.linalg.eigvalsh(Hd) > 0):
+            assert failed == 1 and np.all(dx == 0.0)
+            paths["not SPD"] += 1
+            continue
+        ref = np.linalg.solve(Hd, b)
+        assert failed == 0
+        np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+        paths["two workgroups" if (n > 174 and _solve_on_device.split[0]) else "one workgroup"] += 1
+    print(paths)
+    assert paths["two workgroups"] >= 20 and paths["one workgroup"] >= 10
