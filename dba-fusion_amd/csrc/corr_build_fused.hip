@@ -69,16 +69,26 @@ __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _F
 // workgroup barrier that orders LDS traffic only (global stores stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NT>
-__global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kernel(
+// LOOP (64-wide tiles, C = 128): the workgroup walks `strips_per_wg` consecutive strips of its target-row tile.  The
+// wave's target fragments (16 KB: every k-step of its row) then live in 64 registers for the whole walk - no fragment
+// load sits between the matrix products any more -, and the next strip's source operand is requested at the top of a
+// strip and put into LDS (double-buffered) right after the strip's tile write, BEFORE the strip's stores are issued: a
+// wave's loads and stores complete in order, so consumed after those stores the operand would wait for all of them to
+// reach HBM; consumed before them it only waits for the previous strip's, which have had a whole multiplication to drain.
+// The stores then drain while the next strip is multiplied.  One workgroup per CU (103 KB of LDS, up to 256 registers
+// per lane).
+template <int NT, bool LOOP>
+__global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_build_fused_kernel(
     const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm, FusedLevels L, int C, int h1, int w1, int h2, int w2,
-    int HW1p, float inv_w1
+    int HW1p, float inv_w1, int strips_per_wg
 #ifdef FB_PROF
     , unsigned long long *prof
 #endif
 ) {
 #ifdef FB_PROF
-#define FB_STAMP(i) do { if ((threadIdx.x & 63) == 0) prof[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  // (LOOP: slot i accumulates the time since the previous stamp over the workgroup's strips; slot 7 counts the strips)
+  unsigned long long fb_last_ = __builtin_amdgcn_s_memtime();
+#define FB_STAMP(i) do { if ((threadIdx.x & 63) == 0) { unsigned long long *ps_ = prof + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8; const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (LOOP) { ps_[i] += t_ - fb_last_; fb_last_ = t_; } else ps_[i] = t_; } } while (0)
 #else
 #define FB_STAMP(i) (void)0
 #endif
@@ -88,17 +98,71 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
   constexpr int PITCH = FT_ROWS * RP + 4;    // halves per source pixel
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   _Float16 *T = smem;                              // [64][PITCH]  level 0, rounded; before that: the strip's A operand
+  _Float16 *Ab0 = LOOP ? smem + 64 * PITCH : smem;  // the strip's source operand (LOOP: two 16 KB buffers behind the tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int p0 = blockIdx.x * 64;                  // first source pixel of the strip
   const int ty0 = blockIdx.y * FT_ROWS;            // first target row of the tile
   const int e = blockIdx.z;
   const int HW1 = h1 * w1, HW2 = h2 * w2;
   const int l31 = lane & 31, kh = (lane >> 5) * 8;
+  const int nstrips = HW1p >> 6;
+  const int s_begin = LOOP ? (int)blockIdx.x * strips_per_wg : (int)blockIdx.x;
+  const int s_end = LOOP ? min(nstrips, s_begin + strips_per_wg) : s_begin + 1;
+  constexpr int KSL = 8;                           // k-steps of the LOOP form (C = 128)
+  half8 bres[LOOP ? KSL : 1][NT];                  // LOOP: the wave's target fragments, resident
+  half8 apre[2];                                   // LOOP: this thread's two 16-byte pieces of the next source operand
+  auto request_a = [&](int strip) {
+    const _Float16 *Ae = A + (size_t)e * HW1 * C;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int idx = tid + 512 * u, kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
+      apre[u] = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(strip * 64 + px, HW1 - 1)) * 16 + hf * 8);
+    }
+  };
+  auto stage_a = [&](_Float16 *dst) {  // this thread's two pieces -> LDS, fragment layout (see the non-LOOP staging below)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int idx = tid + 512 * u, kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
+      const int fa = ((((kbk * 2 + 0) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4;
+      half4 lo, hi;
+#pragma unroll
+      for (int c = 0; c < 4; c++) lo[c] = apre[u][c], hi[c] = apre[u][4 + c];
+      *reinterpret_cast<half4 *>(dst + fa) = lo;
+      *reinterpret_cast<half4 *>(dst + fa + 2 * 2 * 32 * 4) = hi;
+    }
+  };
+  if constexpr (LOOP) {
+    const int ty = min(ty0 + wave, h2 - 1);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const _Float16 *bpt = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + t * 32 + l31, HW2 - 1) * 16 + kh;
+#pragma unroll
+      for (int ks = 0; ks < KSL; ks++) bres[ks][t] = *reinterpret_cast<const half8 *>(bpt + (size_t)ks * 16 * HW2);
+    }
+    // (pinned: left to itself the compiler sinks these loads into the strip loop and re-reads the fragments per strip)
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int ks = 0; ks < KSL; ks++) asm volatile("" : "+v"(bres[ks][t]));
+    request_a(s_begin);
+    stage_a(Ab0);
+  }
+  for (int strip = s_begin; strip < s_end; strip++) {
+  const int p0 = strip * 64;                       // first source pixel of the strip
+  _Float16 *Ab = LOOP ? Ab0 + ((strip - s_begin) & 1) * (64 * 128) : Ab0;
+  // LOOP: the next strip's operand is requested now and consumed after this strip's tile write, i.e. BEFORE this strip's
+  // stores are issued: the wait for it (loads and stores of a wave complete in order) then only covers the previous
+  // strip's stores, which have had this strip's whole multiplication to drain
+  if constexpr (LOOP) {
+    if (strip + 1 < s_end) request_a(strip + 1);
+  }
+#ifdef FB_PROF
+  if (LOOP && (threadIdx.x & 63) == 0) prof[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + 7] += 1;
+#endif
 
   // ---- the strip's source operand, shared by the 8 waves: [C/16][64 pixels][16] halves into the (still unused) tile ----
   // (k-block-major like the global map, so a k-step's fragment is 32 lanes x 32 B contiguous: conflict-free b128 reads)
 #ifndef FB_ABLATE_MFMA
-  {
+  if constexpr (!LOOP) {
     const _Float16 *Ae = A + (size_t)e * HW1 * C;
     const int kblocks = C >> 4;
     for (int idx = tid; idx < kblocks * 128; idx += 512) {  // 16-byte pieces: [kblock][pixel][half of the 16 channels]
@@ -116,7 +180,8 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     }
   }
 #endif
-  __syncthreads();
+  if constexpr (LOOP) lds_barrier();  // (a __syncthreads would wait for the previous strip's stores)
+  else __syncthreads();
   FB_STAMP(1);
 
   // ---- MFMA: acc[i][j] = 32x32 tile (sources 32 i .. , targets 32 j ..) of target row ty0 + wave ------------------
@@ -127,7 +192,27 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
     for (int j = 0; j < NT; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  {
+  auto read_a = [&](int ks, half8 (&a)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const _Float16 *fp = Ab + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
+      const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
+    }
+  };
+  if constexpr (LOOP) {
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) {
+      half8 a[2];
+      read_a(ks, a);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bres[ks][j], a[i], acc[i][j], 0, 0, 0);  // targets x sources
+    }
+  } else {
     const int ty = min(ty0 + wave, h2 - 1);  // rows past the map are computed on a valid row and never stored
     const _Float16 *bp[NT];  // k-block-major map: element (k, pixel) at ((k >> 4) * HW + pixel) * 16 + (k & 15)
 #pragma unroll
@@ -150,13 +235,7 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
 #pragma unroll
       for (int t = 0; t < NT; t++) b2[t] = *reinterpret_cast<const half8 *>(bp[t] + (size_t)kn * 16 * kb);
       half8 a[2];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const _Float16 *fp = T + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
-        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
-#pragma unroll
-        for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
-      }
+      read_a(ks, a);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -198,6 +277,10 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
   }
   lds_barrier();  // the last barrier: everything below reads the tile only
   FB_STAMP(3);
+  if constexpr (LOOP) {
+    if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));  // ahead of this strip's stores
+    FB_STAMP(6);
+  }
 
   // ---- this lane's source pixel (levels 2, 3: a lane is one pixel) and its QUAD of pixels (levels 0, 1) ------------------
   const int p = p0 + lane;
@@ -446,10 +529,14 @@ __global__ __launch_bounds__(512, (NT <= 2) ? 4 : 2) void corr_build_fused_kerne
   store_level(2, P2, 2, W2P / 4);
   store_level(3, P3, 1, W2P / 8);
 #endif
-  FB_STAMP(5);
+  if constexpr (LOOP) FB_STAMP(5);
+  }  // strips of this workgroup
+  if constexpr (!LOOP) FB_STAMP(5);
 #ifdef FB_PROF
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  FB_STAMP(6);
+  if constexpr (!LOOP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FB_STAMP(6);
+  }
 #endif
 }
 
@@ -492,9 +579,11 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
   const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2>),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<4>),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<4, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
@@ -507,15 +596,51 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
 #else
 #define FB_PROF_ARG
 #endif
-  if (w2 <= 64) {
+  // DBA_BUILD_KERNEL=classic|loop forces one form where both apply (tests, A/B runs); read once per process
+  static const int force = [] {
+    const char *e = getenv("DBA_BUILD_KERNEL");
+    return !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  // the strip walk pays off where every quad of pixels is regular (rows of the source map a multiple of 4 wide and the
+  // map a whole number of strips: 64x64, 48x64); elsewhere (55x55) the two-workgroups-per-CU form hides the irregular
+  // quads' extra latency better
+  const bool loop_shape = (w1 % 4 == 0) && ((h1 * w1) % 64 == 0);
+  if (w2 <= 64 && C == 128 && force != 1 && (loop_shape || force == 2)) {
+    // strips per workgroup: as many as leave >= ~512 workgroups (two rounds of the 256 CUs), at most 16
+    const int nstrips = HW1p / 64;
+    const long long rows = (long long)grid.y * n;
+    int spw = (int)(((long long)nstrips * rows) / 512);
+    spw = spw < 1 ? 1 : (spw > 16 ? 16 : spw);
+    if (force == 2 && spw < 2) spw = 2;
+    const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
+    const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
+    hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
+                       inv_w1, spw FB_PROF_ARG);
+  } else if (w2 <= 64) {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
-    hipLaunchKernelGGL((corr_build_fused_kernel<2>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
+    hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
+                       1 FB_PROF_ARG);
   } else {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
-    hipLaunchKernelGGL((corr_build_fused_kernel<4>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1 FB_PROF_ARG);
+    hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
+                       1 FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
 #ifdef FB_PROF
+  if (w2 <= 64 && C == 128 && force != 1 && (loop_shape || force == 2)) {
+    (void)hipStreamSynchronize(s);
+    const int nstrips = HW1p / 64;
+    const size_t nw = (size_t)((nstrips + 15) / 1) * grid.y * n * 8;  // upper bound of wave slots
+    unsigned long long *hp = (unsigned long long *)malloc(nw * 64);
+    (void)hipMemcpy(hp, prof, nw * 64, hipMemcpyDeviceToHost);
+    double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nw; i++)
+      for (int k = 0; k < 8; k++) ph[k] += (double)hp[i * 8 + k];
+    const double per = ph[7] > 0 ? 1.0 / ph[7] : 0.0;
+    fprintf(stderr, "FB_PROF loop n=%d | ticks per strip and wave: operand in LDS + barrier %.0f, mfma %.0f, tile write %.0f, next operand (waits for the previous strip's stores) %.0f, level-0 stores + pooling %.0f, pooled stores %.0f | strips %.0f\n",
+            n, ph[1] * per, ph[2] * per, ph[3] * per, ph[6] * per, ph[4] * per, ph[5] * per, ph[7]);
+    free(hp);
+  } else
   {  // scratch builds: dump the phase timestamps of this launch (cycles of the 100 MHz constant clock)
     (void)hipStreamSynchronize(s);
     const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
