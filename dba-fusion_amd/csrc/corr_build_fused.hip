@@ -24,11 +24,14 @@
 //     LDS (two barriers) for the sheared store loops;
 //   * the strip's source operand (16 KB at C = 128) is staged ONCE per workgroup in the LDS the tile will take, and the
 //     target fragments are requested two k-steps ahead.
-// Where the time goes (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges; a workgroup lives 47 k cycles, two per CU):
-// source operand 9 %, MFMA phase 43 % (the 32 MFMAs per wave need a third of it; the rest is the target fragments,
-// 16 KB per wave out of L2 at ~20 B/clk/CU), tile write 6 %, level-0 stores 25 %, pooled levels 13 %, drain 3 %.
-// 19.8 us per edge = 2.36 TB/s of output, 0.295 of the HBM peak (round 1: 23.3 us; before the store loops below were
-// cut from ~70 to ~10 VALU instructions per 8-byte store: 22.6 us, 1935 VALU instructions per wave, VALU busy 64 %).
+// Where the time goes, one-strip form (in-kernel timestamps, -DFB_PROF, 64x64, 32 edges; a workgroup lives 47 k cycles,
+// two per CU): source operand 9 %, MFMA phase 43 % (the 32 MFMAs per wave need a third of it; the rest is the target
+// fragments, 16 KB per wave out of L2 at ~20 B/clk/CU), tile write 6 %, level-0 stores 25 %, pooled levels 13 %, drain
+// 3 %: 517 us per 32 edges = 16.2 us per edge, 0.36 of the HBM peak on the kernel alone (round 1: 23.3 us; before the
+// store loops below were cut from ~70 to ~10 VALU instructions per 8-byte store: 20.1 us, 1935 VALU instructions per
+// wave, VALU busy 64 %).  The strip-walking form (LOOP, see the kernel's comment) takes 413-439 us = 12.9-13.7 us per
+// edge, 0.43-0.45: ~21 k cycles per strip and wave, of which level-0 stores + pooling 7.1 k, pooled stores 4.5 k, 3.3-4.4 k
+// at the top of a strip (the next operand's loads wait behind the previous strip's stores), products 2.4 k, tile write 1.9 k.
 // What was measured and did not help (scratch/cu_rates.hip, scratch/lds_rates.hip, scratch/corr_build_pipe_experiment.hip):
 //   * one CU alone stores 28 B/clk, the whole chip 5.4-5.6 TB/s = 9 B/clk/CU: in the store phases, which all
 //     workgroups enter together, the chip is at HBM's write ceiling, in the MFMA phases HBM idles.  A persistent,
