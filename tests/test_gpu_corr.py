@@ -343,3 +343,31 @@ def test_sheared_lookup_with_workgroup_counts_that_are_not_multiples_of_8(n, h, 
     out = cb(torch.from_numpy(coords)[None].cuda()).cpu().numpy()[0]
     ref = orc.corr_lookup_pyramid(pyr_ref, coords, 3)
     assert np.array_equal(out.view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 11, 32])
+def test_strip_walking_build_for_every_chunking(n):
+    """the strip-walking form of the fused build (64-wide maps, C = 128) hands a workgroup 1, 2, 3, ... 16 consecutive
+    strips depending on the number of edges (incl. a last chunk that is shorter): bit for bit the unfused pipeline"""
+    from dbaf_amd.corr import CorrBlock
+    rng = np.random.default_rng(40 + n)
+    h, w, C = 64, 64, 128
+    t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    fused = CorrBlock.build_sheared_fused(t1, t2, 4)
+    unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
+    for lvl in range(4):
+        assert torch.equal(fused[lvl][..., :h * w].view(torch.int16), unfused[lvl][..., :h * w].view(torch.int16)), lvl
+
+
+def test_strip_walking_build_on_a_48x64_map_with_few_edges():
+    from dbaf_amd.corr import CorrBlock
+    rng = np.random.default_rng(77)
+    h, w, C = 48, 64, 128
+    for n in (1, 4):
+        t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+        t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+        fused = CorrBlock.build_sheared_fused(t1, t2, 4)
+        unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
+        for lvl in range(4):
+            assert torch.equal(fused[lvl][..., :h * w].view(torch.int16), unfused[lvl][..., :h * w].view(torch.int16)), (n, lvl)
