@@ -715,11 +715,16 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
   } else {
     if (!scratch) return DBA_ERR_WORKSPACE;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
-    // two tiles per thread on 1024 threads first (a step costs what one wave's tiles cost), three on 512 for what is left
+    // two tiles per thread on 1024 threads (a step costs what one wave's tiles cost).  The older variant with three tiles
+    // on 512 threads has fewer tile slots (1536 against 2048) and the same panel limits, so nothing reaches it that the
+    // first one left: it is no longer queued (4.6 us per solve even when it returns at once), only kept for
+    // DBA_SOLVE_BAND_BIG=512
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 2, true>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
                        H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
-    hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
-                       SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
+    static const bool also512 = [] { const char *e = getenv("DBA_SOLVE_BAND_BIG"); return e && e[0] == '5'; }();
+    if (also512)
+      hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
+                         SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;
