@@ -193,8 +193,28 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   const int ablocks = (N + 3) / 4 + (plan.T.Mmax + 7) / 8;
   if (plan.P <= 0) return DBA_OK;
   if (!motion_only) {  // Schur products and the pose-block assembly share one launch (both only add into H, b)
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
-                       (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
+    // per-source-frame form (every row of E read once, Gram tiles on the matrix cores); DBA_SCHUR_KERNEL=rows keeps
+    // the (row, partner) grid, which also takes graphs with more edges than the frame form's row list holds
+    static const bool rows_form = [] { const char *e = getenv("DBA_SCHUR_KERNEL"); return e && e[0] == 'r'; }();
+    static const int env_nch = [] { const char *e = getenv("DBA_SCHUR_NCH"); return e ? atoi(e) : 0; }();
+    if (rows_form || N + 1 > GRAM_LIST_CAP) {
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
+                         (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
+    } else {
+      // pixel chunks per frame: ~1024 pixels per workgroup (256 per wave) on windows whose frames have many rows (the
+      // matrix-core time of a chunk grows with the square of the row count), ~512 on sparse ones (latency-bound)
+      const int rows_est = 1 + (plan.T.Mmax > 0 ? (N + plan.T.Mmax - 1) / plan.T.Mmax : 0);
+      const int px = (rows_est > 6) ? 1024 : 512;
+      int nch = env_nch > 0 ? env_nch : (plan.HW + px - 1) / px;
+      nch = std::max(1, std::min(nch, (plan.HW + 15) / 16));
+      const dim3 grid((unsigned)(plan.T.Mmax * nch + ablocks));
+      if (plan.HW % 4 == 0)
+        hipLaunchKernelGGL((ba_schur_gram_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
+                           plan.HW, t0, plan.P, nch, plan.T, plan.W);
+      else
+        hipLaunchKernelGGL((ba_schur_gram_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
+                           plan.HW, t0, plan.P, nch, plan.T, plan.W);
+    }
     DBA_LAUNCH_CHECK();
   } else if (ablocks > 0) {
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,

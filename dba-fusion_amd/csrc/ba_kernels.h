@@ -70,6 +70,10 @@ __global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const u
                                    int t0, int P, BaTables T, BaBuffers W);
 __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                 int t0, int P, BaTables T, BaBuffers W);
+constexpr int GRAM_LIST_CAP = 1024;  // rows of one frame the per-source-frame Schur kernel lists in LDS
+template <bool VEC>
+__global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
+                                     int t0, int P, int nch, BaTables T, BaBuffers W);
 __global__ void ba_update_kernel(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned,
                                  int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
                                  float *dx_out, BaTables T, BaBuffers W);

@@ -939,6 +939,289 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage 2, per-source-frame form: every row of E is read ONCE
+// ---------------------------------------------------------------------------------------------
+// The rows of E that share a source frame m -- the row of its own pose and the rows of its out-edges -- are mutually
+// coupled through Q_m:  H -= E_a diag(Q_m) E_b^T for every pair (a, b),  b -= E_a (Q_m o w_m)
+// (schur_block + EEt6x6_kernel + Ev6x1_kernel, droid_kernels.cu:1046-1138, :1297-1391).  Stack the frame's values per
+// pixel k as x_k = [w_m | E_0 (6) | E_1 (6) | ...] (R = 1 + 6 r values): all of the above are entries of ONE Gram matrix
+//     G = sum_k q_k x_k x_k^T          (column 0 of G holds the right-hand side terms),
+// a SYRK with K = HW.  ba_schur_kernel walks (row, partner) pairs and re-reads every row once per partner (5 x at 64 KF /
+// 512 edges, from L2 / the Infinity Cache: 86 us); here a workgroup owns (frame, pixel chunk), every wave streams its
+// share of the pixels ONCE and accumulates the lower triangle of G in 16 x 16 tiles on the matrix cores
+// (v_mfma_f32_16x16x4_f32: A = q o x, B = x; a lane's operand for tile t is value 16 t + (lane & 15) of pixel
+// 4 (lane >> 4) + s of its 16-pixel group, i.e. one 16-byte load per tile and group serves four k-steps), the four
+// waves' tiles meet in LDS (fixed order: the sum does not depend on scheduling) and leave as float64 atomics.
+constexpr int GRAM_MAX_T = 6;                             // 16-value tiles of the stacked vector (21 tiles of G: 84 accumulator
+                                                          // registers; with 8 the kernel needs 477 and one wave per SIMD is left)
+constexpr int GRAM_MAX_ROWS = (16 * GRAM_MAX_T - 1) / 6;  // 15 rows; frames with more take the row-pair path below
+constexpr int GRAM_MAX_TILES = GRAM_MAX_T * (GRAM_MAX_T + 1) / 2;
+
+template <int T>
+struct GramStage {
+  lin_f4 q;
+  lin_f4 e[T];
+};
+
+template <int T, bool VEC>
+__device__ __forceinline__ void gram_load(GramStage<T> &S, const float *const (&bp)[T], const float *qm, int g, int gend,
+                                          int c0, int c1, int lk) {
+  const int p4 = c0 + 16 * g + 4 * lk;
+  if (g < gend && p4 + 3 < c1) {
+    if constexpr (VEC) {
+      S.q = *reinterpret_cast<const lin_f4 *>(qm + p4);
+#pragma unroll
+      for (int t = 0; t < T; t++) S.e[t] = *reinterpret_cast<const lin_f4 *>(bp[t] + p4);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++) S.q[s] = qm[p4 + s];
+#pragma unroll
+      for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) S.e[t][s] = bp[t][p4 + s];
+    }
+  } else {  // past the wave's share, or the ragged last group of the chunk: exact zeros
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const bool ok = (g < gend) && (p4 + s < c1);
+      const int pi = ok ? p4 + s : c0;
+      const float qv = qm[pi];
+      S.q[s] = ok ? qv : 0.f;
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const float ev = bp[t][pi];
+        S.e[t][s] = ok ? ev : 0.f;
+      }
+    }
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void gram_mac(const GramStage<T> &S, lin_f4 (&acc)[T * (T + 1) / 2]) {
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    float a[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) a[t] = S.e[t][s] * S.q[s];
+#pragma unroll
+    for (int ti = 0; ti < T; ti++)
+#pragma unroll
+      for (int tj = 0; tj <= ti; tj++)
+        acc[ti * (ti + 1) / 2 + tj] =
+            __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], S.e[tj][s], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+  }
+}
+
+// the frame's Gram tiles over the pixels [c0, c1) -> red[tile][r][lane] (sum of the workgroup's four waves)
+template <int T, bool VEC>
+__device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, const float *qm, const int *s_rows, int nrows,
+                                           int c0, int c1, int HW, float *red) {
+  constexpr int NT = T * (T + 1) / 2;
+  constexpr int UNR = (T <= 3) ? 4 : (T <= 5 ? 2 : 1);  // 16-pixel groups per batch; two batches in flight
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const float *bp[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    const int c = 16 * t + li;             // stacked value: 0 = w, 1 + 6 a + comp = row a of the frame's list
+    const int a = (c > 0) ? (c - 1) / 6 : 0;
+    const int comp = (c > 0) ? (c - 1) - 6 * a : 0;
+    // (values past the stack read w again: finite, and their rows / columns of G are never looked at)
+    bp[t] = (c == 0 || a >= nrows) ? wm : W.E + ((size_t)s_rows[a] * 6 + comp) * HW;
+  }
+  lin_f4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = lin_f4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups = (c1 - c0 + 15) / 16;
+  const int per = (ngroups + 3) / 4;  // a wave takes a contiguous run of groups: consecutive groups share 128-byte lines
+  const int gbeg = wv * per, gend = min(ngroups, gbeg + per);
+  GramStage<T> A[UNR], B[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; u++) gram_load<T, VEC>(A[u], bp, qm, gbeg + u, gend, c0, c1, lk);
+  for (int g = gbeg; g < gend; g += 2 * UNR) {
+#pragma unroll
+    for (int u = 0; u < UNR; u++) gram_load<T, VEC>(B[u], bp, qm, g + UNR + u, gend, c0, c1, lk);
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      if (g + u < gend) gram_mac<T>(A[u], acc);
+#pragma unroll
+    for (int u = 0; u < UNR; u++) gram_load<T, VEC>(A[u], bp, qm, g + 2 * UNR + u, gend, c0, c1, lk);
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      if (g + UNR + u < gend) gram_mac<T>(B[u], acc);
+  }
+  // the four waves' tiles, added in wave order (a sum that does not depend on which wave arrives first)
+  for (int w = 0; w < 4; w++) {
+    if (wv == w) {
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float *p = red + (i * 4 + r) * 64 + lane;
+          *p = (w == 0) ? acc[i][r] : *p + acc[i][r];
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// frames with more rows than the tiles hold: one (a, b) pair of rows at a time over the chunk (the arithmetic of
+// ba_schur_kernel; such frames have 15 or more out-edges)
+__device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const float *qm, const int *s_rows, const int *s_tgt,
+                                 int nrows, int c0, int c1, int HW, int n6, float *red) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int a = 0; a < nrows; a++) {
+    const float *E1 = W.E + (size_t)s_rows[a] * 6 * HW;
+    const int tgt1 = s_tgt[a];
+    for (int b = a; b < nrows; b++) {
+      const bool self = (a == b);
+      const float *E2 = W.E + (size_t)s_rows[b] * 6 * HW;
+      const int tgt2 = s_tgt[b];
+      float acc[36], sv[6];
+#pragma unroll
+      for (int c = 0; c < 36; c++) acc[c] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; c++) sv[c] = 0.f;
+      for (int k = c0 + tid; k < c1; k += 256) {
+        const float q = qm[k];
+        float e1v[6], e2v[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          e1v[c] = E1[(size_t)c * HW + k] * q;
+          e2v[c] = E2[(size_t)c * HW + k];
+        }
+#pragma unroll
+        for (int x = 0; x < 6; x++)
+#pragma unroll
+          for (int y = 0; y < 6; y++) acc[x * 6 + y] = fmaf(e1v[x], e2v[y], acc[x * 6 + y]);
+        if (self) {
+          const float wk = wm[k];
+#pragma unroll
+          for (int c = 0; c < 6; c++) sv[c] = fmaf(e1v[c], wk, sv[c]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 36; c++) {
+        const float r = wave_sum_to_lane63(acc[c]);
+        if (lane == 63) red[wv * 44 + c] = r;
+      }
+      if (self) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const float r = wave_sum_to_lane63(sv[c]);
+          if (lane == 63) red[wv * 44 + 36 + c] = r;
+        }
+      }
+      __syncthreads();
+      if (tid < 36) {
+        const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
+        const int x = tid / 6, y = tid % 6;
+        atomic_add_f64(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s);
+        if (!self) atomic_add_f64(&W.H[(size_t)(6 * tgt2 + y) * n6 + 6 * tgt1 + x], -s);
+      } else if (self && tid < 42) {
+        const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
+        atomic_add_f64(&W.b[6 * tgt1 + (tid - 36)], -s);
+      }
+    }
+  }
+}
+
+// grid: [0, Mmax * nch) = (frame slot, pixel chunk); blocks after that do the pose-block assembly (as in ba_schur_kernel)
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
+                                                            const uint8_t *__restrict__ frame_owned, int N, int HW,
+                                                            int t0, int P, int nch, BaTables T, BaBuffers W) {
+  __shared__ float red[GRAM_MAX_TILES * 256];
+  __shared__ int s_rows[GRAM_LIST_CAP], s_tgt[GRAM_LIST_CAP];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int frames_blocks = T.Mmax * nch;
+  if ((int)blockIdx.x >= frames_blocks) {
+    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, T, W);
+    return;
+  }
+  const int m = (int)blockIdx.x / nch, ch = (int)blockIdx.x - m * nch;
+  if (m >= T.meta[0]) return;
+  const int frame = T.kx[m];
+  if (frame_owned && !frame_owned[frame]) return;
+  // chunk of the frame's pixels: a multiple of 16 (aligned 16-byte operand loads)
+  const int cpx = ((HW + nch - 1) / nch + 15) / 16 * 16;
+  const int c0 = ch * cpx, c1 = min(HW, c0 + cpx);
+  if (c0 >= c1) return;
+
+  // the frame's rows of E with a pose inside the window: its own pose row, then its out-edges in list order
+  if (tid < 64) {
+    int n = 0;
+    const int p = frame - t0;
+    if (p >= 0 && p < P) {
+      if (lane == 0) s_rows[0] = p, s_tgt[0] = p;
+      n = 1;
+    }
+    const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
+    for (int base = e0; base < e1; base += 64) {
+      const int pos = base + lane;
+      int en = 0, tg = -1;
+      if (pos < e1) {
+        const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * pos);
+        en = ei.x, tg = ei.y - t0;
+      }
+      const bool ok = (tg >= 0) && (tg < P);
+      const unsigned long long bal = __ballot(ok);
+      const int idx = n + __popcll(bal & ((1ull << lane) - 1ull));
+      if (ok && idx < GRAM_LIST_CAP) s_rows[idx] = P + en, s_tgt[idx] = tg;
+      n += __popcll(bal);
+    }
+    if (lane == 0) s_n = min(n, GRAM_LIST_CAP);
+  }
+  __syncthreads();
+  const int nrows = s_n;
+  if (nrows == 0) return;
+  const float *wm = W.w + (size_t)m * HW, *qm = W.Q + (size_t)m * HW;
+  const int n6 = 6 * P;
+  if (nrows > GRAM_MAX_ROWS) {
+    gram_frame_pairs(W, wm, qm, s_rows, s_tgt, nrows, c0, c1, HW, n6, red);
+    return;
+  }
+  const int R = 1 + 6 * nrows, Tn = (R + 15) / 16;
+  switch (Tn) {
+    case 1: gram_frame<1, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    case 2: gram_frame<2, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    case 3: gram_frame<3, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    case 4: gram_frame<4, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    case 5: gram_frame<5, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    default: gram_frame<6, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+  }
+  // scatter: tile (ti, tj <= ti), register r, lane l  <->  G[i][j], i = 16 ti + 4 (l >> 4) + r, j = 16 tj + (l & 15).
+  // Entry (i, j), i >= j >= 1, is row a = (i - 1) / 6 against row b = (j - 1) / 6 of the list: it goes to both mirrored
+  // positions of H (the two orders of a pair; within a diagonal block G[i][j] serves (i, j) and (j, i)); column 0 is b.
+  const int ntiles = Tn * (Tn + 1) / 2;
+  const int r = tid >> 6, li = lane & 15, lk = lane >> 4;
+  int ti = 0, tj = 0;
+  for (int idx = 0; idx < ntiles; idx++) {
+    const int i = 16 * ti + 4 * lk + r, j = 16 * tj + li;
+    if (i < R && j <= i && i >= 1) {
+      const double s = -(double)red[(idx * 4 + r) * 64 + lane];
+      const int a = (i - 1) / 6, ca = (i - 1) - 6 * a;
+      const int hr = 6 * s_tgt[a] + ca;
+      if (j == 0) {
+        atomic_add_f64(&W.b[hr], s);
+      } else {
+        const int b = (j - 1) / 6, cb = (j - 1) - 6 * b;
+        const int hc = 6 * s_tgt[b] + cb;
+        atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
+        if (i != j) atomic_add_f64(&W.H[(size_t)hc * n6 + hr], s);
+      }
+    }
+    if (++tj > ti) ti++, tj = 0;
+  }
+}
+template __global__ void ba_schur_gram_kernel<true>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int, int,
+                                                    BaTables, BaBuffers);
+template __global__ void ba_schur_gram_kernel<false>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int,
+                                                     int, BaTables, BaBuffers);
+
+// ---------------------------------------------------------------------------------------------
 // stage 4: back-substitution + retraction
 // ---------------------------------------------------------------------------------------------
 // expSE3 / retrSE3 (droid_kernels.cu:113-178, :922-940); quaternion deliberately not renormalised.
