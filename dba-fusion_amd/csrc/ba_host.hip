@@ -57,6 +57,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const size_t o_fpose = take(sizeof(int) * (size_t)(P > 0 ? P : 1));
   const size_t o_einfo = take(sizeof(int) * 2 * (size_t)(N > 0 ? N : 1));
   const size_t o_rowinfo = take(sizeof(int) * 8 * (size_t)(P + N > 0 ? P + N : 1));
+  const size_t o_fhead = take(sizeof(int) * 4 * (size_t)(Mmax > 0 ? Mmax : 1));
+  const size_t o_frow = take(sizeof(int) * 2 * (size_t)(P + N > 0 ? P + N : 1));
   L.E = take(sizeof(float) * (size_t)(P + N) * 6 * HW);
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
@@ -93,6 +95,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->T.fpose = reinterpret_cast<int *>(base + o_fpose);
     plan->T.einfo = reinterpret_cast<int *>(base + o_einfo);
     plan->T.rowinfo = reinterpret_cast<int *>(base + o_rowinfo);
+    plan->T.fhead = reinterpret_cast<int *>(base + o_fhead);
+    plan->T.frow = reinterpret_cast<int *>(base + o_frow);
     plan->T.Mmax = Mmax;
     plan->T.B = B;
     plan->W.E = reinterpret_cast<float *>(base + L.E);
@@ -143,14 +147,15 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
   const int want = std::max(std::max(N, B), t1 - t0);
   const int threads = std::min(1024, std::max(64, (want + 63) / 64 * 64));
   const size_t scan_ints = std::max<size_t>(std::max(threads, t1 - t0), N > threads ? 1024 : 0) + 32;
-  const size_t lds = sizeof(int) * ((size_t)B + 2 * (size_t)plan.T.Mmax + 1 + scan_ints);
+  // (+ validity flags of the edges and per-slot row counts for the frame row table: threads + Mmax + 1 ints)
+  const size_t lds = sizeof(int) * ((size_t)B + 2 * (size_t)plan.T.Mmax + 1 + scan_ints + threads + plan.T.Mmax + 1);
   if (lds > 160 * 1024 || t1 - t0 > 16384) return DBA_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_prepare_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
-                     plan.T);
+                     (int)scan_ints, plan.T);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -185,21 +190,25 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
   return DBA_OK;
 }
 
-int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
-                  int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
+// lower != 0: only the lower triangle of H is kept up (half the float64 atomics; the solvers read nothing else)
+static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
+                           int wd, int t0, int t1, int motion_only, int lower, void *ws, size_t ws_bytes,
+                           dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int ablocks = (N + 3) / 4 + (plan.T.Mmax + 7) / 8;
   if (plan.P <= 0) return DBA_OK;
+  static const bool force_full = [] { const char *e = getenv("DBA_H_FULL"); return e && e[0] == '1'; }();
+  if (force_full) lower = 0;
   if (!motion_only) {  // Schur products and the pose-block assembly share one launch (both only add into H, b)
     // per-source-frame form (every row of E read once, Gram tiles on the matrix cores); DBA_SCHUR_KERNEL=rows keeps
-    // the (row, partner) grid, which also takes graphs with more edges than the frame form's row list holds
+    // the (row, partner) grid, which also takes graphs with more edges than the prepare kernel lists per frame
     static const bool rows_form = [] { const char *e = getenv("DBA_SCHUR_KERNEL"); return e && e[0] == 'r'; }();
     static const int env_nch = [] { const char *e = getenv("DBA_SCHUR_NCH"); return e ? atoi(e) : 0; }();
     if (rows_form || N + 1 > GRAM_LIST_CAP) {
       hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
-                         (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, plan.T, plan.W);
+                         (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, lower, plan.T, plan.W);
     } else {
       // pixel chunks per frame: ~1024 pixels per workgroup (256 per wave) on windows whose frames have many rows (the
       // matrix-core time of a chunk grows with the square of the row count), ~512 on sparse ones (latency-bound)
@@ -210,17 +219,33 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
       const dim3 grid((unsigned)(plan.T.Mmax * nch + ablocks));
       if (plan.HW % 4 == 0)
         hipLaunchKernelGGL((ba_schur_gram_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
-                           plan.HW, t0, plan.P, nch, plan.T, plan.W);
+                           plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
       else
         hipLaunchKernelGGL((ba_schur_gram_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
-                           plan.HW, t0, plan.P, nch, plan.T, plan.W);
+                           plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
     }
     DBA_LAUNCH_CHECK();
   } else if (ablocks > 0) {
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned,
-                       N, t0, plan.P, plan.T, plan.W);
+                       N, t0, plan.P, lower, plan.T, plan.W);
     DBA_LAUNCH_CHECK();
   }
+  return DBA_OK;
+}
+
+int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
+                  int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  return ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 0, ws, ws_bytes, stream);
+}
+
+int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  const int n = 6 * plan.P;
+  if (n <= 0) return DBA_OK;
+  hipLaunchKernelGGL(ba_symmetrize_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.H, n);
+  DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
 
@@ -272,7 +297,8 @@ int dba_ba_shard_front(const float *poses, const float *disps, const float *intr
   const int rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj,
                                   frame_owned, N, B, ht, wd, t0, t1, alpha, ws, ws_bytes, stream);
   if (rc != DBA_OK) return rc;
-  return dba_ba_reduce(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, ws, ws_bytes, stream);
+  // (lower triangle only: what the redundant solves read; ShardedBACore mirrors it before handing H to the host)
+  return ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
 }
 
 int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
@@ -299,7 +325,7 @@ int dba_ba(float *poses, float *disps, const float *intrinsics, const float *dis
     rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj,
                           nullptr, N, B, ht, wd, t0, t1, alpha, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
-    rc = dba_ba_reduce(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, ws, ws_bytes, stream);
+    rc = ba_reduce_stage(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
     rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true);
     if (rc != DBA_OK) return rc;

@@ -30,6 +30,10 @@ struct BaTables {
   int *einfo;       // [N][2]     per list position: edge id, target frame jj
   int *rowinfo;     // [P+N][8]   per row of E (pose p | P + edge n): slot (-1: nothing to do), target pose - t0,
                     //            first partner position, end of the slot's list, source frame
+  // per source frame, for the per-source-frame Schur kernel: the rows of E it couples (its own pose row, then its
+  // out-edges with a pose inside the window, in list order)
+  int *fhead;       // [Mmax][4]  frame id (-1: slot unused), first entry in frow, number of rows, -
+  int *frow;        // [P+N][2]   row of E, pose index (- t0) it belongs to
   int Mmax, B;
 };
 
@@ -58,7 +62,7 @@ struct BaPlan {  // host-side view of the workspace
 int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan);
 
 // kernels (ba_kernels.hip / ba_solve.hip)
-__global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1,
+__global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1, int scan_ints,
                                   BaTables T);
 template <int PPL, bool MF, int EW>
 __global__ void ba_linearize_kernel(const float *poses, const float *disps, const float *intrinsics,
@@ -66,14 +70,16 @@ __global__ void ba_linearize_kernel(const float *poses, const float *disps, cons
                                     const float *eta, int eta_rows, const int64_t *jj,
                                     const uint8_t *frame_owned, int N, int HW, int wd, int t0, int P,
                                     float alpha, BaTables T, BaBuffers W);
+// lower != 0 (here and below): only the lower triangle of H is kept up (what the solvers read)
 __global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
-                                   int t0, int P, BaTables T, BaBuffers W);
+                                   int t0, int P, int lower, BaTables T, BaBuffers W);
 __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
-                                int t0, int P, BaTables T, BaBuffers W);
+                                int t0, int P, int lower, BaTables T, BaBuffers W);
+__global__ void ba_symmetrize_kernel(double *H, int n);
 constexpr int GRAM_LIST_CAP = 1024;  // rows of one frame the per-source-frame Schur kernel lists in LDS
 template <bool VEC>
 __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
-                                     int t0, int P, int nch, BaTables T, BaBuffers W);
+                                     int t0, int P, int nch, int lower, BaTables T, BaBuffers W);
 __global__ void ba_update_kernel(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned,
                                  int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
                                  float *dx_out, BaTables T, BaBuffers W);

@@ -41,12 +41,14 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // cheaper than among 16).  LDS: flag[B] cnt[Mmax + 1] kxs[Mmax] scan[max(blockDim, 1024 if N > blockDim)].
 __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restrict__ ii,
                                                           const int64_t *__restrict__ jj, int N, int B,
-                                                          int t0, int t1, BaTables T) {
+                                                          int t0, int t1, int scan_ints, BaTables T) {
   extern __shared__ int sm[];
   int *flag = sm;
   int *cnt = sm + B;
   int *kxs = cnt + T.Mmax + 1;
   int *scan = kxs + T.Mmax;
+  int *sval = scan + scan_ints;      // [blockDim] 1 = the edge of this thread has its target pose inside the window
+  int *vcnt = sval + blockDim.x;     // [Mmax + 1] rows of E per slot (frame row table), then their exclusive scan
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int P = t1 - t0;
   // this thread's first edge stays in registers (the usual graph has at most one edge per thread): the passes
@@ -133,21 +135,61 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   // ascending-n fill: position = #earlier edges with the same source frame (source frames staged in LDS, so the
   // O(N^2) comparison never goes back to global memory)
   int *sii = scan;
+  const int Mv0 = min(M, T.Mmax);
   if (N <= nt) {  // the usual case: one pass, the rank stays in a register
+    // ... and the frame row table of the per-source-frame Schur kernel is built on the way: slot m couples its own
+    // pose row (if the frame is a window pose) and the rows of its out-edges whose target is one, in list order
+    const bool myvalid = (tid < N) && (slot_of(my_i) >= 0) && (my_j - t0 >= 0) && (my_j - t0 < P);
     if (tid < N) sii[tid] = my_i;
+    sval[tid] = myvalid ? 1 : 0;
+    for (int m = tid; m <= T.Mmax; m += nt) {
+      const int pp = (m < Mv0) ? kxs[m] - t0 : -1;
+      vcnt[m] = (pp >= 0 && pp < P) ? 1 : 0;
+    }
     __syncthreads();
+    int vrank = 0;
     if (tid < N) {
       const int f = sii[tid], m = slot_of(f);
       int pos = -1;
       if (m >= 0) {
         int rank = 0;
-        for (int q = 0; q < tid; q++) rank += (sii[q] == f);
+        for (int q = 0; q < tid; q++) {
+          const bool same = (sii[q] == f);
+          rank += same;
+          vrank += same && sval[q];
+        }
         pos = cnt[m] + rank;
         T.elist[pos] = tid;
+        if (myvalid) atomicAdd(&vcnt[m], 1);
       }
       emit_edge(tid, m, pos, my_j);
     }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the row counts; vcnt keeps the offsets
+      int carry = 0;
+      for (int base = 0; base < T.Mmax; base += 64) {
+        const int m = base + lane;
+        const int v = (m < T.Mmax) ? vcnt[m] : 0;
+        const int w = wave_incl_scan(v, lane);
+        if (m < T.Mmax) {
+          const int pp = (m < Mv0) ? kxs[m] - t0 : -1;
+          const bool own = (pp >= 0 && pp < P);
+          const int off = carry + w - v;
+          int *fh = T.fhead + 4 * m;
+          fh[0] = (m < Mv0) ? kxs[m] : -1, fh[1] = off, fh[2] = v, fh[3] = 0;
+          if (own) T.frow[2 * off] = pp, T.frow[2 * off + 1] = pp;
+          vcnt[m] = off + (own ? 1 : 0);  // where the slot's edge rows start
+        }
+        carry += __shfl(w, 63, 64);
+      }
+    }
+    __syncthreads();
+    if (myvalid) {
+      const int o = vcnt[slot_of(my_i)] + vrank;
+      T.frow[2 * o] = P + tid, T.frow[2 * o + 1] = my_j - t0;
+    }
   } else {        // chunks of 1024 source frames, ranks accumulated in global scratch
+    for (int m = tid; m < T.Mmax; m += nt) T.fhead[4 * m] = -1, T.fhead[4 * m + 2] = 0;  // (the row-pair Schur kernel runs)
     for (int n = tid; n < N; n += nt) T.elist_rank[n] = 0;
     for (int base = 0; base < N; base += 1024) {
       __syncthreads();
@@ -763,13 +805,26 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// lower-triangle bookkeeping of H: position (hr, hc) and its mirror image both receive s in the full matrix; with
+// lower = true only the lower triangle is kept up (what the solvers read), the diagonal then receives both
+__device__ __forceinline__ void h_add_pair(const BaBuffers &W, int n6, int hr, int hc, double s, bool lower) {
+  if (lower) {
+    if (hr == hc) atomic_add_f64(&W.H[(size_t)hr * n6 + hc], 2.0 * s);
+    else atomic_add_f64(&W.H[(size_t)max(hr, hc) * n6 + min(hr, hc)], s);
+  } else {
+    atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
+    atomic_add_f64(&W.H[(size_t)hc * n6 + hr], s);
+  }
+}
+
+
 // pose-block assembly (SparseBlock::update_lhs / update_rhs, :1176-1218, :1457-1462): fold the per-wave
 // J^T W J partials and scatter them into H, b.  blocks [0, ceil(N/4)) take 4 edges each (64 lanes per
 // edge), blocks after that take 8 frame slots each (32 lanes per slot).
 __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__restrict__ ii,
                                                   const int64_t *__restrict__ jj,
                                                   const uint8_t *__restrict__ frame_owned, int N, int t0, int P,
-                                                  const BaTables &T, const BaBuffers &W) {
+                                                  bool lower, const BaTables &T, const BaBuffers &W) {
   const int tid = threadIdx.x;
   const int n6 = 6 * P;
   const int edge_blocks = (N + 3) / 4;
@@ -794,10 +849,7 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
     const bool iv = (i >= 0 && i < P), jv = (j >= 0 && j < P);
     if (l < 36) {  // Hji[a][b] and its transpose Hij[b][a]
       const int a = l / 6, b = l % 6;
-      if (iv && jv) {
-        atomic_add_f64(&W.H[(size_t)(6 * j + a) * n6 + 6 * i + b], s);
-        atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * j + a], s);
-      }
+      if (iv && jv) h_add_pair(W, n6, 6 * j + a, 6 * i + b, s, lower);
     } else if (l < 57) {  // Hjj
       int a = 0;
       const int t = l - 36;
@@ -805,7 +857,7 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
       const int b = t - a * (a + 1) / 2;
       if (jv) {
         atomic_add_f64(&W.H[(size_t)(6 * j + a) * n6 + 6 * j + b], s);
-        if (a != b) atomic_add_f64(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s);
+        if (a != b && !lower) atomic_add_f64(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s);
       }
     } else {
       if (jv) atomic_add_f64(&W.b[6 * j + (l - 57)], s);
@@ -837,7 +889,7 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
     while ((a + 1) * (a + 2) / 2 <= l) a++;
     const int b = l - a * (a + 1) / 2;
     atomic_add_f64(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s);
-    if (a != b) atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s);
+    if (a != b && !lower) atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s);
   } else {
     atomic_add_f64(&W.b[6 * i + (l - 21)], s);
   }
@@ -846,8 +898,8 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
 __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restrict__ ii,
                                                           const int64_t *__restrict__ jj,
                                                           const uint8_t *__restrict__ frame_owned, int N,
-                                                          int t0, int P, BaTables T, BaBuffers W) {
-  ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, T, W);
+                                                          int t0, int P, int lower, BaTables T, BaBuffers W) {
+  ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
 }
 
 // Schur complement (schur_block + EEt6x6_kernel + Ev6x1_kernel, :1046-1138, :1297-1391).
@@ -859,12 +911,13 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
 __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict__ ii,
                                                        const int64_t *__restrict__ jj,
                                                        const uint8_t *__restrict__ frame_owned, int N, int HW,
-                                                       int t0, int P, BaTables T, BaBuffers W) {
+                                                       int t0, int P, int lower, BaTables T, BaBuffers W) {
   __shared__ float red[4][44];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n6 = 6 * P;
   if ((int)blockIdx.x >= P + N) {
-    if (blockIdx.y == 0 && blockIdx.z == 0) ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, T, W);
+    if (blockIdx.y == 0 && blockIdx.z == 0)
+      ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
     return;
   }
   // everything a row needs comes from its table row (one load): slot, target pose, partner range, source frame
@@ -929,8 +982,8 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
     if (tid < 36) {
       const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
       const int a = tid / 6, b = tid % 6;
-      atomic_add_f64(&W.H[(size_t)(6 * tgt1 + a) * n6 + 6 * tgt2 + b], -s);
-      if (!self) atomic_add_f64(&W.H[(size_t)(6 * tgt2 + b) * n6 + 6 * tgt1 + a], -s);
+      if (!self) h_add_pair(W, n6, 6 * tgt1 + a, 6 * tgt2 + b, -s, lower != 0);
+      else if (!lower || a >= b) atomic_add_f64(&W.H[(size_t)(6 * tgt1 + a) * n6 + 6 * tgt2 + b], -s);
     } else if (self && tid < 42) {
       const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
       atomic_add_f64(&W.b[6 * tgt1 + (tid - 36)], -s);
@@ -948,14 +1001,17 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
 //     G = sum_k q_k x_k x_k^T          (column 0 of G holds the right-hand side terms),
 // a SYRK with K = HW.  ba_schur_kernel walks (row, partner) pairs and re-reads every row once per partner (5 x at 64 KF /
 // 512 edges, from L2 / the Infinity Cache: 86 us); here a workgroup owns (frame, pixel chunk), every wave streams its
-// share of the pixels ONCE and accumulates the lower triangle of G in 16 x 16 tiles on the matrix cores
-// (v_mfma_f32_16x16x4_f32: A = q o x, B = x; a lane's operand for tile t is value 16 t + (lane & 15) of pixel
-// 4 (lane >> 4) + s of its 16-pixel group, i.e. one 16-byte load per tile and group serves four k-steps), the four
-// waves' tiles meet in LDS (fixed order: the sum does not depend on scheduling) and leave as float64 atomics.
-constexpr int GRAM_MAX_T = 6;                             // 16-value tiles of the stacked vector (21 tiles of G: 84 accumulator
-                                                          // registers; with 8 the kernel needs 477 and one wave per SIMD is left)
-constexpr int GRAM_MAX_ROWS = (16 * GRAM_MAX_T - 1) / 6;  // 15 rows; frames with more take the row-pair path below
+// share of the pixels ONCE and accumulates the lower triangle of G in 16 x 16 tiles on the matrix cores, in FLOAT64
+// (v_mfma_f64_16x16x4_f64: the products of two floats are exact in double and so, to all purposes, are the sums: the
+// reduced system loses nothing to the order of summation -- an f32 accumulation was measured 2.3 x further from the
+// float64 arbiter than the row-pair kernel's tree sums on the small fixtures).  A lane's operand for tile t is value
+// 16 t + (lane & 15) of pixel 4 (lane >> 4) + s of its 16-pixel group, i.e. one 16-byte load per tile and group serves
+// four k-steps.  The four waves' tiles meet in LDS in wave order; the lower triangle leaves as float64 atomics.
+constexpr int GRAM_MAX_T = 5;                             // 16-value tiles of the stacked vector (15 tiles of G: 120
+                                                          // accumulator registers)
+constexpr int GRAM_MAX_ROWS = (16 * GRAM_MAX_T - 1) / 6;  // 13 rows; frames with more take the row-pair path below
 constexpr int GRAM_MAX_TILES = GRAM_MAX_T * (GRAM_MAX_T + 1) / 2;
+typedef double gram_d4 __attribute__((ext_vector_type(4)));
 
 template <int T>
 struct GramStage {
@@ -997,27 +1053,31 @@ __device__ __forceinline__ void gram_load(GramStage<T> &S, const float *const (&
 }
 
 template <int T>
-__device__ __forceinline__ void gram_mac(const GramStage<T> &S, lin_f4 (&acc)[T * (T + 1) / 2]) {
+__device__ __forceinline__ void gram_mac(const GramStage<T> &S, gram_d4 (&acc)[T * (T + 1) / 2]) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    float a[T];
+    double a[T], b[T];
+    const double qs = (double)S.q[s];
 #pragma unroll
-    for (int t = 0; t < T; t++) a[t] = S.e[t][s] * S.q[s];
+    for (int t = 0; t < T; t++) {
+      b[t] = (double)S.e[t][s];
+      a[t] = b[t] * qs;
+    }
 #pragma unroll
     for (int ti = 0; ti < T; ti++)
 #pragma unroll
       for (int tj = 0; tj <= ti; tj++)
         acc[ti * (ti + 1) / 2 + tj] =
-            __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], S.e[tj][s], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+            __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
   }
 }
 
 // the frame's Gram tiles over the pixels [c0, c1) -> red[tile][r][lane] (sum of the workgroup's four waves)
 template <int T, bool VEC>
-__device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, const float *qm, const int *s_rows, int nrows,
-                                           int c0, int c1, int HW, float *red) {
+__device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, const float *qm, int my_row, int nrows,
+                                           int c0, int c1, int HW, double *red) {
   constexpr int NT = T * (T + 1) / 2;
-  constexpr int UNR = (T <= 3) ? 4 : (T <= 5 ? 2 : 1);  // 16-pixel groups per batch; two batches in flight
+  constexpr int UNR = (T <= 2) ? 4 : (T == 3 ? 2 : 1);  // 16-pixel groups per batch; two batches in flight
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const float *bp[T];
 #pragma unroll
@@ -1025,12 +1085,13 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
     const int c = 16 * t + li;             // stacked value: 0 = w, 1 + 6 a + comp = row a of the frame's list
     const int a = (c > 0) ? (c - 1) / 6 : 0;
     const int comp = (c > 0) ? (c - 1) - 6 * a : 0;
+    const int erow = __shfl(my_row, a, 64);  // lane a of every wave holds row a of the list (a < 64 always)
     // (values past the stack read w again: finite, and their rows / columns of G are never looked at)
-    bp[t] = (c == 0 || a >= nrows) ? wm : W.E + ((size_t)s_rows[a] * 6 + comp) * HW;
+    bp[t] = (c == 0 || a >= nrows) ? wm : W.E + ((size_t)erow * 6 + comp) * HW;
   }
-  lin_f4 acc[NT];
+  gram_d4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < NT; i++) acc[i] = lin_f4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NT; i++) acc[i] = gram_d4{0.0, 0.0, 0.0, 0.0};
 
   const int ngroups = (c1 - c0 + 15) / 16;
   const int per = (ngroups + 3) / 4;  // a wave takes a contiguous run of groups: consecutive groups share 128-byte lines
@@ -1057,7 +1118,7 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
       for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          float *p = red + (i * 4 + r) * 64 + lane;
+          double *p = red + (i * 4 + r) * 64 + lane;
           *p = (w == 0) ? acc[i][r] : *p + acc[i][r];
         }
     }
@@ -1066,17 +1127,17 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
 }
 
 // frames with more rows than the tiles hold: one (a, b) pair of rows at a time over the chunk (the arithmetic of
-// ba_schur_kernel; such frames have 15 or more out-edges)
-__device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const float *qm, const int *s_rows, const int *s_tgt,
-                                 int nrows, int c0, int c1, int HW, int n6, float *red) {
+// ba_schur_kernel; such frames have 13 or more out-edges)
+__device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const float *qm, const int *frow, int nrows, int c0,
+                                 int c1, int HW, int n6, bool lower, float *red) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int a = 0; a < nrows; a++) {
-    const float *E1 = W.E + (size_t)s_rows[a] * 6 * HW;
-    const int tgt1 = s_tgt[a];
+    const float *E1 = W.E + (size_t)frow[2 * a] * 6 * HW;
+    const int tgt1 = frow[2 * a + 1];
     for (int b = a; b < nrows; b++) {
       const bool self = (a == b);
-      const float *E2 = W.E + (size_t)s_rows[b] * 6 * HW;
-      const int tgt2 = s_tgt[b];
+      const float *E2 = W.E + (size_t)frow[2 * b] * 6 * HW;
+      const int tgt2 = frow[2 * b + 1];
       float acc[36], sv[6];
 #pragma unroll
       for (int c = 0; c < 36; c++) acc[c] = 0.f;
@@ -1117,8 +1178,8 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
       if (tid < 36) {
         const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
         const int x = tid / 6, y = tid % 6;
-        atomic_add_f64(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s);
-        if (!self) atomic_add_f64(&W.H[(size_t)(6 * tgt2 + y) * n6 + 6 * tgt1 + x], -s);
+        if (!self) h_add_pair(W, n6, 6 * tgt1 + x, 6 * tgt2 + y, -s, lower);
+        else if (!lower || x >= y) atomic_add_f64(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s);
       } else if (self && tid < 42) {
         const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
         atomic_add_f64(&W.b[6 * tgt1 + (tid - 36)], -s);
@@ -1127,81 +1188,62 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
   }
 }
 
-// grid: [0, Mmax * nch) = (frame slot, pixel chunk); blocks after that do the pose-block assembly (as in ba_schur_kernel)
+// grid: [0, Mmax * nch) = (frame slot, pixel chunk); blocks after that do the pose-block assembly (as in ba_schur_kernel).
+// lower != 0: only the lower triangle of H is kept up (dba_ba: the solvers read nothing else).
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
-                                                            const uint8_t *__restrict__ frame_owned, int N, int HW,
-                                                            int t0, int P, int nch, BaTables T, BaBuffers W) {
-  __shared__ float red[GRAM_MAX_TILES * 256];
-  __shared__ int s_rows[GRAM_LIST_CAP], s_tgt[GRAM_LIST_CAP];
-  __shared__ int s_n;
+                                                               const uint8_t *__restrict__ frame_owned, int N, int HW,
+                                                               int t0, int P, int nch, int lower, BaTables T, BaBuffers W) {
+  __shared__ double red[GRAM_MAX_TILES * 256];
+  __shared__ int s_tgt[64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int frames_blocks = T.Mmax * nch;
   if ((int)blockIdx.x >= frames_blocks) {
-    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, T, W);
+    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
     return;
   }
   const int m = (int)blockIdx.x / nch, ch = (int)blockIdx.x - m * nch;
-  if (m >= T.meta[0]) return;
-  const int frame = T.kx[m];
+  const int4 fh = *reinterpret_cast<const int4 *>(T.fhead + 4 * m);  // frame, first row entry, rows
+  const int frame = fh.x, nrows = fh.z;
+  if (frame < 0 || nrows == 0) return;
   if (frame_owned && !frame_owned[frame]) return;
   // chunk of the frame's pixels: a multiple of 16 (aligned 16-byte operand loads)
   const int cpx = ((HW + nch - 1) / nch + 15) / 16 * 16;
   const int c0 = ch * cpx, c1 = min(HW, c0 + cpx);
   if (c0 >= c1) return;
-
-  // the frame's rows of E with a pose inside the window: its own pose row, then its out-edges in list order
-  if (tid < 64) {
-    int n = 0;
-    const int p = frame - t0;
-    if (p >= 0 && p < P) {
-      if (lane == 0) s_rows[0] = p, s_tgt[0] = p;
-      n = 1;
-    }
-    const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
-    for (int base = e0; base < e1; base += 64) {
-      const int pos = base + lane;
-      int en = 0, tg = -1;
-      if (pos < e1) {
-        const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * pos);
-        en = ei.x, tg = ei.y - t0;
-      }
-      const bool ok = (tg >= 0) && (tg < P);
-      const unsigned long long bal = __ballot(ok);
-      const int idx = n + __popcll(bal & ((1ull << lane) - 1ull));
-      if (ok && idx < GRAM_LIST_CAP) s_rows[idx] = P + en, s_tgt[idx] = tg;
-      n += __popcll(bal);
-    }
-    if (lane == 0) s_n = min(n, GRAM_LIST_CAP);
-  }
-  __syncthreads();
-  const int nrows = s_n;
-  if (nrows == 0) return;
   const float *wm = W.w + (size_t)m * HW, *qm = W.Q + (size_t)m * HW;
   const int n6 = 6 * P;
+  const int *frow = T.frow + 2 * fh.y;
   if (nrows > GRAM_MAX_ROWS) {
-    gram_frame_pairs(W, wm, qm, s_rows, s_tgt, nrows, c0, c1, HW, n6, red);
+    gram_frame_pairs(W, wm, qm, frow, nrows, c0, c1, HW, n6, lower != 0, reinterpret_cast<float *>(red));
     return;
   }
+  // lane a < nrows of every wave: row a of the frame's list (E row, pose)
+  int my_row = 0, my_tgt = 0;
+  if (lane < nrows) {
+    const int2 rt = *reinterpret_cast<const int2 *>(frow + 2 * lane);
+    my_row = rt.x, my_tgt = rt.y;
+  }
+  if (tid < 64) s_tgt[lane] = my_tgt;
   const int R = 1 + 6 * nrows, Tn = (R + 15) / 16;
   switch (Tn) {
-    case 1: gram_frame<1, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
-    case 2: gram_frame<2, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
-    case 3: gram_frame<3, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
-    case 4: gram_frame<4, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
-    case 5: gram_frame<5, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
-    default: gram_frame<6, VEC>(W, wm, qm, s_rows, nrows, c0, c1, HW, red); break;
+    case 1: gram_frame<1, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 2: gram_frame<2, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 3: gram_frame<3, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 4: gram_frame<4, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    default: gram_frame<5, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
   }
-  // scatter: tile (ti, tj <= ti), register r, lane l  <->  G[i][j], i = 16 ti + 4 (l >> 4) + r, j = 16 tj + (l & 15).
-  // Entry (i, j), i >= j >= 1, is row a = (i - 1) / 6 against row b = (j - 1) / 6 of the list: it goes to both mirrored
-  // positions of H (the two orders of a pair; within a diagonal block G[i][j] serves (i, j) and (j, i)); column 0 is b.
+  // scatter: tile (ti, tj <= ti), register r, lane l  <->  G[i][j], i = 16 ti + (l >> 4) + 4 r, j = 16 tj + (l & 15)
+  // (the float64 instruction's result layout).  Entry (i, j), i >= j >= 1, is row a = (i - 1) / 6 against row
+  // b = (j - 1) / 6 of the list: it belongs to both mirrored positions of H (the two orders of a pair; within a diagonal
+  // block G[i][j] serves (i, j) and (j, i)); column 0 is the right-hand side.
   const int ntiles = Tn * (Tn + 1) / 2;
   const int r = tid >> 6, li = lane & 15, lk = lane >> 4;
   int ti = 0, tj = 0;
   for (int idx = 0; idx < ntiles; idx++) {
-    const int i = 16 * ti + 4 * lk + r, j = 16 * tj + li;
+    const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
     if (i < R && j <= i && i >= 1) {
-      const double s = -(double)red[(idx * 4 + r) * 64 + lane];
+      const double s = -red[(idx * 4 + r) * 64 + lane];
       const int a = (i - 1) / 6, ca = (i - 1) - 6 * a;
       const int hr = 6 * s_tgt[a] + ca;
       if (j == 0) {
@@ -1209,17 +1251,25 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
       } else {
         const int b = (j - 1) / 6, cb = (j - 1) - 6 * b;
         const int hc = 6 * s_tgt[b] + cb;
-        atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
-        if (i != j) atomic_add_f64(&W.H[(size_t)hc * n6 + hr], s);
+        if (i == j) atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
+        else h_add_pair(W, n6, hr, hc, s, lower != 0);
       }
     }
     if (++tj > ti) ti++, tj = 0;
   }
 }
 template __global__ void ba_schur_gram_kernel<true>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int, int,
-                                                    BaTables, BaBuffers);
+                                                    int, BaTables, BaBuffers);
 template __global__ void ba_schur_gram_kernel<false>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int,
-                                                     int, BaTables, BaBuffers);
+                                                     int, int, BaTables, BaBuffers);
+
+// H <- its lower triangle mirrored (for the consumers of the full matrix: BACore.hessian, the stage API)
+__global__ __launch_bounds__(256) void ba_symmetrize_kernel(double *__restrict__ H, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const int i = idx / n, j = idx - i * n;
+  if (j > i) H[idx] = H[(size_t)j * n + i];
+}
 
 // ---------------------------------------------------------------------------------------------
 // stage 4: back-substitution + retraction

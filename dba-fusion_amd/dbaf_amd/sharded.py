@@ -213,6 +213,8 @@ class ShardedBACore:
             self.dist.reduce(hb, dst=0)          # RCCL sum onto rank 0 (in place on the workspace view there)
         if self.win.rank != 0:
             return
+        if hasattr(st, "symmetrize"):            # the front stage keeps only the lower triangle up; GTSAM gets the full H
+            st.symmetrize(c)
         flat = torch.cat([hb[:n * n], hb[-n:]]) if hb.numel() != n * n + n else hb
         self._Hpin.copy_(flat, non_blocking=True)  # one D2H into pinned staging
         if flat.is_cuda:
@@ -301,6 +303,9 @@ class HipStages:
         n2 = c["H"].numel()
         c["H"].copy_(hb[:n2])
         c["b"].copy_(hb[n2:])
+
+    def symmetrize(self, c):
+        _lib.check(c["lib"].dba_ba_symmetrize(*c["dims"], self._p(c["ws"]), c["nbytes"], self._s()), "dba_ba_symmetrize")
 
     def solve(self, c, lm, ep):
         _lib.check(c["lib"].dba_ba_solve(*c["dims"], float(lm), float(ep), self._p(c["ws"]), c["nbytes"], self._s()),

@@ -113,6 +113,25 @@ def graph_64_512():
     return graph_banded(64, 4, extra=[(i, i + 5) for i in range(10)])
 
 
+def graph_64_weak(world):
+    """Weak-scaling family of the 64-KF window (bench.py --scaling weak): every frame has exactly `world` out-edges, to its
+    nearest neighbours (+1, -1, +2, -2, ...; frames near the ends reach further on the side that exists), i.e. 64 * world
+    edges -- 64 per rank once the source frames are dealt out (8 ranks: the |i-j| <= 4 band of graph_64_512 away from the
+    ends, 512 edges)."""
+    num_kf = 64
+    ii, jj = [], []
+    for i in range(num_kf):
+        picked, d = [], 1
+        while len(picked) < world and d < num_kf:
+            for j in (i + d, i - d):
+                if 0 <= j < num_kf and len(picked) < world:
+                    picked.append(j)
+            d += 1
+        ii += [i] * len(picked)
+        jj += picked
+    return np.asarray(ii, np.int64), np.asarray(jj, np.int64)
+
+
 def _box3(a):
     p = np.pad(a, ((0, 0), (1, 1), (1, 1)), mode="edge")
     out = np.zeros_like(a)
@@ -215,6 +234,11 @@ def window_32_122(seed=0, **kw):
 
 def window_64_512(seed=0, **kw):
     ii, jj = graph_64_512()
+    return make_window(ii, jj, 64, 64, 64, seed=seed, **kw)
+
+
+def window_64_weak(world, seed=0, **kw):
+    ii, jj = graph_64_weak(world)
     return make_window(ii, jj, 64, 64, 64, seed=seed, **kw)
 
 

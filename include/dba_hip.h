@@ -92,6 +92,11 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
                   int ht, int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes,
                   dba_stream_t stream);
 
+/* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
+ * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
+ * first.  dba_ba_reduce and dba_bacore_hessian always produce the full symmetric matrix. */
+int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
+
 /* stage 3: damped dense solve in float64 on the device
  * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx.  Register-tile block LDL^T up
  * to 29 poses, skyline variants up to 64 poses, blocked Cholesky beyond / for wide skylines (csrc/ba_solve*.hip).

@@ -1,8 +1,8 @@
 """numpy model of the per-source-frame Schur kernel's index logic (csrc/ba_kernels.hip: ba_schur_gram_kernel).
 
 The kernel stacks a frame's values per pixel as x = [w | E_0 | E_1 | ...], accumulates the lower triangle of
-G = sum_k q_k x_k x_k^T in 16 x 16 tiles of v_mfma_f32_16x16x4_f32 and scatters tile (ti, tj), register r, lane l to
-H / b.  This model walks the same lanes, registers, pixel groups and scatter rule in float64 and compares with the
+G = sum_k q_k x_k x_k^T in 16 x 16 tiles of v_mfma_f64_16x16x4_f64 and scatters tile (ti, tj), register r, lane l to
+H / b (both triangles, or -- what dba_ba asks for -- the lower triangle only).  This model walks the same lanes, registers, pixel groups and scatter rule in float64 and compares with the
 definition the row-pair kernel implements (schur_block + EEt6x6 + Ev6x1, droid_kernels.cu:1046-1138, :1297-1391):
 for every ordered pair of rows (a, b) of one source frame, H[tgt_a, tgt_b] -= E_a diag(Q) E_b^T, b[tgt_a] -= E_a (Q o w).
 What it pins is the bookkeeping (operand lanes, tile order, triangle handling, duplicates, ragged chunks), not the rounding.
@@ -13,7 +13,8 @@ import pytest
 
 def mfma_16x16x4(a_lanes, b_lanes, acc):
     """D = A B + C with the gfx950 operand layout: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
-    register r of lane l holds D[4 (l >> 4) + r][l & 15] (the layout ba_linearize_kernel's matrix-core sums rely on)."""
+    register r of lane l holds D[(l >> 4) + 4 r][l & 15] (the FLOAT64 instruction's result layout, the one
+    ba_solve_kernel's trailing update relies on; the f32 instruction has rows 4 (l >> 4) + r)."""
     A = np.zeros((16, 4)); B = np.zeros((4, 16))
     for l in range(64):
         A[l & 15, l >> 4] = a_lanes[l]
@@ -21,10 +22,10 @@ def mfma_16x16x4(a_lanes, b_lanes, acc):
     D = A @ B
     for l in range(64):
         for r in range(4):
-            acc[l, r] += D[4 * (l >> 4) + r, l & 15]
+            acc[l, r] += D[(l >> 4) + 4 * r, l & 15]
 
 
-def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch):
+def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False):
     """E [nrows_total, 6, HW], rows/tgts = the frame's list; returns the H, b contribution of the frame"""
     n6 = 6 * P
     H = np.zeros((n6, n6)); b = np.zeros(n6)
@@ -70,7 +71,7 @@ def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch):
         for idx in range(NT):
             for r in range(4):
                 for l in range(64):
-                    i, j = 16 * ti + 4 * (l >> 4) + r, 16 * tj + (l & 15)
+                    i, j = 16 * ti + (l >> 4) + 4 * r, 16 * tj + (l & 15)
                     if i < R and j <= i and i >= 1:
                         s = -red[idx, r, l]
                         a, ca = (i - 1) // 6, (i - 1) % 6
@@ -80,9 +81,15 @@ def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch):
                         else:
                             bq, cb = (j - 1) // 6, (j - 1) % 6
                             hc = 6 * tgts[bq] + cb
-                            H[hr, hc] += s
-                            if i != j:
+                            if i == j:
+                                H[hr, hc] += s
+                            elif not lower:
+                                H[hr, hc] += s
                                 H[hc, hr] += s
+                            elif hr == hc:
+                                H[hr, hc] += 2 * s
+                            else:
+                                H[max(hr, hc), min(hr, hc)] += s
             tj += 1
             if tj > ti:
                 ti, tj = ti + 1, 0
@@ -114,3 +121,5 @@ def test_gram_scatter_matches_the_pairwise_definition(nrows, HW, nch, seed):
     Hd, bd = definition(E, Q, w, rows, tgts, P)
     assert np.allclose(H, Hd, rtol=0, atol=1e-9 * np.abs(Hd).max())
     assert np.allclose(b, bd, rtol=0, atol=1e-9 * np.abs(bd).max())
+    Hl, bl = gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=True)
+    assert np.allclose(Hl, np.tril(Hd), rtol=0, atol=1e-9 * np.abs(Hd).max()) and np.allclose(bl, bd)
