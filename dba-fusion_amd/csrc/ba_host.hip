@@ -20,6 +20,23 @@ void set_last_error(const char *what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s -> %s", what, hipGetErrorString(e));
 }
 
+// Schur kernel of a window: the per-source-frame form (float64 Gram tiles, every row of E read once) where frames couple
+// many rows -- 64 KF / 512 edges: 47 us against 86 us for the (row, partner) grid --, the (row, partner) grid on sparse
+// windows, whose pairs are few and whose kernel is a chain of latencies either way (25 KF / 96 edges: 12.9 against 16.6 us).
+// DBA_SCHUR_KERNEL = rows | frame or dba_ba_schur_select() force one (the tests run both).
+static std::atomic<int> g_schur_form{[] {
+  const char *e = getenv("DBA_SCHUR_KERNEL");
+  return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'f' || e[0] == 'g') ? 2 : 0);
+}()};  // 0 = automatic, 1 = (row, partner) grid, 2 = per-source-frame form; dba_ba_schur_select() changes it
+
+bool ba_schur_frame_form(int N, int Mmax) {
+  const int forced = g_schur_form.load(std::memory_order_relaxed);
+  if (N + 1 > GRAM_LIST_CAP) return false;
+  if (forced) return forced == 2;
+  const int rows_est = 1 + (Mmax > 0 ? (N + Mmax - 1) / Mmax : 0);
+  return rows_est > 6;
+}
+
 int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan) {
   if (N < 0 || B <= 0 || ht <= 0 || wd <= 0 || t1 < t0 || t0 < 0 || t1 > B) return DBA_ERR_ARG;
   const int P = t1 - t0;
@@ -147,15 +164,15 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
   const int want = std::max(std::max(N, B), t1 - t0);
   const int threads = std::min(1024, std::max(64, (want + 63) / 64 * 64));
   const size_t scan_ints = std::max<size_t>(std::max(threads, t1 - t0), N > threads ? 1024 : 0) + 32;
-  // (+ validity flags of the edges and per-slot row counts for the frame row table: threads + Mmax + 1 ints)
-  const size_t lds = sizeof(int) * ((size_t)B + 2 * (size_t)plan.T.Mmax + 1 + scan_ints + threads + plan.T.Mmax + 1);
+  // (+ per-slot row counts for the frame row table: Mmax + 1 ints)
+  const size_t lds = sizeof(int) * ((size_t)B + 2 * (size_t)plan.T.Mmax + 1 + scan_ints + plan.T.Mmax + 1);
   if (lds > 160 * 1024 || t1 - t0 > 16384) return DBA_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_prepare_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
-                     (int)scan_ints, plan.T);
+                     (int)scan_ints, ba_schur_frame_form(N, plan.T.Mmax) ? 1 : 0, plan.T);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -204,9 +221,8 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
   if (!motion_only) {  // Schur products and the pose-block assembly share one launch (both only add into H, b)
     // per-source-frame form (every row of E read once, Gram tiles on the matrix cores); DBA_SCHUR_KERNEL=rows keeps
     // the (row, partner) grid, which also takes graphs with more edges than the prepare kernel lists per frame
-    static const bool rows_form = [] { const char *e = getenv("DBA_SCHUR_KERNEL"); return e && e[0] == 'r'; }();
     static const int env_nch = [] { const char *e = getenv("DBA_SCHUR_NCH"); return e ? atoi(e) : 0; }();
-    if (rows_form || N + 1 > GRAM_LIST_CAP) {
+    if (!ba_schur_frame_form(N, plan.T.Mmax)) {
       hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
                          (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, lower, plan.T, plan.W);
     } else {
@@ -236,6 +252,12 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
 int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
                   int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
   return ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 0, ws, ws_bytes, stream);
+}
+
+int dba_ba_schur_select(int form) {
+  if (form < 0 || form > 2) return DBA_ERR_ARG;
+  g_schur_form.store(form, std::memory_order_relaxed);
+  return DBA_OK;
 }
 
 int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {

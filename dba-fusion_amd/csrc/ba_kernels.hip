@@ -41,14 +41,13 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // cheaper than among 16).  LDS: flag[B] cnt[Mmax + 1] kxs[Mmax] scan[max(blockDim, 1024 if N > blockDim)].
 __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restrict__ ii,
                                                           const int64_t *__restrict__ jj, int N, int B,
-                                                          int t0, int t1, int scan_ints, BaTables T) {
+                                                          int t0, int t1, int scan_ints, int ftable, BaTables T) {
   extern __shared__ int sm[];
   int *flag = sm;
   int *cnt = sm + B;
   int *kxs = cnt + T.Mmax + 1;
   int *scan = kxs + T.Mmax;
-  int *sval = scan + scan_ints;      // [blockDim] 1 = the edge of this thread has its target pose inside the window
-  int *vcnt = sval + blockDim.x;     // [Mmax + 1] rows of E per slot (frame row table), then their exclusive scan
+  int *vcnt = scan + scan_ints;      // [Mmax + 1] rows of E per slot (frame row table), then their exclusive scan
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int P = t1 - t0;
   // this thread's first edge stays in registers (the usual graph has at most one edge per thread): the passes
@@ -139,31 +138,37 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   if (N <= nt) {  // the usual case: one pass, the rank stays in a register
     // ... and the frame row table of the per-source-frame Schur kernel is built on the way: slot m couples its own
     // pose row (if the frame is a window pose) and the rows of its out-edges whose target is one, in list order
+    // (the validity flag rides in bit 30 of the staged source frame: one LDS read per comparison, as before)
     const bool myvalid = (tid < N) && (slot_of(my_i) >= 0) && (my_j - t0 >= 0) && (my_j - t0 < P);
-    if (tid < N) sii[tid] = my_i;
-    sval[tid] = myvalid ? 1 : 0;
-    for (int m = tid; m <= T.Mmax; m += nt) {
-      const int pp = (m < Mv0) ? kxs[m] - t0 : -1;
-      vcnt[m] = (pp >= 0 && pp < P) ? 1 : 0;
-    }
+    constexpr int VBIT = 1 << 30;
+    if (tid < N) sii[tid] = (my_i & (VBIT - 1)) | (myvalid ? VBIT : 0);
+    if (ftable)
+      for (int m = tid; m <= T.Mmax; m += nt) {
+        const int pp = (m < Mv0) ? kxs[m] - t0 : -1;
+        vcnt[m] = (pp >= 0 && pp < P) ? 1 : 0;
+      }
     __syncthreads();
     int vrank = 0;
     if (tid < N) {
-      const int f = sii[tid], m = slot_of(f);
+      const int f = my_i & (VBIT - 1), m = slot_of(my_i);
       int pos = -1;
       if (m >= 0) {
         int rank = 0;
         for (int q = 0; q < tid; q++) {
-          const bool same = (sii[q] == f);
+          const int x = sii[q];
+          const bool same = ((x & (VBIT - 1)) == f);
           rank += same;
-          vrank += same && sval[q];
+          vrank += same ? (x >> 30) : 0;
         }
         pos = cnt[m] + rank;
         T.elist[pos] = tid;
-        if (myvalid) atomicAdd(&vcnt[m], 1);
+        if (myvalid && ftable) atomicAdd(&vcnt[m], 1);
       }
       emit_edge(tid, m, pos, my_j);
     }
+    if (!ftable) {
+      for (int m = tid; m < T.Mmax; m += nt) T.fhead[4 * m] = -1, T.fhead[4 * m + 2] = 0;
+    } else {
     __syncthreads();
     if (wave == 0) {  // exclusive scan of the row counts; vcnt keeps the offsets
       int carry = 0;
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     if (myvalid) {
       const int o = vcnt[slot_of(my_i)] + vrank;
       T.frow[2 * o] = P + tid, T.frow[2 * o + 1] = my_j - t0;
+    }
     }
   } else {        // chunks of 1024 source frames, ranks accumulated in global scratch
     for (int m = tid; m < T.Mmax; m += nt) T.fhead[4 * m] = -1, T.fhead[4 * m + 2] = 0;  // (the row-pair Schur kernel runs)

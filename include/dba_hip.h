@@ -92,6 +92,12 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
                   int ht, int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes,
                   dba_stream_t stream);
 
+/* Which kernel forms the Schur products of stage 2 (must be set before dba_ba_prepare of the call it applies to: the
+ * prepare stage builds the tables of the form in force): 0 = automatic (the per-source-frame form -- float64 Gram tiles on
+ * the matrix cores, every row of E read once -- on windows whose frames couple many rows, the (row, partner) grid on
+ * sparse ones), 1 = (row, partner) grid, 2 = per-source-frame form.  Initialised from DBA_SCHUR_KERNEL = rows | frame. */
+int dba_ba_schur_select(int form);
+
 /* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
  * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
  * first.  dba_ba_reduce and dba_bacore_hessian always produce the full symmetric matrix. */

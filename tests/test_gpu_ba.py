@@ -71,6 +71,79 @@ def test_ba_matches_oracle(name):
     np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
 
 
+def _bacore_system(W, form):
+    """the Schur-reduced camera system of W as BACore.hessian hands it to the host, with the given Schur kernel form"""
+    import droid_backends
+    from dbaf_amd import _lib
+    lib = _lib.load()
+    assert lib.dba_ba_schur_select(form) == 0
+    try:
+        d = to_dev(W)
+        core = droid_backends.BACore()
+        core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+                  d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+        n = 6 * (W.t1 - W.t0)
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        core.hessian(H, v)
+        return H.numpy().copy(), v.numpy().copy()
+    finally:
+        lib.dba_ba_schur_select(0)
+
+
+def _dense_graph(num_kf, radius):
+    return syn.graph_banded(num_kf, radius)
+
+
+SCHUR_WINDOWS = dict(WINDOWS)
+SCHUR_WINDOWS.update({
+    # frames with up to 17 rows: more than the Gram tiles hold (13), the row-pair path inside the per-frame kernel
+    "dense_16kf_radius8_24x32": lambda: syn.make_window(*_dense_graph(16, 8), 16, 24, 32, seed=61,
+                                                         intr=(12.0, 11.5, 15.6, 12.2)),
+    # every tile count 1..5 in one window (out-degrees 0 .. 12), duplicate edges, an odd pixel count (15 x 17)
+    "ragged_degrees_15x17": lambda: syn.make_window(
+        np.array([1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 0], np.int64),
+        np.array([2, 2, 1, 3, 4, 5, 1, 2, 4, 5, 6, 7, 0, 1, 2, 3, 5, 6, 7, 8, 0, 1, 2, 3, 5, 4, 6, 1], np.int64),
+        9, 15, 17, seed=62, intr=(8.0, 8.5, 8.2, 7.1)),
+})
+
+
+@pytest.mark.parametrize("name", list(SCHUR_WINDOWS))
+def test_schur_kernel_forms_agree_on_the_reduced_system(name):
+    """The per-source-frame kernel (float64 Gram tiles on the matrix cores, csrc/ba_kernels.hip) against the (row, partner)
+    grid: the same H, v up to the fp32 rounding of the latter's products (the former's are exact), symmetric, and the
+    frame form reproducible bit for bit (its sums are ordered; float64 atomics of fp32-exact addends)."""
+    W = SCHUR_WINDOWS[name]()
+    Hr, vr = _bacore_system(W, 1)
+    Hf, vf = _bacore_system(W, 2)
+    Hf2, vf2 = _bacore_system(W, 2)
+    scale = np.abs(Hr).max()
+    assert scale > 0 and np.isfinite(Hf).all() and np.isfinite(vf).all()
+    # blockwise scale: an entry is a difference A - E Q E^T of two sums; compare against the larger block norm
+    assert np.abs(Hf - Hr).max() <= 3e-6 * scale, np.abs(Hf - Hr).max() / scale
+    assert np.abs(vf - vr).max() <= 3e-6 * max(np.abs(vr).max(), scale), np.abs(vf - vr).max()
+    assert np.abs(Hf - Hf.T).max() <= 1e-12 * scale          # mirrored from one sum per pair
+    assert np.abs(Hf - Hf2).max() <= 1e-9 * scale and np.abs(vf - vf2).max() <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("name", STRICT)
+def test_ba_matches_oracle_with_the_per_frame_schur_kernel(name):
+    """the windows of BASELINE.json's configs through the per-source-frame Schur kernel whatever the automatic choice is
+    (the 64-KF window takes it anyway), at the north-star tolerance with no allowance"""
+    from dbaf_amd import _lib
+    orc = _oracle()
+    W = WINDOWS[name]()
+    r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+                 W.lm, W.ep, False, 0.05, np.float64)
+    lib = _lib.load()
+    lib.dba_ba_schur_select(2)
+    try:
+        poses, disps, dx, dz = _run_gpu_ba(W)
+    finally:
+        lib.dba_ba_schur_select(0)
+    clamp = lambda a: np.maximum(a, 0.001)  # noqa: E731
+    check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps, ref32_disps=None, frac=1.0)
+
+
 def test_ba_full_size_properties_64kf():
     """BASELINE.json configs[3] size (64 KF / 512 edges / 64x64), size-independent properties:
     (i) a noise-free window is a fixed point; (ii) Gauss-Newton contracts towards the ground truth;
