@@ -13,7 +13,16 @@ N=1 workload = BASELINE.json configs[1] shape: 25 KF / 96 edges / 512x512 frames
 
 Rank 0 prints ONE JSON line.  For N > 1 the edge set is sharded by source frame over the ranks, the reduced camera
 system is all-reduced over RCCL once per Gauss-Newton iteration and the updated inverse depths of the frames a rank
-owns are all-gathered once per call (strong scaling of the same window).
+owns are all-gathered once per call.  Two multi-GPU modes (--scaling):
+  weak   (default for N > 1) the north star's "edge throughput": a 64-KF window whose every frame has N out-edges
+         (64 N edges: 64 per rank, 512 at N = 8; dbaf_amd.synthetic.graph_64_weak), per-rank work constant.  `value` is
+         edge-normalised: dba_update/s x (edges / 96), i.e. updates per second of 96-edge windows' worth of edges, so
+         that the N = 1 headline line (25 KF / 96 edges) and the N > 1 lines are in one unit; `extra.edges_per_s` and
+         `extra.edge_throughput_vs_1gpu` (against the same family's 64-edge window run by rank 0 alone, untimed
+         region) are on the line.
+  strong the same window (--window) sharded over the ranks.
+--backend gloo (or DBA_BENCH_BACKEND=gloo) runs the exchange step through gloo with host staging, so that the WHOLE
+multi-rank path can be executed by several processes on a one-GPU box (tests/test_gpu_entrypoints.py).
 
 Cache state: a real update never finds its correlation windows in the 256 MB Infinity Cache (the ConvGRU and the BA
 run in between, and the volumes of a window are gigabytes), whereas a benchmark that replays one step would.  The
@@ -75,6 +84,10 @@ def main():
                     help="also record one event per step (p10/p50/p90 of the step time; costs ~1 us per step)")
     ap.add_argument("--window", default="25_96", choices=["25_96", "32_122", "64_512"],
                     help="synthetic window (default = BASELINE.json configs[1]; 64_512 = configs[3], the multi-GPU case)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto = the headline window on one GPU, weak scaling (64 KF, 64 edges per rank) on several")
+    ap.add_argument("--backend", default=os.environ.get("DBA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="process-group backend of the exchange step (gloo: host-staged, several ranks may share one GPU)")
     args = ap.parse_args()
 
     from dbaf_amd import synthetic as syn
@@ -88,20 +101,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (gloo: several ranks may share one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=dev)
+            dist = dist_mod
+        else:
+            from dbaf_amd.sharded import HostStagedDist
+            dist_mod.init_process_group("gloo")
+            dist = HostStagedDist(dist_mod)
     _lib.load()
     # the exchange step of the sharded BA: RCCL, or (DBA_PEER_ALLREDUCE=1) the one-shot peer-read all-reduce
     from dbaf_amd.peer import PeerDist
-    ba_dist = PeerDist.wrap(dist)
+    ba_dist = PeerDist.wrap(dist) if args.backend == "nccl" else dist
 
     # ---- workload (synthetic) -----------------------------------------------------------
-    W = {"25_96": syn.window_25_96, "32_122": syn.window_32_122, "64_512": syn.window_64_512}[args.window](args.seed)
+    scaling = args.scaling if args.scaling != "auto" else ("weak" if world > 1 else "headline")
+    if scaling == "weak":
+        W = syn.window_64_weak(world, args.seed)
+        args.window = "64_weak%d" % world
+    else:
+        W = {"25_96": syn.window_25_96, "32_122": syn.window_32_122, "64_512": syn.window_64_512}[args.window](args.seed)
     h, w, HW, N = W.h, W.w, W.h * W.w, W.N
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     poses0, disps0 = t(W.poses), t(W.disps)
@@ -203,9 +227,69 @@ def main():
     ba_us = np.array([ev[4 * i + 2].elapsed_time(ev[4 * i + 3]) for i in range(nb)]) * 1e3
     lookup_ms = float(look_us.mean()) * 1e-3 if corrs and args.steps else float("nan")
 
-    # ---- untimed extras (rank 0, one GPU): warm lookup, zero-edit route, volume build ------------------------
+    # ---- weak scaling: the 1-GPU point of the same family, run by rank 0 alone while the others wait ---------------
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras and corrs:
+    if scaling == "weak" and world > 1:
+        if rank == 0:
+            W1 = syn.window_64_weak(1, args.seed)
+            st1 = torch.cat([t(W1.poses).reshape(-1), t(W1.disps).reshape(-1)])
+            st1_0 = st1.clone()
+            p1 = st1[:W1.poses.size].view(W1.B, 7)
+            d1 = st1[W1.poses.size:].view(W1.B, W1.h, W1.w)
+            ii1, jj1 = t(W1.ii), t(W1.jj)
+            tg1, wt1, eta1 = t(W1.target), t(W1.weight), t(W1.eta)
+            cb1 = CorrBlock(fmaps[ii1][None], fmaps[jj1][None], num_levels=4, radius=3)
+            K1 = intr[None, None].expand(1, W1.B, 4).contiguous()
+
+            def step1():
+                st1.copy_(st1_0)
+                c1, _ = pops.projective_transform(p1[None], d1[None], K1, ii1, jj1)
+                keep[0] = cb1(c1)
+                droid_backends.ba(p1, d1, intr, dsens, tg1, wt1, eta1, ii1, jj1, W1.t0, W1.t1, 2, W1.lm, W1.ep, False)
+                d1.clamp_(min=0.001)
+
+            for _ in range(5):
+                step1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = max(10, args.steps // 2)
+            for _ in range(n1):
+                step1()
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t1) / n1
+            extras["edges_per_s_1gpu_same_family"] = round(W1.N / t1, 1)
+            extras["edge_throughput_vs_1gpu"] = round((N * args.steps / dt) / (W1.N / t1), 3)
+            del cb1
+        dist.barrier()
+
+    # ---- untimed extras (rank 0, one GPU): sharded-driver overhead, warm lookup, zero-edit route, volume build ----------
+    if rank == 0 and world == 1 and not args.no_extras and shard is None:
+        # what the sharded driver costs on ONE rank (same kernels, the stage calls of dbaf_amd.sharded instead of dba_ba,
+        # no collective): the host-side price of the multi-GPU path
+        from dbaf_amd.sharded import ShardedWindow
+        sh1 = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, 1, 0)
+
+        def loop(fn, reps):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / reps * 1e6
+
+        def plain():
+            state.copy_(state0)
+            droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep, False)
+
+        def sharded1():
+            state.copy_(state0)
+            sh1.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, None)
+
+        reps = max(10, args.steps // 2)
+        extras["sharded_x1_overhead_us"] = round(loop(sharded1, reps) - loop(plain, reps), 1)
+    if rank == 0 and world == 1 and not args.no_extras and corrs and scaling != "weak":
         def timed(fn, reps):
             fn()
             torch.cuda.synchronize()
@@ -262,29 +346,36 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / max(args.steps, 1)
-        value = args.steps / dt
+        updates_per_s = args.steps / dt
+        # weak mode: edge-normalised throughput (updates/s of 96-edge windows' worth of edges), one unit for every N
+        value = updates_per_s * (N / 96.0) if scaling == "weak" else updates_per_s
         alg_bytes = lookup_algorithmic_bytes(n_loc, HW)
         if args.window != "25_96":
             args.no_cpu_baseline = True
         achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
         gn_bytes = N * HW * 16 + W.M * HW * 16  # SURVEY 8(d) B_gn: target, weight + disps r/w, eta, disps_sens
         out = {
-            "metric": "DBA iterations/sec (%d-KF, %d-edge, 512x512) [dba_update/s]" % (W.num_kf, N),
+            "metric": ("DBA iterations/sec (%d-KF, %d-edge, 512x512) [dba_update/s]" % (W.num_kf, N) if scaling != "weak" else
+                       "DBA iterations/sec, edge-normalised (%d-KF, %d-edge window; x edges/96) [dba_update/s per 96 edges]"
+                       % (W.num_kf, N)),
             "value": round(value, 3),
-            "unit": "dba_update/s",
+            "unit": "dba_update/s" if scaling != "weak" else "dba_update/s (96-edge equivalents)",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong" if scaling == "strong" and world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
             "config": {"workload": "synthetic TUM-VI-shape 512x512 -> %dx%d maps, %d-KF window, %d edges, "
                                    "reproject + 4-level r=3 lookup + ba(itrs=2) per step; lookups rotate over %d disjoint "
                                    "pyramid copies (MALL-cold)" % (h, w, W.num_kf, N, ncopies),
-                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world, "exchange": "peer-read" if ba_dist is not dist else "rccl",
+                       "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
+                       "scaling_mode": scaling,
+                       "exchange": ("gloo (host-staged)" if args.backend == "gloo" and world > 1 else
+                                    "peer-read" if ba_dist is not dist else "rccl"),
                        "pyramid_copies": ncopies},
             "roofline": {
                 "kernel": "%s (fused 4-level r=3 lookup, f16, %d edges on rank 0, "
@@ -318,8 +409,10 @@ def main():
         # both units of work, and the spread of the per-step device times (events on the launch stream)
         step_us = (np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3
                    if args.steps and args.step_events else np.zeros(1))
-        out["extra"] = {"gn_iter_per_s": round(2.0 * value, 3),
-                        "edge_lookups_per_s": round(N * value, 1),
+        out["extra"] = {"dba_update_per_s": round(updates_per_s, 3),
+                        "gn_iter_per_s": round(2.0 * updates_per_s, 3),
+                        "edges_per_s": round(N * updates_per_s, 1),
+                        "edge_lookups_per_s": round(N * updates_per_s, 1),
                         "step_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(step_us, [10, 50, 90])]
                                                 if args.step_events else None),
                         "lookup_us_p10_p50_p90": [round(float(v), 1) for v in np.percentile(look_us, [10, 50, 90])],

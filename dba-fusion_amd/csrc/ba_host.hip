@@ -249,9 +249,13 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
   return DBA_OK;
 }
 
+// the stage as the C ABI exposes it (BACore.hessian, ba_extend, tests): the FULL matrix, mirrored from the lower triangle,
+// so that H is symmetric to the last bit and identical to what the sharded BACore hands over
 int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int B, int ht,
                   int wd, int t0, int t1, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream) {
-  return ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 0, ws, ws_bytes, stream);
+  const int rc = ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  return dba_ba_symmetrize(N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
 }
 
 int dba_ba_schur_select(int form) {

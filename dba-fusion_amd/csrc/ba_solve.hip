@@ -314,8 +314,12 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
   int chained = 0;
   if (!prof && forced <= 1 && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);
   if (!prof && (forced == 0 || forced == 3) && ba_solve_band_supported(n)) {
-    int rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, Lscratch, Lscratch ? ba_solve_scratch_doubles(n) : 0, false, stream);
-    if (rc != DBA_OK || ba_solve_tile_supported(n)) return rc;  // n <= 174: the skyline kernel cannot bail out
+    // n <= 174 (only reached with DBA_SOLVE_KERNEL=band): one workgroup, which cannot bail out -- with the scratch the
+    // kernel would run on two workgroups, whose hand-shake can give the system up, and nothing is queued behind it here
+    const bool single = ba_solve_tile_supported(n);
+    int rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, single ? nullptr : Lscratch,
+                                  (Lscratch && !single) ? ba_solve_scratch_doubles(n) : 0, false, stream);
+    if (rc != DBA_OK || single) return rc;
     if (Lscratch && !ba_solve_fits_lds(n)) {  // wider skylines: several tiles per thread, panels in the global scratch
       rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, Lscratch, ba_solve_scratch_doubles(n), true, stream);
       if (rc != DBA_OK) return rc;

@@ -647,6 +647,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   for (int r = 0; r < RMAX; r++)
     if (lane + 64 * r < n && !isfinite(xo[r])) bad = true;
   int failed = (*fail != 0) || (__ballot(bad) != 0ull);
+  bool absent = false;
   if (SPLIT && split) {  // one verdict for both blocks
     int other = 0;
     if (lane == 0) {
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       __threadfence();
       __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
-      other = 1;  // (a partner that never reports counts as failed)
+      other = 2;  // (2 = the partner never reported: its block of dx is unknown)
       while (wall_clock64() - t0 < 100000000ll) {
         if (__hip_atomic_load(xflag + 4 + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gen) {
           other = __hip_atomic_load(xflag + 6 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,7 +664,9 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         __builtin_amdgcn_s_sleep(4);
       }
     }
-    failed |= __builtin_amdgcn_readfirstlane(other);
+    other = __builtin_amdgcn_readfirstlane(other);
+    absent = (other == 2);
+    failed |= (other != 0);
   }
 #pragma unroll
   for (int r = 0; r < RMAX; r++) {
@@ -674,7 +677,9 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   BPROF(4);
   if (lane == 0 && role == 0) {
     meta[1] = failed;
-    meta[3] = 1;  // solved here: the general kernel queued behind this one returns at once
+    // solved here: the general kernel queued behind this one returns at once -- unless the partner workgroup never
+    // delivered its verdict (its block of dx is then stale): the system is left to the kernel queued behind
+    meta[3] = absent ? 0 : 1;
   }
   BPROF(7);
 }

@@ -12,8 +12,11 @@
 //                                              [256 ...] two slots of max_doubles float64, used alternately by epoch.
 // Epoch protocol: a rank writes slot e & 1 and then raises its flag to e; a peer that has raised e has finished reading
 // every slot of epoch e - 1 (program order on its stream), so slot (e + 1) & 1 is free to be rewritten once all flags
-// show e.  Flags and peer data are read with system-scope atomics (no stale lines out of the reader's L2); a rank that
-// waits longer than ~2 s for a peer gives up, reports DBA_PEER_TIMEOUT through `status` and leaves `buf` untouched.
+// show e.  Flags and peer data are read with system-scope atomics (no stale lines out of the reader's L2); a workgroup
+// that waits longer than the time-out for a peer (20 s unless DBA_PEER_TIMEOUT_MS says otherwise: a peer may be busy on
+// the host between two calls) gives up and reports DBA_PEER_TIMEOUT through the sticky `status` word.  `buf` is then
+// UNDEFINED (other workgroups may already have summed their part): the caller must not use it -- PeerDist.check(),
+// which the sharded driver calls once per ba(), raises.
 //
 // Opt-in (dbaf_amd/peer.py, DBA_PEER_ALLREDUCE=1): this box has one GPU, so the path is tested with two PROCESSES that
 // map each other's regions on the same device (tests/test_gpu_peer.py) - handles, epochs, ordering, determinism - but
@@ -21,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -44,7 +48,8 @@ __device__ __forceinline__ double sys_load_f64(const double *p) {
 
 __global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_kernel(double *__restrict__ buf, size_t n, PeerRegions R,
                                                                       int rank, int world, unsigned epoch,
-                                                                      size_t max_doubles, int *__restrict__ status) {
+                                                                      size_t max_doubles, long long timeout_ticks,
+                                                                      int *__restrict__ status) {
   unsigned char *mine = R.r[rank];
   unsigned *flag = reinterpret_cast<unsigned *>(mine);
   unsigned *arrived = reinterpret_cast<unsigned *>(mine + 64);
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_allreduce_kernel(double *__
     const long long t0 = wall_clock64();
     // (epochs only grow; the signed difference keeps the comparison right across a wrap of the counter)
     while ((int)(sys_load_u32(pf) - epoch) < 0) {
-      if (wall_clock64() - t0 > 200000000ll) {  // ~2 s of the 100 MHz clock
+      if (wall_clock64() - t0 > timeout_ticks) {  // (100 MHz clock)
         s_fail = 1;
         break;
       }
@@ -109,12 +114,30 @@ size_t dba_peer_exchange_bytes(size_t max_doubles) { return PEER_HEADER + 2 * ma
 int dba_peer_exchange_create(size_t bytes, void **region, unsigned char *handle64) {
   if (!region || !handle64 || bytes < PEER_HEADER) return DBA_ERR_ARG;
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI passes IPC handles as 64 bytes");
+  // The region is polled and read by OTHER devices while the producing kernel is still running.  HIP only promises
+  // cross-device visibility of ordinary (coarse-grained) device memory at kernel boundaries, so the region is asked for
+  // uncached first (DBA_PEER_COARSE=1 skips that); if the runtime cannot export such an allocation through hipIpc the
+  // plain allocation is the fall-back, which relies on __threadfence_system writing the L2 back on gfx950.
   void *p = nullptr;
-  DBA_HIP_CHECK(hipMalloc(&p, bytes));
-  hipError_t e = hipMemset(p, 0, bytes);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
   hipIpcMemHandle_t h;
-  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  hipError_t e = hipErrorUnknown;
+  static const bool coarse_only = [] { const char *v = getenv("DBA_PEER_COARSE"); return v && v[0] == '1'; }();
+  if (!coarse_only && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess) {
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      p = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (!p) {
+    DBA_HIP_CHECK(hipMalloc(&p, bytes));
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  }
   if (e != hipSuccess) {
     (void)hipFree(p);
     set_last_error("dba_peer_exchange_create", e);
@@ -154,8 +177,13 @@ int dba_peer_allreduce_f64(double *buf, size_t n, void *const *regions, int rank
   // the flags; 128 single-wave-group workgroups are a fraction of the 256 CUs)
   size_t blocks = n / (8 * PEER_THREADS);
   blocks = blocks < PEER_MIN_BLOCKS ? PEER_MIN_BLOCKS : (blocks > PEER_MAX_BLOCKS ? PEER_MAX_BLOCKS : blocks);
+  static const long long timeout_ticks = [] {
+    const char *v = getenv("DBA_PEER_TIMEOUT_MS");
+    const long long ms = v ? atoll(v) : 20000;
+    return (ms > 0 ? ms : 20000) * 100000ll;  // 100 MHz wall clock
+  }();
   hipLaunchKernelGGL(peer_allreduce_kernel, dim3((unsigned)blocks), dim3(PEER_THREADS), 0, (hipStream_t)stream, buf, n, R,
-                     rank, world, epoch, max_doubles, status);
+                     rank, world, epoch, max_doubles, timeout_ticks, status);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -55,6 +55,14 @@ class PeerAllReduce:
         """True if any all-reduce so far gave up waiting for a peer (synchronises)"""
         return bool(self._status.item())
 
+    def check(self):
+        """Raises if an all-reduce since the last check gave up waiting for a peer -- its buffer then holds a partial sum
+        and whatever was computed from it (solve, retraction) is wrong.  Synchronises; clears the sticky status word."""
+        if self._status.item():
+            self._status.zero_()
+            raise RuntimeError("peer all-reduce: a rank waited longer than DBA_PEER_TIMEOUT_MS for a peer's contribution; "
+                               "the reduced camera system of this call is incomplete (state must be discarded)")
+
     def close(self):
         torch.cuda.synchronize()
         for ptr in self._opened:
@@ -91,6 +99,9 @@ class PeerDist:
                 and t.numel() <= self.peer.max_doubles:
             return self.peer.all_reduce(t)
         return self._dist.all_reduce(t, *args, **kwargs)
+
+    def check(self):
+        self.peer.check()
 
     def __getattr__(self, name):
         return getattr(self._dist, name)

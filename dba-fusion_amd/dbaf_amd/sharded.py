@@ -161,6 +161,8 @@ class ShardedWindow:
         # edges), so the replicas are made coherent ONCE per call: every rank sends the rows it owns.
         if not motion_only:
             self.merge_disps(disps, dist)
+        if hasattr(dist, "check"):   # the peer-read exchange reports a missing peer through a status word: surface it
+            dist.check()
         assert hb.numel() >= n6 * n6 + n6
         return stages.finish(ctx)
 
@@ -234,6 +236,46 @@ class ShardedBACore:
         st.update(c, update_disps=True)
         self.win.merge_disps(self.disps, self.dist)
         return [st.finish(c), None]
+
+
+class HostStagedDist:
+    """`dist` stand-in that runs the collectives of the sharded drivers through a process group that cannot take device
+    tensors (gloo), by staging through the host: the WHOLE multi-rank path -- partition, front stage, exchange, redundant
+    solves, depth all-gather -- can then be executed by several processes on a box with one GPU (bench.py --backend gloo;
+    tests/test_gpu_entrypoints.py).  Not a performance path: RCCL is."""
+
+    def __init__(self, dist):
+        self._dist = dist
+        self.ReduceOp = dist.ReduceOp
+
+    @staticmethod
+    def _host(t):
+        return t.detach().to("cpu").contiguous()
+
+    def all_reduce(self, t, op=None, **kw):
+        h = self._host(t)
+        self._dist.all_reduce(h, **({} if op is None else {"op": op}))
+        t.copy_(h)
+
+    def reduce(self, t, dst=0, **kw):
+        h = self._host(t)
+        self._dist.reduce(h, dst=dst)
+        if self._dist.get_rank() == dst:
+            t.copy_(h)
+
+    def broadcast(self, t, src=0, **kw):
+        h = self._host(t)
+        self._dist.broadcast(h, src=src)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp, **kw):
+        hi = self._host(inp)
+        parts = [torch.empty_like(hi) for _ in range(self._dist.get_world_size())]
+        self._dist.all_gather(parts, hi)
+        out.copy_(torch.cat([p.reshape((-1,) + tuple(hi.shape[1:])) for p in parts], 0).reshape(out.shape))
+
+    def __getattr__(self, name):   # barrier, get_rank, get_world_size, all_gather_object, destroy_process_group, ...
+        return getattr(self._dist, name)
 
 
 class HipStages:

@@ -100,7 +100,8 @@ int dba_ba_schur_select(int form);
 
 /* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
  * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
- * first.  dba_ba_reduce and dba_bacore_hessian always produce the full symmetric matrix. */
+ * first.  dba_ba_reduce and dba_bacore_hessian always produce the full matrix (mirrored from the lower triangle: symmetric
+ * to the last bit). */
 int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
 
 /* stage 3: damped dense solve in float64 on the device

@@ -41,3 +41,45 @@ def test_smoke_entry_point():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _bench_ranks(world, *args):
+    """bench.py as the driver launches it for N > 1 (one process per rank, torch.distributed.run), with the exchange step on
+    gloo so that the ranks can share this box's GPU(s)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(world), "--steps", "4", "--warmup", "2", "--backend", "gloo", "--no-cpu-baseline",
+                        *args], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]      # rank 0 prints ONE line
+    return json.loads(lines[-1])
+
+
+def test_bench_weak_scaling_mode_on_one_gpu():
+    """--scaling weak at N = 1: the 64-KF / 64-edge member of the weak-scaling family, edge-normalised value"""
+    d = _bench(None, "--no-cpu-baseline", "--no-extras", "--scaling", "weak")
+    assert d["scaling"] == "weak" and d["config"]["edges"] == 64 and d["config"]["keyframes"] == 64
+    assert abs(d["value"] - d["extra"]["dba_update_per_s"] * 64 / 96) < 1e-2 * d["value"]
+    assert abs(d["extra"]["edges_per_s"] - 64 * d["extra"]["dba_update_per_s"]) < 1e-3 * d["extra"]["edges_per_s"]
+
+
+def test_bench_two_ranks_whole_path_weak_and_strong():
+    """two processes (sharing the GPU if the box has one), whole bench path: partition by source frame, front stage,
+    exchange (gloo, host-staged), redundant solves, depth all-gather; default mode for N > 1 is weak scaling"""
+    d = _bench_ranks(2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["edges"] == 128 and d["value"] > 0
+    assert d["extra"]["edge_throughput_vs_1gpu"] > 0 and d["config"]["exchange"].startswith("gloo")
+    d = _bench_ranks(2, "--scaling", "strong")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["edges"] == 96 and d["value"] > 0
+
+
+def test_bench_reports_the_sharded_driver_overhead():
+    d = _bench(None, "--no-cpu-baseline")
+    assert "sharded_x1_overhead_us" in d["extra"]

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+os.environ.setdefault("DBA_PEER_TIMEOUT_MS", "1500")   # (read once per process by the library; the default is 20 s)
 
 SIZES = [20880, 1, 7, 64, 4097, 6 * 64 * (6 * 64 + 1), 20880, 20880]   # 24 poses; odd sizes; 64 poses; repeats
 EPOCHS = 40
@@ -96,8 +97,8 @@ def test_peer_allreduce_between_processes_on_one_device(world, tmp_path):
 
 
 def test_peer_allreduce_times_out_without_hanging():
-    """a world of two in which the peer never raises its flag: the kernel gives up after ~2 s, reports it, and the
-    buffer keeps this rank's values"""
+    """a world of two in which the peer never raises its flag: the kernel gives up after the time-out (1.5 s here; 20 s by
+    default), reports it, and -- one workgroup, nothing summed yet -- the buffer keeps this rank's values"""
     import ctypes
     from dbaf_amd import _lib
     from dbaf_amd.peer import PeerAllReduce
@@ -124,6 +125,10 @@ def test_peer_allreduce_times_out_without_hanging():
     peer.all_reduce(t)
     assert peer.timed_out()
     assert torch.equal(t.cpu(), torch.arange(64, dtype=torch.float64))
+    # the sharded driver surfaces it (PeerDist.check after every ba()): raises once, then the status word is clear again
+    with pytest.raises(RuntimeError):
+        peer.check()
+    peer.check()
     peer.close()
     lib.dba_peer_exchange_close(other, 0)
 
