@@ -82,6 +82,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   const size_t o_hparte = take(sizeof(float) * (size_t)(N > 0 ? N : 1) * nparts_max * HPE_STRIDE);
   const size_t o_hpartf = take(sizeof(float) * (size_t)(Mmax > 0 ? Mmax : 1) * nparts_max * HPF_STRIDE);
   L.dx = take(sizeof(float) * (size_t)(n6 > 0 ? n6 : 1));
+  const size_t o_ptmp = take(sizeof(float) * 2 * 7 * (size_t)B);
   L.H = take(sizeof(double) * (size_t)(n6 > 0 ? n6 * (size_t)n6 : 1));
   L.b = take(sizeof(double) * (size_t)(n6 > 0 ? n6 : 1));
   size_t o_lscratch = 0;
@@ -122,6 +123,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->W.HpartE = reinterpret_cast<float *>(base + o_hparte);
     plan->W.HpartF = reinterpret_cast<float *>(base + o_hpartf);
     plan->W.dx = reinterpret_cast<float *>(base + L.dx);
+    plan->W.poses_tmp = reinterpret_cast<float *>(base + o_ptmp);
     plan->W.H = reinterpret_cast<double *>(base + L.H);
     plan->W.b = reinterpret_cast<double *>(base + L.b);
     plan->W.Lscratch = want_scratch ? reinterpret_cast<double *>(base + o_lscratch) : nullptr;
@@ -177,12 +179,14 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
   return DBA_OK;
 }
 
-int dba_ba_linearize(const float *poses, const float *disps, const float *intrinsics,
-                     const float *disps_sens, const float *targets, const float *weights,
-                     const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
-                     const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
-                     float alpha, void *ws, size_t ws_bytes, dba_stream_t stream) {
-  (void)ii;
+// upd: 0 = linearise the state as stored; bit 0 = poses still need Exp(W.dx) (retracted on the fly, the retracted window is
+// stored in poses_out), bit 1 = the depths still need the previous iteration's dz (applied in place in disps_w)
+static int ba_linearize_stage(const float *poses, const float *disps, const float *intrinsics,
+                              const float *disps_sens, const float *targets, const float *weights,
+                              const float *eta, int eta_rows, const int64_t *jj,
+                              const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                              float alpha, int upd, float *poses_out, float *disps_w, void *ws, size_t ws_bytes,
+                              dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -195,7 +199,7 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
 #define LAUNCH_LIN(PPL, MF, EW)                                                                                \
   hipLaunchKernelGGL((ba_linearize_kernel<PPL, MF, EW>), dim3(plan.nchunks * EW, plan.T.Mmax + 1), dim3(256), 0, \
                      (hipStream_t)stream, poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, \
-                     frame_owned, N, plan.HW, wd, t0, plan.P, alpha, plan.T, plan.W)
+                     frame_owned, N, plan.HW, wd, t0, plan.P, alpha, upd, poses_out, disps_w, plan.T, plan.W)
   // one pixel per lane: the per-edge sums run on the matrix cores (DBA_LINEARIZE_MFMA=0 keeps the LDS transpose-reduce)
   static const bool no_mfma = [] { const char *e = getenv("DBA_LINEARIZE_MFMA"); return e && e[0] == '0'; }();
   if (plan.W.ppl == 4) LAUNCH_LIN(4, false, 1);
@@ -205,6 +209,16 @@ int dba_ba_linearize(const float *poses, const float *disps, const float *intrin
 #undef LAUNCH_LIN
   DBA_LAUNCH_CHECK();
   return DBA_OK;
+}
+
+int dba_ba_linearize(const float *poses, const float *disps, const float *intrinsics,
+                     const float *disps_sens, const float *targets, const float *weights,
+                     const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                     const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1,
+                     float alpha, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  (void)ii;
+  return ba_linearize_stage(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, B,
+                            ht, wd, t0, t1, alpha, 0, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 // lower != 0: only the lower triangle of H is kept up (half the float64 atomics; the solvers read nothing else)
@@ -258,11 +272,16 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   return dba_ba_symmetrize(N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
 }
 
+static std::atomic<int> g_schur_generation{0};
+
 int dba_ba_schur_select(int form) {
   if (form < 0 || form > 2) return DBA_ERR_ARG;
   g_schur_form.store(form, std::memory_order_relaxed);
+  g_schur_generation.fetch_add(1, std::memory_order_relaxed);
   return DBA_OK;
 }
+
+int dba_ba_schur_generation(void) { return g_schur_generation.load(std::memory_order_relaxed); }
 
 int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
   BaPlan plan;
@@ -297,12 +316,13 @@ int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float e
 
 static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
                             int ht, int wd, int t0, int t1, int update_poses, int update_disps, float *dz_out,
-                            float *dx_out, void *ws, size_t ws_bytes, dba_stream_t stream) {
+                            float *dx_out, void *ws, size_t ws_bytes, dba_stream_t stream,
+                            const float *poses_src = nullptr) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1);
-  hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, jj, frame_owned,
+  hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, poses_src, disps, jj, frame_owned,
                      plan.HW, t0, plan.P, update_poses, update_disps, dz_out, dx_out, plan.T, plan.W);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
@@ -336,31 +356,70 @@ int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64
                        stream);
 }
 
-int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
-           const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
-           const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
-           float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
-           dba_stream_t stream) {
+// prepared != 0: the index tables in `ws` are those of this graph already (a previous dba_ba / dba_ba_prepare with the
+// same ii, jj, sizes, t0, t1 and Schur form on this workspace): stage 0 is skipped.
+static int ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+                  const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+                  const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+                  float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
+                  dba_stream_t stream, int prepared) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
-  if (rc != DBA_OK) return rc;
-  const float alpha = 0.05f;  // droid_kernels.cu:1474
-  for (int itr = 0; itr < iterations; itr++) {
-    rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj,
-                          nullptr, N, B, ht, wd, t0, t1, alpha, ws, ws_bytes, stream);
+  if (!prepared) {
+    rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
+  }
+  const float alpha = 0.05f;  // droid_kernels.cu:1474
+  // Back-substitution + retraction of iteration k are folded into the linearisation of iteration k + 1 (one launch less
+  // per iteration; DBA_BA_FUSE_UPDATE=0 keeps them apart): the poses the next launch reads stay untouched, the retracted
+  // window travels through two workspace copies, and only the last iteration's update is a launch of its own, which
+  // writes the caller's poses.
+  static const bool fuse = [] { const char *e = getenv("DBA_BA_FUSE_UPDATE"); return !(e && e[0] == '0'); }();
+  const float *pose_src = poses;   // where the current poses are (before the pending retraction, if any)
+  bool pending = false;            // W.dx of the previous iteration has not been applied yet
+  for (int itr = 0; itr < iterations; itr++) {
+    float *pose_dst = plan.W.poses_tmp + (size_t)(itr & 1) * 7 * B;
+    const int upd = pending ? (motion_only ? 1 : 3) : 0;
+    rc = ba_linearize_stage(pose_src, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, nullptr, N, B,
+                            ht, wd, t0, t1, alpha, upd, pending ? pose_dst : nullptr, disps, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+    if (pending) pose_src = pose_dst;
     rc = ba_reduce_stage(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
     rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true);
     if (rc != DBA_OK) return rc;
     const bool last = (itr == iterations - 1);
+    if (fuse && !last) {
+      pending = true;
+      continue;
+    }
     rc = ba_update_launch(poses, disps, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
-                          last ? dz_out : nullptr, last ? dx_out : nullptr, ws, ws_bytes, stream);
+                          last ? dz_out : nullptr, last ? dx_out : nullptr, ws, ws_bytes, stream,
+                          pose_src == poses ? nullptr : pose_src);
     if (rc != DBA_OK) return rc;
+    pose_src = poses;
+    pending = false;
   }
   return DBA_OK;
+}
+
+int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+           const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+           const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+           float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
+           dba_stream_t stream) {
+  return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 0);
+}
+
+int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+                    const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+                    const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+                    float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
+                    dba_stream_t stream) {
+  return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 1);
 }
 
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,

@@ -47,6 +47,7 @@ struct BaBuffers {
   double *b;     // [6P]
   float *dx;     // [P, 6]
   double *Lscratch;  // packed lower triangle for systems too large for LDS
+  float *poses_tmp;  // [2][B, 7] the window as retracted by the iterations folded into the next linearisation (dba_ba)
   int nparts;    // pixel slices (waves) per frame for the chosen pixels-per-lane
   int ppl;       // pixels per lane of the linearisation kernel (1, 2 or 4)
 };
@@ -71,7 +72,7 @@ __global__ void ba_linearize_kernel(const float *poses, const float *disps, cons
                                     const float *disps_sens, const float *targets, const float *weights,
                                     const float *eta, int eta_rows, const int64_t *jj,
                                     const uint8_t *frame_owned, int N, int HW, int wd, int t0, int P,
-                                    float alpha, BaTables T, BaBuffers W);
+                                    float alpha, int upd, float *poses_out, float *disps_w, BaTables T, BaBuffers W);
 // lower != 0 (here and below): only the lower triangle of H is kept up (what the solvers read)
 __global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
                                    int t0, int P, int lower, BaTables T, BaBuffers W);
@@ -82,7 +83,7 @@ constexpr int GRAM_LIST_CAP = 1024;  // rows of one frame the per-source-frame S
 template <bool VEC>
 __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                      int t0, int P, int nch, int lower, BaTables T, BaBuffers W);
-__global__ void ba_update_kernel(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned,
+__global__ void ba_update_kernel(float *poses, const float *poses_src, float *disps, const int64_t *jj, const uint8_t *frame_owned,
                                  int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
                                  float *dx_out, BaTables T, BaBuffers W);
 __global__ void ba_copy_dx_kernel(const double *src, float *dst, int n);

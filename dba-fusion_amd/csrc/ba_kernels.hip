@@ -255,6 +255,106 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   for (int pp = tid; pp < P; pp += nt) T.fpose[pp] = fps[pp];
 }
 
+// expSE3 / retrSE3 (droid_kernels.cu:113-178, :922-940); quaternion deliberately not renormalised.
+__device__ void retract_pose(float *pose, const float *xi) {
+  const float *tau = xi, *phi = xi + 3;
+  const float th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  const float th4 = th2 * th2;
+  const float th = sqrtf(th2);
+  float imag, real;
+  if (th2 < 1e-8f) {
+    imag = 0.5f - (1.0f / 48.0f) * th2 + (1.0f / 3840.0f) * th4;
+    real = 1.0f - (1.0f / 8.0f) * th2 + (1.0f / 384.0f) * th4;
+  } else {
+    imag = sinf(0.5f * th) / th;
+    real = cosf(0.5f * th);
+  }
+  const float dq[4] = {imag * phi[0], imag * phi[1], imag * phi[2], real};
+  float dt[3] = {tau[0], tau[1], tau[2]};
+  if (th > 1e-4f) {
+    const float a = (1.f - cosf(th)) / th2;
+    const float b = (th - sinf(th)) / (th * th2);
+    const float c1[3] = {phi[1] * tau[2] - phi[2] * tau[1], phi[2] * tau[0] - phi[0] * tau[2],
+                         phi[0] * tau[1] - phi[1] * tau[0]};
+    const float c2[3] = {phi[1] * c1[2] - phi[2] * c1[1], phi[2] * c1[0] - phi[0] * c1[2],
+                         phi[0] * c1[1] - phi[1] * c1[0]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) dt[c] += a * c1[c] + b * c2[c];
+  }
+  const float t[3] = {pose[0], pose[1], pose[2]};
+  const float q[4] = {pose[3], pose[4], pose[5], pose[6]};
+  float q1[4], t1[3];
+  q1[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+  q1[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
+  q1[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
+  q1[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+  quat_rotate(dq, t, t1);
+  pose[0] = t1[0] + dt[0];
+  pose[1] = t1[1] + dt[1];
+  pose[2] = t1[2] + dt[2];
+  pose[3] = q1[0];
+  pose[4] = q1[1];
+  pose[5] = q1[2];
+  pose[6] = q1[3];
+}
+
+
+// pose row f as the linearisation must see it: the stored one, or -- when the retraction of the previous iteration is
+// folded into this kernel (upd) -- Exp(dx) applied to it for the poses of the window
+__device__ __forceinline__ void load_pose(const float *__restrict__ poses, const float *__restrict__ dx, int f, int t0, int P,
+                                          bool upd, float *out) {
+#pragma unroll
+  for (int c = 0; c < 7; c++) out[c] = poses[7 * f + c];
+  const int p = f - t0;
+  if (upd && p >= 0 && p < P) retract_pose(out, dx + 6 * p);
+}
+
+// relative pose of an edge (edge_pose of common.h) on poses that may still need the previous iteration's retraction
+__device__ __forceinline__ void edge_pose_upd(const float *__restrict__ poses, const float *__restrict__ dx, int ix, int jx,
+                                              int t0, int P, bool upd, float *tij, float *qij) {
+  if (ix == jx) {
+    tij[0] = -0.1f; tij[1] = 0.f; tij[2] = 0.f;
+    qij[0] = 0.f; qij[1] = 0.f; qij[2] = 0.f; qij[3] = 1.f;
+  } else {
+    float Pi[7], Pj[7];
+    load_pose(poses, dx, ix, t0, P, upd, Pi);
+    load_pose(poses, dx, jx, t0, P, upd, Pj);
+    rel_pose(Pi, Pj, tij, qij);
+  }
+}
+
+// depth update of pixel k of slot m: dz = Q (w - sum over the frame's rows of E^T dx)
+// (EvT6x1_kernel :1140-1160 incl. its skip of pose index <= 0, accum, :1495)
+__device__ __forceinline__ float backsub_pixel(const BaTables &T, const BaBuffers &W, int m, int frame, int k, int HW, int t0,
+                                               int P) {
+  float acc = 0.f;
+  const int p = frame - t0;
+  // EvT6x1_kernel skips rows whose pose index is <= 0 or >= P (droid_kernels.cu:1150)
+  if (p > 0 && p < P) {
+    const float *Er = W.E + ((size_t)p * 6) * HW + k;
+    const float *x = W.dx + 6 * p;
+    float dw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) dw += Er[(size_t)c * HW] * x[c];
+    acc += dw;
+  }
+  const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
+  for (int e = e0; e < e1; e++) {
+    const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * e);  // edge id, target frame: one lookup
+    const int n = ei.x;
+    const int tgt = ei.y - t0;
+    if (tgt <= 0 || tgt >= P) continue;
+    const float *Er = W.E + ((size_t)(P + n) * 6) * HW + k;
+    const float *x = W.dx + 6 * tgt;
+    float dw = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) dw += Er[(size_t)c * HW] * x[c];
+    acc += dw;
+  }
+  const size_t mk = (size_t)m * HW + k;
+  return W.Q[mk] * (W.w[mk] - acc);  // :1495
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage 1: fused linearisation per (source frame, 64-pixel wave slice)
 // ---------------------------------------------------------------------------------------------
@@ -434,13 +534,21 @@ __device__ unsigned long long g_lin_span[2 * 8192];
 // per edge, nearly all of it dependent latency, and the kernel lasts as long as the busiest frame's edge walk: with two
 // waves per slice that walk is half as long and twice as many waves hide each other's latency; their per-frame sums
 // (C, w, Ei, Hii, vi) meet in LDS at the end.
+// (one pixel per lane: four workgroups per CU, i.e. every workgroup of a 25-keyframe window resident at once, is worth
+// keeping: the register budget is held at 128)
 template <int PPL, bool MF, int EW>
-__global__ __launch_bounds__(256) void ba_linearize_kernel(
+__global__ __launch_bounds__(256, (PPL == 1 ? 4 : 1)) void ba_linearize_kernel(
     const float *__restrict__ poses, const float *__restrict__ disps, const float *__restrict__ intrinsics,
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
     const float *__restrict__ weights, const float *__restrict__ eta, int eta_rows,
     const int64_t *__restrict__ jj, const uint8_t *__restrict__ frame_owned, int N, int HW, int wd,
-    int t0, int P, float alpha, BaTables T, BaBuffers W) {
+    int t0, int P, float alpha, int upd, float *__restrict__ poses_out, float *__restrict__ disps_w, BaTables T,
+    BaBuffers W) {
+  // upd != 0: the back-substitution + retraction of the PREVIOUS Gauss-Newton iteration is folded into this launch
+  // (dba_ba: one launch and one kernel boundary less per iteration).  W.dx, W.E, W.Q, W.w still hold that iteration's
+  // values: a workgroup first moves the depths of its own pixels (bit 1; nobody else reads them: the linearisation only
+  // needs the SOURCE frame's depths), the poses are retracted on the fly wherever they are read, from `poses`, which is
+  // not written; one workgroup stores the retracted window in poses_out for the next launch.
 #ifdef LIN_PROF
   unsigned long long lp_ = wall_clock64();
   const unsigned long long lp_start_ = lp_;
@@ -451,8 +559,16 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
     const size_t total = (size_t)n6 * n6;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
       W.H[i] = 0.0;
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
       for (int i = threadIdx.x; i < n6; i += blockDim.x) W.b[i] = 0.0;
+      if (upd && poses_out)
+        for (int f = threadIdx.x; f < T.B; f += blockDim.x) {
+          float pr[7];
+          load_pose(poses, W.dx, f, t0, P, true, pr);
+#pragma unroll
+          for (int c = 0; c < 7; c++) poses_out[7 * f + c] = pr[c];
+        }
+    }
     return;
   }
   const int M = T.meta[0];
@@ -478,6 +594,18 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
     u[q] = (float)(kc[q] % wd);
     v[q] = (float)(kc[q] / wd);
     disp[q] = disps[(size_t)frame * HW + kc[q]];
+    if ((upd & 2) && active[q])  // disp_retr_kernel :988 of the previous iteration
+      disp[q] = disp[q] + backsub_pixel(T, W, m, frame, kc[q], HW, t0, P);
+  }
+  if (upd & 2) {
+    // every wave of the workgroup has read the old depths and the old rows of E by now: the waves that share a pixel
+    // slice computed the same new depth, one of them stores it; the rows of E are rewritten further down
+    __syncthreads();
+    if ((threadIdx.x >> 6) % EW == 0) {
+#pragma unroll
+      for (int q = 0; q < PPL; q++)
+        if (active[q]) disps_w[(size_t)frame * HW + kc[q]] = disp[q];
+    }
   }
 
   float Csum[PPL], wsum[PPL], Ei[PPL][6];
@@ -515,7 +643,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(
       const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * (batch + threadIdx.x));
       const int n = ei.x, jx = ei.y;
       float tij[3], qij[4];
-      edge_pose(poses, frame, jx, tij, qij);
+      edge_pose_upd(poses, W.dx, frame, jx, t0, P, upd != 0, tij, qij);
       const Rot3 R = quat_to_rot(qij);
       s_edge[threadIdx.x][0] = n;
       s_edge[threadIdx.x][1] = jx;
@@ -793,16 +921,20 @@ extern "C" void dba_lin_prof_dump() {
 
 template __global__ void ba_linearize_kernel<1, true, 2>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
-                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+                                                const uint8_t *, int, int, int, int, int, float, int, float *, float *,
+                                                BaTables, BaBuffers);
 template __global__ void ba_linearize_kernel<1, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
-                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+                                                const uint8_t *, int, int, int, int, int, float, int, float *, float *,
+                                                BaTables, BaBuffers);
 template __global__ void ba_linearize_kernel<2, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
-                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+                                                const uint8_t *, int, int, int, int, int, float, int, float *, float *,
+                                                BaTables, BaBuffers);
 template __global__ void ba_linearize_kernel<4, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
-                                                const uint8_t *, int, int, int, int, int, float, BaTables, BaBuffers);
+                                                const uint8_t *, int, int, int, int, int, float, int, float *, float *,
+                                                BaTables, BaBuffers);
 
 // ---------------------------------------------------------------------------------------------
 // stage 2: reduced camera system in float64
@@ -1280,50 +1412,10 @@ __global__ __launch_bounds__(256) void ba_symmetrize_kernel(double *__restrict__
 // ---------------------------------------------------------------------------------------------
 // stage 4: back-substitution + retraction
 // ---------------------------------------------------------------------------------------------
-// expSE3 / retrSE3 (droid_kernels.cu:113-178, :922-940); quaternion deliberately not renormalised.
-__device__ void retract_pose(float *pose, const float *xi) {
-  const float *tau = xi, *phi = xi + 3;
-  const float th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
-  const float th4 = th2 * th2;
-  const float th = sqrtf(th2);
-  float imag, real;
-  if (th2 < 1e-8f) {
-    imag = 0.5f - (1.0f / 48.0f) * th2 + (1.0f / 3840.0f) * th4;
-    real = 1.0f - (1.0f / 8.0f) * th2 + (1.0f / 384.0f) * th4;
-  } else {
-    imag = sinf(0.5f * th) / th;
-    real = cosf(0.5f * th);
-  }
-  const float dq[4] = {imag * phi[0], imag * phi[1], imag * phi[2], real};
-  float dt[3] = {tau[0], tau[1], tau[2]};
-  if (th > 1e-4f) {
-    const float a = (1.f - cosf(th)) / th2;
-    const float b = (th - sinf(th)) / (th * th2);
-    const float c1[3] = {phi[1] * tau[2] - phi[2] * tau[1], phi[2] * tau[0] - phi[0] * tau[2],
-                         phi[0] * tau[1] - phi[1] * tau[0]};
-    const float c2[3] = {phi[1] * c1[2] - phi[2] * c1[1], phi[2] * c1[0] - phi[0] * c1[2],
-                         phi[0] * c1[1] - phi[1] * c1[0]};
-#pragma unroll
-    for (int c = 0; c < 3; c++) dt[c] += a * c1[c] + b * c2[c];
-  }
-  const float t[3] = {pose[0], pose[1], pose[2]};
-  const float q[4] = {pose[3], pose[4], pose[5], pose[6]};
-  float q1[4], t1[3];
-  q1[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
-  q1[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
-  q1[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
-  q1[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
-  quat_rotate(dq, t, t1);
-  pose[0] = t1[0] + dt[0];
-  pose[1] = t1[1] + dt[1];
-  pose[2] = t1[2] + dt[2];
-  pose[3] = q1[0];
-  pose[4] = q1[1];
-  pose[5] = q1[2];
-  pose[6] = q1[3];
-}
-
-__global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ poses, float *__restrict__ disps,
+// poses_src: where the poses to retract are read from (dba_ba keeps the previous iterations' retractions in a workspace
+// copy, see ba_linearize_kernel); null = `poses` itself
+__global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ poses, const float *__restrict__ poses_src,
+                                                        float *__restrict__ disps,
                                                         const int64_t *__restrict__ jj,
                                                         const uint8_t *__restrict__ frame_owned, int HW,
                                                         int t0, int P, int update_poses, int update_disps,
@@ -1335,7 +1427,12 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
     if (dx_out)  // the caller's copy of the last pose update
       for (int i = threadIdx.x; i < 6 * P; i += blockDim.x) dx_out[i] = W.dx[i];
     if (!update_poses) return;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) retract_pose(poses + 7 * (t0 + p), W.dx + 6 * p);
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      float pr[7];
+      load_pose(poses_src ? poses_src : poses, W.dx, t0 + p, t0, P, true, pr);
+#pragma unroll
+      for (int c = 0; c < 7; c++) poses[7 * (t0 + p) + c] = pr[c];
+    }
     return;
   }
   if (!update_disps) return;
@@ -1346,32 +1443,8 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= HW) return;
 
-  float acc = 0.f;
-  const int p = frame - t0;
-  // EvT6x1_kernel skips rows whose pose index is <= 0 or >= P (droid_kernels.cu:1150)
-  if (p > 0 && p < P) {
-    const float *Er = W.E + ((size_t)p * 6) * HW + k;
-    const float *x = W.dx + 6 * p;
-    float dw = 0.f;
-#pragma unroll
-    for (int c = 0; c < 6; c++) dw += Er[(size_t)c * HW] * x[c];
-    acc += dw;
-  }
-  const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
-  for (int e = e0; e < e1; e++) {
-    const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * e);  // edge id, target frame: one lookup
-    const int n = ei.x;
-    const int tgt = ei.y - t0;
-    if (tgt <= 0 || tgt >= P) continue;
-    const float *Er = W.E + ((size_t)(P + n) * 6) * HW + k;
-    const float *x = W.dx + 6 * tgt;
-    float dw = 0.f;
-#pragma unroll
-    for (int c = 0; c < 6; c++) dw += Er[(size_t)c * HW] * x[c];
-    acc += dw;
-  }
+  const float dz = backsub_pixel(T, W, m, frame, k, HW, t0, P);
   const size_t mk = (size_t)m * HW + k;
-  const float dz = W.Q[mk] * (W.w[mk] - acc);  // :1495
   const size_t fk = (size_t)frame * HW + k;
   disps[fk] = disps[fk] + dz;                  // disp_retr_kernel :988
   if (dz_out) dz_out[mk] = dz;

@@ -31,6 +31,7 @@ SYMBOLS = {
     "dba_ba_linearize": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
     "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_ba_schur_select": (c_int, [c_int]),
+    "dba_ba_schur_generation": (c_int, []),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
     "dba_ba_solve": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
     "dba_ba_update": (c_int, [_P] * 5 + [c_int] * 8 + [_P, _P, c_size_t, _P]),
@@ -38,6 +39,8 @@ SYMBOLS = {
     "dba_ba_shard_back": (c_int, [_P] * 5 + [c_int] * 6 + [c_float, c_float, c_int, _P, _P, c_size_t, _P]),
     "dba_ba": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
                                                                      c_size_t, _P]),
+    "dba_ba_prepared": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
+                                                                              c_size_t, _P]),
     "dba_bacore_hessian": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P]),
     "dba_bacore_retract": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
     "dba_bacore_optimize": (c_int, [_P, _P] + [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),
@@ -86,6 +89,10 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def schur_generation():
+    return load().dba_ba_schur_generation()
 
 
 def check(rc, what):

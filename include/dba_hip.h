@@ -97,6 +97,8 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
  * the matrix cores, every row of E read once -- on windows whose frames couple many rows, the (row, partner) grid on
  * sparse ones), 1 = (row, partner) grid, 2 = per-source-frame form.  Initialised from DBA_SCHUR_KERNEL = rows | frame. */
 int dba_ba_schur_select(int form);
+int dba_ba_schur_generation(void); /* number of dba_ba_schur_select calls so far: tables prepared under another generation
+                                    * may lack what the form in force needs (callers of dba_ba_prepared compare it) */
 
 /* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
  * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
@@ -143,6 +145,18 @@ int dba_ba(float *poses, float *disps, const float *intrinsics, const float *dis
            const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
            int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
            void *ws, size_t ws_bytes, dba_stream_t stream);
+
+/* The same with stage 0 skipped: the index tables in `ws` must be those of THIS graph already, i.e. the last dba_ba /
+ * dba_ba_prepare on this workspace had the same ii, jj (contents), N, B, ht, wd, t0, t1 and Schur kernel form.  For callers
+ * that run several updates on one covisibility graph (CovisibleGraph.update does, dbaf/covisible_graph.py:214-342: the
+ * adapter keeps one workspace per window shape and recognises an unchanged edge list, droid_backends/__init__.py).
+ * Back-substitution + retraction of every iteration but the last are folded into the next iteration's linearisation in
+ * both (iterations launches fewer; DBA_BA_FUSE_UPDATE=0 keeps them apart). */
+int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+                    const float *targets, const float *weights, const float *eta, int eta_rows,
+                    const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
+                    int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
+                    void *ws, size_t ws_bytes, dba_stream_t stream);
 
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
  * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */

@@ -67,6 +67,13 @@ def test_ba_matches_oracle(name):
     else:
         msg = check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
                           ref32_disps=clamp(r32["disps"]))
+    # (the fp32-faithful oracle's own pose deviation goes into the report next to the device's; it widens nothing here)
+    from util import quat_angle, _record
+    _record(dict(kind="oracle32_pose_deviation", window=name,
+                 ref32_own_dt_m=float(np.abs(r32["poses"][:, :3].astype(np.float64) - r64["poses"][:, :3]).max()),
+                 ref32_own_dr_rad=float(quat_angle(r32["poses"][:, 3:].astype(np.float64), r64["poses"][:, 3:]).max()),
+                 device_dt_m=float(np.abs(poses[:, :3].astype(np.float64) - r64["poses"][:, :3]).max()),
+                 device_dr_rad=float(quat_angle(poses[:, 3:].astype(np.float64), r64["poses"][:, 3:]).max())))
     print(name, "vs fp64 arbiter:", msg)
     np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
 
@@ -302,6 +309,85 @@ def test_ba_rejects_cpu_and_noncontiguous():
                           d["weight"], d["eta"], d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
 
 
+def test_ba_three_and_four_iterations_match_the_oracle():
+    """iterations > 2: the retracted window ping-pongs between the two workspace copies while back-substitution +
+    retraction ride in the next linearisation (csrc/ba_host.hip: ba_run); motion_only folds the pose part alone"""
+    orc = _oracle()
+    for itrs, motion_only in ((3, False), (4, False), (3, True)):
+        W = syn.window_tiny_b(70 + itrs)
+        r64 = orc.ba(W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, itrs,
+                     W.lm, W.ep, motion_only, 0.05, np.float64)
+        poses, disps, dx, dz = _run_gpu_ba(W, itrs=itrs, motion_only=motion_only)
+        if motion_only:
+            assert np.array_equal(disps, W.disps)
+        check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
+        np.testing.assert_allclose(dx, r64["dx"], rtol=2e-3, atol=5e-6)
+
+
+def test_ba_with_update_and_linearisation_in_separate_launches():
+    """DBA_BA_FUSE_UPDATE=0: one update launch per iteration, as the sharded driver runs them -- the same parity cases"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, DBA_BA_FUSE_UPDATE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_ba.py"),
+                        "-k", "test_ba_matches_oracle or three_and_four or motion_only or prepared"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ba_prepared_workspace_is_reused_only_for_the_same_graph():
+    """droid_backends.ba keeps one workspace per window shape and skips stage 0 when it finds it prepared for the very same
+    edge tensors (CovisibleGraph.update calls ba repeatedly on self.ii / self.jj): repeated calls, an in-place edit of jj,
+    another graph of the same shape in between, and fresh tensors with the same contents all give what a cold call gives"""
+    import droid_backends
+    from droid_backends import _BA_WS
+    assert _BA_WS.enabled
+    W = syn.window_tiny_b(81)
+
+    def cold(Wx):
+        saved = _BA_WS.enabled
+        _BA_WS.enabled = False
+        try:
+            return _run_gpu_ba(Wx)
+        finally:
+            _BA_WS.enabled = saved
+
+    ref = cold(W)
+    d = to_dev(W)
+    args = lambda dd: (dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], dd["target"], dd["weight"], dd["eta"],
+                       dd["ii"], dd["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)  # noqa: E731
+    ii, jj = d["ii"], d["jj"]
+    state = lambda dd: (dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy())  # noqa: E731
+    for rep in range(3):     # rep 0 prepares, rep 1, 2 find the tables in place
+        dd = to_dev(W)
+        dd["ii"], dd["jj"] = ii, jj
+        droid_backends.ba(*args(dd))
+        p, z = state(dd)
+        assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1]), rep
+    key = [k for k in _BA_WS.graph if k[-1] == (W.N, W.B, W.h, W.w, W.t0, W.t1)]
+    assert key and _BA_WS.prepared_for(key[0], ii, jj)
+    # a different graph of the same shape (same N, so the same workspace): edge 3 re-targeted, in place (version bump)
+    W2 = syn.window_tiny_b(81)
+    W2.jj = W2.jj.copy()
+    W2.jj[3] = 5 if W2.jj[3] != 5 else 4
+    ref2 = cold(W2)
+    jj[3] = int(W2.jj[3])
+    assert not _BA_WS.prepared_for(key[0], ii, jj)
+    dd = to_dev(W2)
+    dd["ii"], dd["jj"] = ii, jj
+    droid_backends.ba(*args(dd))
+    p, z = state(dd)
+    assert np.array_equal(p, ref2[0]) and np.array_equal(z, ref2[1])
+    # fresh tensors holding the first graph again: a miss, the tables are rebuilt
+    dd = to_dev(W)
+    droid_backends.ba(*args(dd))
+    p, z = state(dd)
+    assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1])
+    assert not _BA_WS.prepared_for(key[0], ii, jj) and _BA_WS.prepared_for(key[0], dd["ii"], dd["jj"])
+
+
 def test_ba_general_size_solver_path_matches_too():
     """Window-sized systems take the register-tile LDL^T (csrc/ba_solve_tile.hip); the general-size blocked
     Cholesky (csrc/ba_solve.hip) stays reachable with DBA_SOLVE_GENERAL=1 and must pass the same parity cases."""
@@ -366,8 +452,10 @@ def test_ba_random_graphs_match_oracle(seed, num_kf, n_edges, t0, long_range):
     # tiny maps make the systems poorly conditioned: the fp32-built system is solved in fp64 on both sides, so the
     # pose update is compared with the fp32-faithful oracle's (same inputs to the solve) and the state with the arbiter
     np.testing.assert_allclose(dx, r32["dx"], rtol=2e-2, atol=2e-4)
+    # poses: the north-star bound (1e-5 m / 1e-6 rad), widened only where the fp32-faithful oracle is itself further than
+    # half of it from the arbiter (then: within twice the reference arithmetic's own deviation, which the report records)
     print(check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps,
-                      ref32_disps=clamp(r32["disps"]), t_tol=2e-4, r_tol=2e-4, d_rtol=2e-3, frac=0.95))
+                      ref32_disps=clamp(r32["disps"]), ref32_poses=r32["poses"], d_rtol=2e-3, frac=0.95))
 
 
 def test_ba_extend_exports_the_system_and_matches_ba_with_a_zero_prior():

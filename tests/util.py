@@ -40,7 +40,7 @@ def _record(rec):
 
 
 def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None, t_tol=1e-5, r_tol=1e-6,
-                d_rtol=1e-4, frac=0.995, ref32_factor=2.0):
+                d_rtol=1e-4, frac=0.995, ref32_factor=2.0, ref32_poses=None):
     """north_star tolerances: poses 1e-5 m / 1e-6 rad; inverse depths 1e-4 relative -- measured against the
     float64 arbiter instantiation of the oracle.
 
@@ -50,10 +50,20 @@ def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None,
         restatement, ref32) is further than that from exact arithmetic, the HIP path must be no worse than
         ref32_factor times the reference's own deviation (pass ref32_disps=None to switch the allowance off).
     In addition at least `frac` of the non-cancelling pixels (|d_ref| >= 0.1 |d_old|) must meet the pure relative
-    bound d_rtol * |d_ref|.  Every call appends its measured worst cases to gpurun_out/parity_report.jsonl."""
+    bound d_rtol * |d_ref|.
+    Pose criterion: t_tol / r_tol; with ref32_poses (the fp32-faithful oracle's poses) the bound of each is widened to
+    ref32_factor x the fp32 oracle's OWN distance from the arbiter where that is larger -- and that distance is recorded,
+    so the report shows whether "the reference's fp32 arithmetic is no better" is true of the poses too.
+    Every call appends its measured worst cases to gpurun_out/parity_report.jsonl."""
     poses, ref_poses = np.asarray(poses, np.float64), np.asarray(ref_poses, np.float64)
     dt = np.abs(poses[:, :3] - ref_poses[:, :3]).max()
     dr = quat_angle(poses[:, 3:], ref_poses[:, 3:]).max()
+    dt32 = dr32 = None
+    if ref32_poses is not None:
+        p32 = np.asarray(ref32_poses, np.float64)
+        dt32 = float(np.abs(p32[:, :3] - ref_poses[:, :3]).max())
+        dr32 = float(quat_angle(p32[:, 3:], ref_poses[:, 3:]).max())
+        t_tol, r_tol = max(t_tol, ref32_factor * dt32), max(r_tol, ref32_factor * dr32)
     d, r, o = np.asarray(disps, np.float64), np.asarray(ref_disps, np.float64), np.asarray(old_disps, np.float64)
     err = np.abs(d - r)
     scale = np.maximum(np.abs(r), np.abs(o))
@@ -74,6 +84,7 @@ def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None,
                depth_max_err_over_dref_noncancelling=float(pure_err.max()), depth_p999_err_over_dref=float(
                    np.quantile(pure_err, 0.999)), frac_pure_rel_ok=float(pure), pixels=int(err.size),
                pixels_needing_ref32_allowance=n_allow, ref32_own_max_dev_over_scale=ref32_worst,
+               ref32_own_dt_m=dt32, ref32_own_dr_rad=dr32,
                tol=dict(t=t_tol, r=r_tol, d_rtol=d_rtol, frac=frac,
                         ref32_factor=ref32_factor if ref32_disps is not None else None))
     _record(rec)
