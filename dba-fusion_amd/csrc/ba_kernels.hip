@@ -309,18 +309,42 @@ __device__ __forceinline__ void load_pose(const float *__restrict__ poses, const
   if (upd && p >= 0 && p < P) retract_pose(out, dx + 6 * p);
 }
 
-// relative pose of an edge (edge_pose of common.h) on poses that may still need the previous iteration's retraction
-__device__ __forceinline__ void edge_pose_upd(const float *__restrict__ poses, const float *__restrict__ dx, int ix, int jx,
-                                              int t0, int P, bool upd, float *tij, float *qij) {
+// relative pose of an edge Gij = Tj Ti^-1 as t[3], R[9] (row-major) in double, from the float poses (retracted in float
+// first where the previous iteration's update is still pending; the stereo special case of droid_kernels.cu:263-273)
+__device__ __forceinline__ void edge_pose64(const float *__restrict__ poses, const float *__restrict__ dx, int ix, int jx,
+                                            int t0, int P, bool upd, double *t, double *R) {
+  double q[4];
   if (ix == jx) {
-    tij[0] = -0.1f; tij[1] = 0.f; tij[2] = 0.f;
-    qij[0] = 0.f; qij[1] = 0.f; qij[2] = 0.f; qij[3] = 1.f;
+    t[0] = -0.1; t[1] = 0.0; t[2] = 0.0;
+    q[0] = 0.0; q[1] = 0.0; q[2] = 0.0; q[3] = 1.0;
   } else {
     float Pi[7], Pj[7];
     load_pose(poses, dx, ix, t0, P, upd, Pi);
     load_pose(poses, dx, jx, t0, P, upd, Pj);
-    rel_pose(Pi, Pj, tij, qij);
+    const double ti[3] = {Pi[0], Pi[1], Pi[2]}, qi[4] = {Pi[3], Pi[4], Pi[5], Pi[6]};
+    const double tj[3] = {Pj[0], Pj[1], Pj[2]}, qj[4] = {Pj[3], Pj[4], Pj[5], Pj[6]};
+    // qij = qj * conj(qi)  (relSE3, droid_kernels.cu:99-110)
+    q[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+    q[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+    q[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+    q[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+    const double uv0 = 2.0 * (q[1] * ti[2] - q[2] * ti[1]);
+    const double uv1 = 2.0 * (q[2] * ti[0] - q[0] * ti[2]);
+    const double uv2 = 2.0 * (q[0] * ti[1] - q[1] * ti[0]);
+    t[0] = tj[0] - (ti[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1));
+    t[1] = tj[1] - (ti[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2));
+    t[2] = tj[2] - (ti[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0));
   }
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1.0 - 2.0 * (y * y + z * z);
+  R[1] = 2.0 * (x * y - w * z);
+  R[2] = 2.0 * (x * z + w * y);
+  R[3] = 2.0 * (x * y + w * z);
+  R[4] = 1.0 - 2.0 * (x * x + z * z);
+  R[5] = 2.0 * (y * z - w * x);
+  R[6] = 2.0 * (x * z - w * y);
+  R[7] = 2.0 * (y * z + w * x);
+  R[8] = 1.0 - 2.0 * (x * x + y * y);
 }
 
 // depth update of pixel k of slot m: dz = Q (w - sum over the frame's rows of E^T dx)
@@ -642,15 +666,19 @@ __global__ __launch_bounds__(256, (PPL == 1 ? 4 : 1)) void ba_linearize_kernel(
     if ((int)threadIdx.x < cnt) {
       const int2 ei = *reinterpret_cast<const int2 *>(T.einfo + 2 * (batch + threadIdx.x));
       const int n = ei.x, jx = ei.y;
-      float tij[3], qij[4];
-      edge_pose_upd(poses, W.dx, frame, jx, t0, P, upd != 0, tij, qij);
-      const Rot3 R = quat_to_rot(qij);
+      // The relative pose Tj Ti^-1 of the edge is formed in FLOAT64 from the float poses and rounded once: its translation
+      // tj - Rij ti is a difference of two absolute positions, which in float costs ~20 x the rounding of the result -- on
+      // the oracle that one cancellation is most of the distance between the fp32 path and the float64 arbiter (worst depth
+      // 7.5e-5 -> 2.9e-5 on the 25-KF window, 2.0e-4 -> 1.1e-4 on the KITTI-shaped fixture; poses 8.2e-6 -> 2.5e-6 m at
+      // 32 KF).  One lane per edge pays for it; the per-pixel arithmetic is the reference's float.
+      double t64[3], R64[9];
+      edge_pose64(poses, W.dx, frame, jx, t0, P, upd != 0, t64, R64);
       s_edge[threadIdx.x][0] = n;
       s_edge[threadIdx.x][1] = jx;
 #pragma unroll
-      for (int c = 0; c < 3; c++) s_pose[threadIdx.x][c] = tij[c];
+      for (int c = 0; c < 3; c++) s_pose[threadIdx.x][c] = (float)t64[c];
 #pragma unroll
-      for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = R.r[c];
+      for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = (float)R64[c];
     }
     __syncthreads();
     LP(2);
