@@ -87,6 +87,11 @@ def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None,
                ref32_own_dt_m=dt32, ref32_own_dr_rad=dr32,
                tol=dict(t=t_tol, r=r_tol, d_rtol=d_rtol, frac=frac,
                         ref32_factor=ref32_factor if ref32_disps is not None else None))
+    # where the worst pixel is and what kind of pixel it is (a depth the update shrinks, a far point ...)
+    wi = int(np.argmax(err / np.maximum(scale, 1e-12)))
+    rec["worst_pixel"] = dict(index=[int(v) for v in np.unravel_index(wi, err.shape)], d_ref=float(r.flat[wi]),
+                              d_old=float(o.flat[wi]), err=float(err.flat[wi]),
+                              ref32_err=(float(dev32.flat[wi]) if ref32_disps is not None else None))
     _record(rec)
     msg = ("dt=%.3e m dr=%.3e rad depth max(err/allowed)=%.3f max(err/scale)=%.3e max(err/|d_ref|)=%.3e "
            "pure-rel frac=%.6f ref32-allowance pixels=%d/%d" % (
