@@ -341,6 +341,22 @@ def main():
         torch.cuda.synchronize()
         tz = time.perf_counter() - tz
         extras["zero_edit_dba_update_per_s"] = round(nz / tz, 1)
+        # what the flow-aligned shadow of the zero-edit route costs: one re-layout pass per level whenever the level
+        # tensors are new (every graph change: torch.cat / boolean index create new tensors), and the pyramid's memory
+        # a second time
+        from droid_backends import _SHADOWS
+        if _SHADOWS.enabled:
+            lib_ = _lib.load()
+
+            def reshear():
+                for lvl in range(4):
+                    v = ref_blk.corr_pyramid[lvl]
+                    ent = _SHADOWS.seen.get(id(v))
+                    if ent is not None and ent[3] is not None:
+                        lib_.dba_corr_shear_level(v.data_ptr(), ent[3].data_ptr(), n_loc, h, w, h >> lvl, w >> lvl, lvl,
+                                                  torch.cuda.current_stream().cuda_stream)
+            extras["zero_edit_shadow_build_us_per_edge"] = round(timed(reshear, 3) / n_loc, 2)
+            extras["zero_edit_shadow_bytes"] = int(sum(e[3].numel() * 2 for e in _SHADOWS.seen.values() if e[3] is not None))
         extras["zero_edit_lookup_us"] = round(float(np.mean([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in range(nz)]))
                                               * 1e3, 1)
 

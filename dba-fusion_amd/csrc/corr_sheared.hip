@@ -129,11 +129,13 @@ struct ShPixel {  // per-pixel lookup state, identical arithmetic in the streami
   _Float16 h00, h01, h10, h11;
 };
 
+// slvl: the level the coordinates still have to be scaled to (lvl, or 0 when the caller passes coords / 2^lvl already, as
+// the reference's CorrBlock.__call__ does per level: a float divided by a power of two is the same float either way)
 template <int R>
-__device__ __forceinline__ ShPixel sh_pixel(float2 c, int lvl, int x1, int y1, int h2l, int w2l, bool active) {
+__device__ __forceinline__ ShPixel sh_pixel(float2 c, int lvl, int x1, int y1, int h2l, int w2l, bool active, int slvl) {
   constexpr int WN = 2 * R + 2;
   ShPixel p;
-  const float scale = 1.0f / (float)(1 << lvl);
+  const float scale = 1.0f / (float)(1 << slvl);
   const float x0 = c.x * scale, y0 = c.y * scale;
   const float fx = floorf(x0), fy = floorf(y0);
   const float dx = x0 - fx, dy = y0 - fy;
@@ -153,6 +155,14 @@ __device__ __forceinline__ ShPixel sh_pixel(float2 c, int lvl, int x1, int y1, i
   p.h10 = (_Float16)w10;
   p.h11 = (_Float16)w11;
   return p;
+}
+
+// coordinates of pixel p of edge e: [n, h, w, 2] (the reprojection's layout) or planar [n, 2, h, w] (what
+// droid_backends.corr_index_forward is handed, corr.py:44-47)
+__device__ __forceinline__ float2 sh_coord(const float2 *__restrict__ coords, bool planar, size_t e, int HW1, int p) {
+  if (!planar) return coords[e * HW1 + p];
+  const float *cf = reinterpret_cast<const float *>(coords) + e * 2 * HW1 + p;
+  return make_float2(cf[0], cf[HW1]);
 }
 
 // c10::Half `a * b` / `a + b` compute in float and round to half; for two halves that is exactly the IEEE half
@@ -194,9 +204,13 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
                                                                           const float2 *__restrict__ coords,
                                                                           _Float16 *__restrict__ out, int n,
                                                                           int h1, int w1, int h2, int w2,
-                                                                          int num_levels) {
+                                                                          int num_levels, int lvl0, int cflags) {
+  // lvl0 / cflags: a launch may serve a sub-range of levels [lvl0, lvl0 + gridDim.y) of the pyramid (num_levels = levels
+  // in `out`, the first of them lvl0), with planar (bit 0) and / or pre-scaled (bit 1) coordinates: the per-level calls of
+  // the reference's unmodified CorrBlock (droid_backends.corr_index_forward on a flow-aligned shadow of the level)
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "the streaming lookup is written for radius 3");
+  const bool cplanar = (cflags & 1) != 0;
   __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
   __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];  // tap rows of lanes that touch nothing
   __shared__ u4v keep_all[SH_WAVES][2][64];  // per staging slot: 16-bit keep mask per half (image-border pieces)
@@ -213,15 +227,16 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   // (XCD k receives the workgroups k, k + 8, ...: q + (k < r) of them for gridDim.x = 8 q + r; a bijection)
   const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
   const int lb = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
-  const int lvl = blockIdx.y;  // (levels stay apart in the dispatch order: interleaving them cost 30 %)
+  const int lvl = blockIdx.y + lvl0;  // (levels stay apart in the dispatch order: interleaving them cost 30 %)
   const int rowid = lb * SH_WAVES + wave;
 #else
-  const int lvl = blockIdx.y;
+  const int lvl = blockIdx.y + lvl0;
   const int rowid = blockIdx.x * SH_WAVES + wave;  // (e * h1 + y1) * xtiles + xt
 #endif
+  const int slvl = (cflags & 2) ? 0 : lvl;
   const int h2l = h2 >> lvl, w2l = w2 >> lvl;
   const bool rowvalid = rowid < n * h1 * xtiles;
-  _Float16 *olvl = out + (size_t)lvl * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
+  _Float16 *olvl = out + (size_t)blockIdx.y * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
   const size_t estride = (size_t)num_levels * RD * RD * HW1;
   if (threadIdx.x == 0) ocount = 0;
   for (int i = threadIdx.x; i < WN * 64; i += SH_BLOCK) zero_taps[i] = (_Float16)0.f;
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     const int x1 = xt * 64 + lane;
     const bool active = x1 < w1;
     const int x1c = min(x1, w1 - 1);
-    const ShPixel P = sh_pixel<R>(coords[(size_t)ey * w1 + x1c], lvl, x1c, y1, h2l, w2l, active);
+    const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1c), lvl, x1c, y1, h2l, w2l, active, slvl);
     const bool touches = P.touches;
     const int ox = P.ox, oy = P.oy, sy = y1 >> lvl;
     _Float16 *obase = olvl + (size_t)e * estride;     // uniform
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     const int pix = olist[t];  // (e * h1 + y1) * w1 + x1
     const int x1 = pix % w1, ey = pix / w1;
     const int y1 = ey % h1, e = ey / h1;
-    const ShPixel P = sh_pixel<R>(coords[pix], lvl, x1, y1, h2l, w2l, true);
+    const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1), lvl, x1, y1, h2l, w2l, true, slvl);
     const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1 + x1;
     _Float16 *o = olvl + (size_t)e * estride + (size_t)y1 * w1 + x1;
     int dxm[WN];
@@ -532,7 +547,7 @@ __device__ __forceinline__ int sh2_mod(int v, int n, float inv_n, bool pow2) {
 template <int R>
 __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_resident_kernel(
     ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1) {
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -547,7 +562,9 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
 #else
   const int lb = blockIdx.x;
 #endif
-  const int lvl = blockIdx.y;
+  const int lvl = blockIdx.y + lvl0;   // (lvl0, cflags: see the streaming kernel)
+  const int slvl = (cflags & 2) ? 0 : lvl;
+  const bool cplanar = (cflags & 1) != 0;
   const int sid = lb * SH2_WAVES + wave;
   if (sid >= n * strips) return;  // (waves of a workgroup are independent: no barriers below)
   const int e = sid / strips, p0 = (sid - e * strips) << 6;
@@ -569,11 +586,11 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
   int x1 = pc - y1 * w1;
   if (x1 < 0) { y1--; x1 += w1; }
   if (x1 >= w1) { y1++; x1 -= w1; }
-  const ShPixel P = sh_pixel<R>(coords[(size_t)e * HW1 + pc], lvl, x1, y1, h2l, w2l, active);
+  const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, pc), lvl, x1, y1, h2l, w2l, active, slvl);
   const bool touches = P.touches;
   const int ox = P.ox, oy = P.oy;
 
-  _Float16 *obase = out + ((size_t)e * num_levels + lvl) * RD * RD * HW1;  // this edge, this level: [49][HW1]
+  _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;  // this edge, this level: [49][HW1]
   const size_t rowstride = (size_t)w2l * HW1p;                              // elements between consecutive dy
   const unsigned rowbytes = (unsigned)(2 * rowstride);
   const _Float16 *vedge = L.vol[lvl] + (size_t)e * h2l * rowstride;
@@ -833,16 +850,9 @@ int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int 
   return DBA_OK;
 }
 
-int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coords_nhw2, void *corr, int n, int h1,
-                                    int w1, int h2, int w2, int num_levels, int radius, dba_stream_t stream) {
-  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS)
-    return DBA_ERR_ARG;
-  if (radius != 3) return DBA_ERR_UNSUPPORTED;
-  if (n == 0) return DBA_OK;
-  if (!volumes || !coords_nhw2 || !corr) return DBA_ERR_ARG;
-  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
-  ShLevels L;
-  for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
+// levels [lvl0, lvl0 + nlv) of the pyramid -> corr [n, nlv, 49, h1, w1]
+static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *corr, int n, int h1, int w1, int h2, int w2,
+                                 int lvl0, int nlv, int cflags, dba_stream_t stream) {
   if ((long)n * h1 * w1 >= 2147483647L) return DBA_ERR_UNSUPPORTED;
   const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
   // Two forms of the kernel (see the comments at each): "streaming" walks the union row by row (2 KB of LDS per wave,
@@ -854,20 +864,20 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
   const bool stream_ok = (w1 % 64 == 0);
   const int sel = g_lookup_select.load(std::memory_order_relaxed);
   const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
+  hipEvent_t e0 = g_time_start, e1 = g_time_stop;
+  g_time_start = g_time_stop = nullptr;
   if (want_stream && stream_ok) {
     const int xtiles = (w1 + 63) / 64;
     const long rows = (long)n * h1 * xtiles;
-    dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), num_levels);
-    hipEvent_t e0 = g_time_start, e1 = g_time_stop;
-    g_time_start = g_time_stop = nullptr;
+    dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), nlv);
     hipExtLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, e0, e1, 0, L,
-                          reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          num_levels);
+                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                          nlv, lvl0, cflags);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
   const long strips = (long)n * (HW1p / 64);
-  dim3 grid((unsigned)((strips + SH2_WAVES - 1) / SH2_WAVES), num_levels);
+  dim3 grid((unsigned)((strips + SH2_WAVES - 1) / SH2_WAVES), nlv);
   const size_t lds = (size_t)SH2_WAVES * SH2_WAVE_BYTES;
   if (lds > 64 * 1024) {
     static DeviceOnce attr_once;
@@ -877,13 +887,35 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
       attr_once.done();
     }
   }
-  hipEvent_t e0 = g_time_start, e1 = g_time_stop;
-  g_time_start = g_time_stop = nullptr;
   hipExtLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, e0, e1, 0, L,
-                        reinterpret_cast<const float2 *>(coords_nhw2), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                        num_levels, HW1p, 1.0f / (float)w1);
+                        reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
+}
+
+int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coords_nhw2, void *corr, int n, int h1,
+                                    int w1, int h2, int w2, int num_levels, int radius, dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS)
+    return DBA_ERR_ARG;
+  if (radius != 3) return DBA_ERR_UNSUPPORTED;
+  if (n == 0) return DBA_OK;
+  if (!volumes || !coords_nhw2 || !corr) return DBA_ERR_ARG;
+  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
+  ShLevels L;
+  for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
+  return lookup_sheared_launch(L, coords_nhw2, corr, n, h1, w1, h2, w2, 0, num_levels, 0, stream);
+}
+
+int dba_corr_lookup_level_sheared(const void *sheared_level, const float *coords_n2hw_scaled, void *corr, int n, int h1,
+                                  int w1, int h2, int w2, int lvl, int radius, dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || lvl < 0 || lvl >= SH_MAX_LEVELS) return DBA_ERR_ARG;
+  if (radius != 3) return DBA_ERR_UNSUPPORTED;
+  if (n == 0) return DBA_OK;
+  if (!sheared_level || !coords_n2hw_scaled || !corr || (h2 >> lvl) < 1 || (w2 >> lvl) < 1) return DBA_ERR_ARG;
+  ShLevels L;
+  for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l == lvl) ? static_cast<const _Float16 *>(sheared_level) : nullptr;
+  return lookup_sheared_launch(L, coords_n2hw_scaled, corr, n, h1, w1, h2, w2, lvl, 1, 3, stream);
 }
 
 }  // extern "C"

@@ -53,6 +53,7 @@ SYMBOLS = {
     "dba_corr_lookup_arm_timing": (c_int, [_P, _P]),
     "dba_corr_shear_level": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_lookup_pyramid_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "dba_corr_lookup_level_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "dba_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_volume_scratch_bytes": (c_size_t, [c_int] * 6),
     "dba_corr_volume_build": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),

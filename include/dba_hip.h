@@ -228,6 +228,14 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes /* host array of 
                                     const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
                                     int w2, int num_levels, int radius, dba_stream_t stream);
 
+/* ONE level of the flow-aligned pyramid looked up with the arguments droid_backends.corr_index_forward receives from the
+ * reference's unmodified CorrBlock.__call__ (dbaf/modules/corr.py:40-50): coords [n, 2, h1, w1] ALREADY divided by 2^lvl,
+ * corr [n, 7, 7, h1, w1].  h2, w2 are the LEVEL-0 target map sizes (the level's planes are (h2 >> lvl) x (w2 >> lvl)).
+ * Bit-identical to dba_corr_index_forward on the reference-layout level; the adapter keeps a flow-aligned shadow of a
+ * reference-layout level it is asked about repeatedly and serves the lookups from it (droid_backends/__init__.py). */
+int dba_corr_lookup_level_sheared(const void *sheared_level, const float *coords_n2hw_scaled, void *corr, int n, int h1,
+                                  int w1, int h2, int w2, int lvl, int radius, dba_stream_t stream);
+
 /* corr_index_backward (src/correlation_kernels.cu:73-124,157-185): adjoint of the lookup;
  * volume_grad [n,h1,w1,h2,w2] must be zero-initialised by the caller. f32 only. */
 int dba_corr_index_backward(const float *coords, const float *corr_grad, float *volume_grad, int n,

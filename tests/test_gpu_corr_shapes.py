@@ -122,3 +122,51 @@ def test_lookups_at_config_shape(name, lookup_kernel):
         ref = orc.corr_lookup_pyramid(pyr, coords[e:e + 1], 3)
         assert np.array_equal(got[e:e + 1].view(np.uint16), ref.view(np.uint16)), (name, e, (got[e:e + 1] != ref).mean())
     assert np.isfinite(got.astype(np.float32)).all() and (got[0, :, 0, 2] == 0).all()
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_zero_edit_route_is_served_from_a_flow_aligned_shadow_bit_for_bit(name):
+    """The reference's own CorrBlock.__call__ (modules/corr.py:40-50: one corr_index_forward per level on the reference
+    layout, coords / 2^l, cat) against droid_backends with no import swapped: the first lookup of a level runs on the
+    reference layout, the second builds a flow-aligned shadow of the level and is served from it, later ones hit it -- all
+    bit-identical to the direct kernel; an in-place write or a new tensor drops the shadow."""
+    import droid_backends
+    from droid_backends import _SHADOWS
+    from dbaf_amd.corr import CorrBlock
+    W, fmaps, coords, _ = _setup(name)
+    f = torch.from_numpy(fmaps).cuda()
+    ii, jj = torch.from_numpy(W.ii).cuda(), torch.from_numpy(W.jj).cuda()
+    pyr = CorrBlock.build_pyramid(f[ii][None], f[jj][None], 4)          # reference layout [n, h1, w1, h2l, w2l]
+    c = torch.from_numpy(coords).cuda().permute(0, 3, 1, 2).contiguous()  # [n, 2, h, w]
+
+    def call():
+        return [droid_backends.corr_index_forward(pyr[l], c / 2 ** l, 3)[0] for l in range(4)]
+
+    assert _SHADOWS.enabled
+    _SHADOWS.enabled = False
+    try:
+        direct = call()
+    finally:
+        _SHADOWS.enabled = True
+    b0, h0 = _SHADOWS.builds, _SHADOWS.hits
+    first, second, third = call(), call(), call()
+    assert _SHADOWS.builds == b0 + 4 and _SHADOWS.hits == h0 + 4      # built at the second use, hit at the third
+    for l in range(4):
+        for got in (first[l], second[l], third[l]):
+            assert torch.equal(got.view(torch.int16), direct[l].view(torch.int16)), l
+    # an in-place write drops the shadow of that level (a stale one would return the old taps)
+    pyr[1][0, 0, 0].zero_()
+    _SHADOWS.enabled = False
+    try:
+        direct1 = droid_backends.corr_index_forward(pyr[1], c / 2, 3)[0]
+    finally:
+        _SHADOWS.enabled = True
+    again = [droid_backends.corr_index_forward(pyr[1], c / 2, 3)[0] for _ in range(3)]
+    for got in again:
+        assert torch.equal(got.view(torch.int16), direct1.view(torch.int16))
+    # a dead tensor takes its shadow with it
+    n_before = len(_SHADOWS.seen)
+    del pyr, first, second, third, again
+    import gc
+    gc.collect()
+    assert len(_SHADOWS.seen) <= n_before - 4
