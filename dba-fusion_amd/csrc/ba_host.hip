@@ -24,6 +24,8 @@ void set_last_error(const char *what, hipError_t e) {
 // many rows -- 64 KF / 512 edges: 47 us against 86 us for the (row, partner) grid --, the (row, partner) grid on sparse
 // windows, whose pairs are few and whose kernel is a chain of latencies either way (25 KF / 96 edges: 12.9 against 16.6 us).
 // DBA_SCHUR_KERNEL = rows | frame or dba_ba_schur_select() force one (the tests run both).
+// deterministic (fixed-point) accumulation of H, b: dba_ba_set_deterministic / DBA_DETERMINISTIC=1 (ba_kernels.hip: acc_add)
+static std::atomic<int> g_deterministic{[] { const char *e = getenv("DBA_DETERMINISTIC"); return (e && e[0] == '1') ? 1 : 0; }()};
 static std::atomic<int> g_schur_form{[] {
   const char *e = getenv("DBA_SCHUR_KERNEL");
   return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'f' || e[0] == 'g') ? 2 : 0);
@@ -232,6 +234,8 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
   if (plan.P <= 0) return DBA_OK;
   static const bool force_full = [] { const char *e = getenv("DBA_H_FULL"); return e && e[0] == '1'; }();
   if (force_full) lower = 0;
+  const bool fixed = g_deterministic.load(std::memory_order_relaxed) != 0;
+  if (fixed) lower |= 2;
   if (!motion_only) {  // Schur products and the pose-block assembly share one launch (both only add into H, b)
     // per-source-frame form (every row of E read once, Gram tiles on the matrix cores); DBA_SCHUR_KERNEL=rows keeps
     // the (row, partner) grid, which also takes graphs with more edges than the prepare kernel lists per frame
@@ -260,6 +264,12 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
                        N, t0, plan.P, lower, plan.T, plan.W);
     DBA_LAUNCH_CHECK();
   }
+  if (fixed) {  // the fixed-point sums back to float64 (one more launch: the price of the opt-in mode)
+    const int n = 6 * plan.P;
+    hipLaunchKernelGGL(ba_fixed_to_f64_kernel, dim3((n * n + n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.H,
+                       plan.W.b, n);
+    DBA_LAUNCH_CHECK();
+  }
   return DBA_OK;
 }
 
@@ -278,6 +288,11 @@ int dba_ba_schur_select(int form) {
   if (form < 0 || form > 2) return DBA_ERR_ARG;
   g_schur_form.store(form, std::memory_order_relaxed);
   g_schur_generation.fetch_add(1, std::memory_order_relaxed);
+  return DBA_OK;
+}
+
+int dba_ba_set_deterministic(int on) {
+  g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
   return DBA_OK;
 }
 

@@ -73,12 +73,14 @@ __global__ void ba_linearize_kernel(const float *poses, const float *disps, cons
                                     const float *eta, int eta_rows, const int64_t *jj,
                                     const uint8_t *frame_owned, int N, int HW, int wd, int t0, int P,
                                     float alpha, int upd, float *poses_out, float *disps_w, BaTables T, BaBuffers W);
-// lower != 0 (here and below): only the lower triangle of H is kept up (what the solvers read)
+// lower (here and below): bit 0 = only the lower triangle of H is kept up (what the solvers read), bit 1 = deterministic
+// accumulation (64-bit fixed point, see acc_add in ba_kernels.hip)
 __global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N,
                                    int t0, int P, int lower, BaTables T, BaBuffers W);
 __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                 int t0, int P, int lower, BaTables T, BaBuffers W);
 __global__ void ba_symmetrize_kernel(double *H, int n);
+__global__ void ba_fixed_to_f64_kernel(double *H, double *b, int n);
 constexpr int GRAM_LIST_CAP = 1024;  // rows of one frame the per-source-frame Schur kernel lists in LDS
 template <bool VEC>
 __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,

@@ -971,15 +971,30 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Deterministic accumulation (opt-in, dba_ba_set_deterministic): the reference adds the blocks of H, b on the host in a
+// fixed order (SparseBlock::update_lhs / update_rhs, droid_kernels.cu:1176-1218); here they arrive from thousands of
+// workgroups in whatever order the scheduler gives.  Float64 atomics make that order-dependent in the last bits (the Gram
+// tiles are sums of 48-bit products).  In this mode every addend is rounded ONCE to a multiple of 2^-30 and accumulated
+// with 64-bit INTEGER atomics in the same storage -- integer addition is associative, so H, b are identical bit for bit
+// whatever the order, the chunking or the number of ranks -- and converted back by ba_fixed_to_f64_kernel before the
+// solve.  Resolution 9.3e-10 absolute (entries of H are 1e2 .. 1e5), range +-8.6e9.
+constexpr double ACC_FIX_SCALE = 1073741824.0;  // 2^30
+__device__ __forceinline__ void acc_add(double *p, double v, bool fixed) {
+  if (fixed)
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double2ll_rn(v * ACC_FIX_SCALE));
+  else
+    atomic_add_f64(p, v);
+}
+
 // lower-triangle bookkeeping of H: position (hr, hc) and its mirror image both receive s in the full matrix; with
 // lower = true only the lower triangle is kept up (what the solvers read), the diagonal then receives both
-__device__ __forceinline__ void h_add_pair(const BaBuffers &W, int n6, int hr, int hc, double s, bool lower) {
+__device__ __forceinline__ void h_add_pair(const BaBuffers &W, int n6, int hr, int hc, double s, bool lower, bool fixed) {
   if (lower) {
-    if (hr == hc) atomic_add_f64(&W.H[(size_t)hr * n6 + hc], 2.0 * s);
-    else atomic_add_f64(&W.H[(size_t)max(hr, hc) * n6 + min(hr, hc)], s);
+    if (hr == hc) acc_add(&W.H[(size_t)hr * n6 + hc], 2.0 * s, fixed);
+    else acc_add(&W.H[(size_t)max(hr, hc) * n6 + min(hr, hc)], s, fixed);
   } else {
-    atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
-    atomic_add_f64(&W.H[(size_t)hc * n6 + hr], s);
+    acc_add(&W.H[(size_t)hr * n6 + hc], s, fixed);
+    acc_add(&W.H[(size_t)hc * n6 + hr], s, fixed);
   }
 }
 
@@ -990,7 +1005,8 @@ __device__ __forceinline__ void h_add_pair(const BaBuffers &W, int n6, int hr, i
 __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__restrict__ ii,
                                                   const int64_t *__restrict__ jj,
                                                   const uint8_t *__restrict__ frame_owned, int N, int t0, int P,
-                                                  bool lower, const BaTables &T, const BaBuffers &W) {
+                                                  int hflags, const BaTables &T, const BaBuffers &W) {
+  const bool lower = (hflags & 1) != 0, fixed = (hflags & 2) != 0;
   const int tid = threadIdx.x;
   const int n6 = 6 * P;
   const int edge_blocks = (N + 3) / 4;
@@ -1015,18 +1031,18 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
     const bool iv = (i >= 0 && i < P), jv = (j >= 0 && j < P);
     if (l < 36) {  // Hji[a][b] and its transpose Hij[b][a]
       const int a = l / 6, b = l % 6;
-      if (iv && jv) h_add_pair(W, n6, 6 * j + a, 6 * i + b, s, lower);
+      if (iv && jv) h_add_pair(W, n6, 6 * j + a, 6 * i + b, s, lower, fixed);
     } else if (l < 57) {  // Hjj
       int a = 0;
       const int t = l - 36;
       while ((a + 1) * (a + 2) / 2 <= t) a++;
       const int b = t - a * (a + 1) / 2;
       if (jv) {
-        atomic_add_f64(&W.H[(size_t)(6 * j + a) * n6 + 6 * j + b], s);
-        if (a != b && !lower) atomic_add_f64(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s);
+        acc_add(&W.H[(size_t)(6 * j + a) * n6 + 6 * j + b], s, fixed);
+        if (a != b && !lower) acc_add(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s, fixed);
       }
     } else {
-      if (jv) atomic_add_f64(&W.b[6 * j + (l - 57)], s);
+      if (jv) acc_add(&W.b[6 * j + (l - 57)], s, fixed);
     }
     return;
   }
@@ -1054,10 +1070,10 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= l) a++;
     const int b = l - a * (a + 1) / 2;
-    atomic_add_f64(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s);
-    if (a != b && !lower) atomic_add_f64(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s);
+    acc_add(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s, fixed);
+    if (a != b && !lower) acc_add(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s, fixed);
   } else {
-    atomic_add_f64(&W.b[6 * i + (l - 21)], s);
+    acc_add(&W.b[6 * i + (l - 21)], s, fixed);
   }
 }
 
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int64_t *__restr
                                                           const int64_t *__restrict__ jj,
                                                           const uint8_t *__restrict__ frame_owned, int N,
                                                           int t0, int P, int lower, BaTables T, BaBuffers W) {
-  ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
+  ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, lower, T, W);
 }
 
 // Schur complement (schur_block + EEt6x6_kernel + Ev6x1_kernel, :1046-1138, :1297-1391).
@@ -1083,7 +1099,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
   const int n6 = 6 * P;
   if ((int)blockIdx.x >= P + N) {
     if (blockIdx.y == 0 && blockIdx.z == 0)
-      ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
+      ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, lower, T, W);
     return;
   }
   // everything a row needs comes from its table row (one load): slot, target pose, partner range, source frame
@@ -1148,11 +1164,11 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
     if (tid < 36) {
       const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
       const int a = tid / 6, b = tid % 6;
-      if (!self) h_add_pair(W, n6, 6 * tgt1 + a, 6 * tgt2 + b, -s, lower != 0);
-      else if (!lower || a >= b) atomic_add_f64(&W.H[(size_t)(6 * tgt1 + a) * n6 + 6 * tgt2 + b], -s);
+      if (!self) h_add_pair(W, n6, 6 * tgt1 + a, 6 * tgt2 + b, -s, (lower & 1) != 0, (lower & 2) != 0);
+      else if (!(lower & 1) || a >= b) acc_add(&W.H[(size_t)(6 * tgt1 + a) * n6 + 6 * tgt2 + b], -s, (lower & 2) != 0);
     } else if (self && tid < 42) {
       const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
-      atomic_add_f64(&W.b[6 * tgt1 + (tid - 36)], -s);
+      acc_add(&W.b[6 * tgt1 + (tid - 36)], -s, (lower & 2) != 0);
     }
   }
 }
@@ -1295,7 +1311,7 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
 // frames with more rows than the tiles hold: one (a, b) pair of rows at a time over the chunk (the arithmetic of
 // ba_schur_kernel; such frames have 13 or more out-edges)
 __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const float *qm, const int *frow, int nrows, int c0,
-                                 int c1, int HW, int n6, bool lower, float *red) {
+                                 int c1, int HW, int n6, bool lower, bool fixed, float *red) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int a = 0; a < nrows; a++) {
     const float *E1 = W.E + (size_t)frow[2 * a] * 6 * HW;
@@ -1344,11 +1360,11 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
       if (tid < 36) {
         const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
         const int x = tid / 6, y = tid % 6;
-        if (!self) h_add_pair(W, n6, 6 * tgt1 + x, 6 * tgt2 + y, -s, lower);
-        else if (!lower || x >= y) atomic_add_f64(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s);
+        if (!self) h_add_pair(W, n6, 6 * tgt1 + x, 6 * tgt2 + y, -s, lower, fixed);
+        else if (!lower || x >= y) acc_add(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s, fixed);
       } else if (self && tid < 42) {
         const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
-        atomic_add_f64(&W.b[6 * tgt1 + (tid - 36)], -s);
+        acc_add(&W.b[6 * tgt1 + (tid - 36)], -s, fixed);
       }
     }
   }
@@ -1365,7 +1381,7 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
   const int tid = threadIdx.x, lane = tid & 63;
   const int frames_blocks = T.Mmax * nch;
   if ((int)blockIdx.x >= frames_blocks) {
-    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower != 0, T, W);
+    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower, T, W);
     return;
   }
   const int m = (int)blockIdx.x / nch, ch = (int)blockIdx.x - m * nch;
@@ -1381,7 +1397,7 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
   const int n6 = 6 * P;
   const int *frow = T.frow + 2 * fh.y;
   if (nrows > GRAM_MAX_ROWS) {
-    gram_frame_pairs(W, wm, qm, frow, nrows, c0, c1, HW, n6, lower != 0, reinterpret_cast<float *>(red));
+    gram_frame_pairs(W, wm, qm, frow, nrows, c0, c1, HW, n6, (lower & 1) != 0, (lower & 2) != 0, reinterpret_cast<float *>(red));
     return;
   }
   // lane a < nrows of every wave: row a of the frame's list (E row, pose)
@@ -1413,12 +1429,12 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
       const int a = (i - 1) / 6, ca = (i - 1) - 6 * a;
       const int hr = 6 * s_tgt[a] + ca;
       if (j == 0) {
-        atomic_add_f64(&W.b[hr], s);
+        acc_add(&W.b[hr], s, (lower & 2) != 0);
       } else {
         const int b = (j - 1) / 6, cb = (j - 1) - 6 * b;
         const int hc = 6 * s_tgt[b] + cb;
-        if (i == j) atomic_add_f64(&W.H[(size_t)hr * n6 + hc], s);
-        else h_add_pair(W, n6, hr, hc, s, lower != 0);
+        if (i == j) acc_add(&W.H[(size_t)hr * n6 + hc], s, (lower & 2) != 0);
+        else h_add_pair(W, n6, hr, hc, s, (lower & 1) != 0, (lower & 2) != 0);
       }
     }
     if (++tj > ti) ti++, tj = 0;
@@ -1428,6 +1444,15 @@ template __global__ void ba_schur_gram_kernel<true>(const int64_t *, const int64
                                                     int, BaTables, BaBuffers);
 template __global__ void ba_schur_gram_kernel<false>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int,
                                                      int, int, BaTables, BaBuffers);
+
+// deterministic mode: the 64-bit fixed-point sums of H (n x n) and b (n) back to float64, in place
+__global__ __launch_bounds__(256) void ba_fixed_to_f64_kernel(double *__restrict__ H, double *__restrict__ b, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  double *p = (idx < n * n) ? H + idx : ((idx < n * n + n) ? b + (idx - n * n) : nullptr);
+  if (!p) return;
+  const long long v = *reinterpret_cast<const long long *>(p);
+  *p = (double)v * (1.0 / ACC_FIX_SCALE);
+}
 
 // H <- its lower triangle mirrored (for the consumers of the full matrix: BACore.hessian, the stage API)
 __global__ __launch_bounds__(256) void ba_symmetrize_kernel(double *__restrict__ H, int n) {

@@ -32,6 +32,7 @@ SYMBOLS = {
     "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_ba_schur_select": (c_int, [c_int]),
     "dba_ba_schur_generation": (c_int, []),
+    "dba_ba_set_deterministic": (c_int, [c_int]),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
     "dba_ba_solve": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
     "dba_ba_update": (c_int, [_P] * 5 + [c_int] * 8 + [_P, _P, c_size_t, _P]),

@@ -100,6 +100,14 @@ int dba_ba_schur_select(int form);
 int dba_ba_schur_generation(void); /* number of dba_ba_schur_select calls so far: tables prepared under another generation
                                     * may lack what the form in force needs (callers of dba_ba_prepared compare it) */
 
+/* Deterministic accumulation of H, b (off by default; DBA_DETERMINISTIC=1 turns it on at load).  The reference adds the
+ * blocks of the camera system on the host in a fixed order (SparseBlock::update_lhs / update_rhs, droid_kernels.cu:1176-1218);
+ * this path adds them with float64 atomics from many workgroups, which is order-dependent in the last bits.  With the mode
+ * on every addend is rounded once to a multiple of 2^-30 and summed with 64-bit integer atomics (associative): H, b, and
+ * with them dx and the retracted state, are identical bit for bit from run to run and between a single GPU and any number
+ * of ranks.  Costs one small launch per Gauss-Newton iteration. */
+int dba_ba_set_deterministic(int on);
+
 /* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
  * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
  * first.  dba_ba_reduce and dba_bacore_hessian always produce the full matrix (mirrored from the lower triangle: symmetric

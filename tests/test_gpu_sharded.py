@@ -270,3 +270,63 @@ def test_sharded_paths_over_real_rccl(world, tmp_path):
     torch.cuda.synchronize()
     print(check_state(got["core_poses"], got["core_disps"], d["poses"].cpu().numpy(), d["disps"].cpu().numpy(), W.disps,
                       t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
+
+
+def test_deterministic_accumulation_gives_identical_bits_across_runs_forms_of_sharding():
+    """dba_ba_set_deterministic(1): H, b accumulate in 64-bit fixed point with integer atomics (associative), so the
+    reduced system -- and with it dx and the retracted state -- no longer depends on the order in which workgroups, pixel
+    chunks or ranks deliver their blocks (the reference adds them in a fixed order on the host,
+    droid_kernels.cu:1176-1218).  The 64-KF / 512-edge window: three single-GPU runs and an 8-way sharded run, all
+    bit-identical; the BACore system of the 25-KF window identical from run to run and within 1e-9 of the default mode."""
+    import droid_backends
+    from dbaf_amd import _lib
+    lib = _lib.load()
+    W = syn.window_64_512(2)
+    W25 = syn.window_25_96(3)
+    n25 = 6 * (W25.t1 - W25.t0)
+
+    def single(Wx):
+        d = to_dev(Wx)
+        droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"],
+                          d["ii"], d["jj"], Wx.t0, Wx.t1, 2, Wx.lm, Wx.ep, False)
+        torch.cuda.synchronize()
+        return d["poses"].cpu().numpy(), d["disps"].cpu().numpy()
+
+    def system(Wx, n):
+        d = to_dev(Wx)
+        core = droid_backends.BACore()
+        core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+                  d["jj"], Wx.t0, Wx.t1, 2, Wx.lm, Wx.ep, False)
+        H, v = torch.zeros(n, n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        core.hessian(H, v)
+        return H.numpy().copy(), v.numpy().copy()
+
+    H0, v0 = system(W25, n25)                 # default mode (float64 atomics)
+    assert lib.dba_ba_set_deterministic(1) == 0
+    try:
+        runs = [single(W) for _ in range(3)]
+        for p, z in runs[1:]:
+            assert np.array_equal(p, runs[0][0]) and np.array_equal(z, runs[0][1])
+
+        def body(rank, dist):
+            sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, 8, rank)
+            sel = sh.local_edges
+            dd = to_dev(W)
+            sh.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], _t(W.target[sel]), _t(W.weight[sel]),
+                  dd["eta"], _t(W.ii[sel]), _t(W.jj[sel]), 2, W.lm, W.ep, dist)
+            torch.cuda.synchronize()
+            return dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy()
+
+        results, _ = _run_ranks(8, body)
+        for p, z in results:   # every rank, bit for bit what one GPU computes
+            assert np.array_equal(p, runs[0][0]) and np.array_equal(z, runs[0][1])
+        sysd = [system(W25, n25) for _ in range(3)]
+        for H, v in sysd[1:]:
+            assert np.array_equal(H, sysd[0][0]) and np.array_equal(v, sysd[0][1])
+        scale = np.abs(H0).max()
+        assert np.abs(sysd[0][0] - H0).max() <= 1e-9 * scale and np.abs(sysd[0][1] - v0).max() <= 1e-9 * scale
+    finally:
+        lib.dba_ba_set_deterministic(0)
+    # ... and the mode changes nothing a parity test could see
+    p1, z1 = single(W)
+    print(check_state(runs[0][0], runs[0][1], p1, z1, W.disps, t_tol=1e-7, r_tol=1e-8, d_rtol=1e-6))
