@@ -31,12 +31,19 @@ static std::atomic<int> g_schur_form{[] {
   return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'f' || e[0] == 'g') ? 2 : 0);
 }()};  // 0 = automatic, 1 = (row, partner) grid, 2 = per-source-frame form; dba_ba_schur_select() changes it
 
+static bool schur_auto_frame_form(int N, int Mmax) {
+  const int rows_est = 1 + (Mmax > 0 ? (N + Mmax - 1) / Mmax : 0);
+  return rows_est > 6;
+}
+
+static thread_local int t_schur_form = 0;  // per-thread pin (dba_ba_schur_select_thread): the sharded driver's ranks
+
 bool ba_schur_frame_form(int N, int Mmax) {
   const int forced = g_schur_form.load(std::memory_order_relaxed);
   if (N + 1 > GRAM_LIST_CAP) return false;
   if (forced) return forced == 2;
-  const int rows_est = 1 + (Mmax > 0 ? (N + Mmax - 1) / Mmax : 0);
-  return rows_est > 6;
+  if (t_schur_form) return t_schur_form == 2;
+  return schur_auto_frame_form(N, Mmax);
 }
 
 int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan) {
@@ -290,6 +297,14 @@ int dba_ba_schur_select(int form) {
   g_schur_generation.fetch_add(1, std::memory_order_relaxed);
   return DBA_OK;
 }
+
+int dba_ba_schur_select_thread(int form) {
+  if (form < 0 || form > 2) return DBA_ERR_ARG;
+  t_schur_form = form;
+  return DBA_OK;
+}
+
+int dba_ba_schur_auto_form(int N, int M) { return schur_auto_frame_form(N, M) ? 2 : 1; }
 
 int dba_ba_set_deterministic(int on) {
   g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);

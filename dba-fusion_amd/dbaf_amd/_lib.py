@@ -31,6 +31,8 @@ SYMBOLS = {
     "dba_ba_linearize": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
     "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_ba_schur_select": (c_int, [c_int]),
+    "dba_ba_schur_select_thread": (c_int, [c_int]),
+    "dba_ba_schur_auto_form": (c_int, [c_int, c_int]),
     "dba_ba_schur_generation": (c_int, []),
     "dba_ba_set_deterministic": (c_int, [c_int]),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),

@@ -93,6 +93,7 @@ class ShardedWindow:
         self.kmax = max(1, max(len(r) for r in self.rows_of))
         self.fpose = window_fpose(self.ii_all, self.jj_all, self.t0, self.t1)
         self._dev = {}
+        self.schur_form = None   # Schur kernel form of the COMPLETE graph (HipStages asks the library once)
 
     def _on(self, device):
         key = str(device)
@@ -136,6 +137,8 @@ class ShardedWindow:
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         n6 = 6 * (self.t1 - self.t0)
+        if hasattr(stages, "select_schur_form"):   # the form the complete graph would get, on every rank
+            stages.select_schur_form(self, len(self.ii_all), len(self.kx_global))
         ctx = stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
                            self.t0, self.t1, alpha)
         if isinstance(ctx, dict):
@@ -197,6 +200,8 @@ class ShardedBACore:
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         self.poses, self.disps = poses, disps
+        if hasattr(self.stages, "select_schur_form"):
+            self.stages.select_schur_form(win, len(win.ii_all), len(win.kx_global))
         self.ctx = self.stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
                                      win.t0, win.t1, 0.001)
         n = 6 * (win.t1 - win.t0)
@@ -283,6 +288,15 @@ class HipStages:
 
     def __init__(self):
         self._cache = {}   # (dims, device) -> workspace, layout and views: one allocation per window shape, not per call
+
+    def select_schur_form(self, window, n_edges, n_frames):
+        """A rank's share of the graph has the complete graph's rows per frame (all out-edges of a frame live on its owner)
+        but few edges over all the window's frames, so the library's automatic choice would differ from a single GPU's:
+        ask it with the complete graph's numbers and pin that form (every rank of a job asks the same question)."""
+        lib = _lib.load()
+        if window.schur_form is None:
+            window.schur_form = int(lib.dba_ba_schur_auto_form(int(n_edges), int(n_frames)))
+        lib.dba_ba_schur_select_thread(window.schur_form)   # (a per-thread pin: cheap, and other callers keep their choice)
 
     def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
         lib = _lib.load()

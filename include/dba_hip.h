@@ -97,6 +97,11 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
  * the matrix cores, every row of E read once -- on windows whose frames couple many rows, the (row, partner) grid on
  * sparse ones), 1 = (row, partner) grid, 2 = per-source-frame form.  Initialised from DBA_SCHUR_KERNEL = rows | frame. */
 int dba_ba_schur_select(int form);
+int dba_ba_schur_select_thread(int form); /* the same choice for the calling host thread only (0 = none); the process-wide
+                                           * dba_ba_schur_select wins when both are set */
+int dba_ba_schur_auto_form(int N, int M); /* the form (1 or 2) the automatic choice gives a graph of N edges over M frames:
+                                           * the sharded driver asks with the COMPLETE graph's numbers and selects that form
+                                           * on every rank (a rank's share has the same rows per frame, but few edges) */
 int dba_ba_schur_generation(void); /* number of dba_ba_schur_select calls so far: tables prepared under another generation
                                     * may lack what the form in force needs (callers of dba_ba_prepared compare it) */
 
