@@ -251,10 +251,9 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
       hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
                          (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, lower, plan.T, plan.W);
     } else {
-      // pixel chunks per frame: ~1024 pixels per workgroup (256 per wave) on windows whose frames have many rows (the
-      // matrix-core time of a chunk grows with the square of the row count), ~512 on sparse ones (latency-bound)
-      const int rows_est = 1 + (plan.T.Mmax > 0 ? (N + plan.T.Mmax - 1) / plan.T.Mmax : 0);
-      const int px = (rows_est > 6) ? 1024 : 512;
+      // pixel chunks per frame: ~1024 pixels per workgroup (256 per wave).  A function of the map size alone: a rank of
+      // the sharded driver must cut a frame exactly as a single GPU does (same partial sums, bit for bit)
+      const int px = 1024;
       int nch = env_nch > 0 ? env_nch : (plan.HW + px - 1) / px;
       nch = std::max(1, std::min(nch, (plan.HW + 15) / 16));
       const dim3 grid((unsigned)(plan.T.Mmax * nch + ablocks));
