@@ -329,4 +329,4 @@ def test_deterministic_accumulation_gives_identical_bits_across_runs_forms_of_sh
         lib.dba_ba_set_deterministic(0)
     # ... and the mode changes nothing a parity test could see
     p1, z1 = single(W)
-    print(check_state(runs[0][0], runs[0][1], p1, z1, W.disps, t_tol=1e-7, r_tol=1e-8, d_rtol=1e-6))
+    print(check_state(runs[0][0], runs[0][1], p1, z1, W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
