@@ -8,7 +8,7 @@
 #   * kernel-trace stats of the on-the-fly correlation (scratch/altcorr_bench.py);
 #   * the HBM ceilings of the box (scratch/hbm_ceiling.py, scratch/bin/mem_pattern) next to them.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -16,6 +16,8 @@ cd $REPO
 bash tools/profile_round.sh $TAG 25_96 corr_lookup_sheared > $OUT/${TAG}_round_25_96.log 2>&1
 bash tools/profile_round.sh $TAG 64_512 corr_lookup_sheared > $OUT/${TAG}_round_64_512.log 2>&1
 bash tools/profile_round.sh $TAG 32_122 corr_lookup_resident > $OUT/${TAG}_round_32_122.log 2>&1
+bash tools/profile_round.sh $TAG 9_36_55x55 corr_lookup_resident > $OUT/${TAG}_round_9_36_55x55.log 2>&1
+bash tools/profile_round.sh $TAG 10_54_48x64 corr_lookup_sheared > $OUT/${TAG}_round_10_54_48x64.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 SQ=$OUT/${TAG}_sq
 rm -rf $SQ; mkdir -p $SQ
@@ -28,12 +30,17 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
   i=$((i+1))
   timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $SQ -o p$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $SQ/log$i.txt 2>&1
 done
+# the per-source-frame Schur kernel only runs on dense windows: its instruction / matrix-core counters from the 64-KF window
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $SQ -o p$i -- python $REPO/bench.py --window 64_512 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $SQ/log$i.txt 2>&1
+done
 # HBM write traffic of the build kernel (its own pass)
 timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SQ -o pw -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $SQ/logw.txt 2>&1
 python - > $OUT/${TAG}_sq_counters.txt <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
-names = ("corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur", "ba_solve_tile", "ba_solve_band", "ba_update")
+names = ("corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur_gram", "ba_schur_kernel", "ba_solve_tile", "ba_solve_band", "ba_update")
 for f in glob.glob("$SQ/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
@@ -49,7 +56,7 @@ timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
 cp $(ls -t $(find $OUT/${TAG}_alt_trace -name "*kernel_stats.csv") | head -1) $OUT/${TAG}_altcorr_kernel_stats.csv
 # ceilings
 python $REPO/scratch/hbm_ceiling.py > $OUT/${TAG}_hbm_ceiling.txt 2>&1
-[ -x $REPO/scratch/bin/mem_pattern ] && $REPO/scratch/bin/mem_pattern 96 > $OUT/${TAG}_mem_pattern_96.txt 2>&1 && $REPO/scratch/bin/mem_pattern 384 > $OUT/${TAG}_mem_pattern_384.txt 2>&1
+[ -x $REPO/scratch/bin/mem_pattern2 ] && $REPO/scratch/bin/mem_pattern2 96 > $OUT/${TAG}_mem_pattern2_96.txt 2>&1 && $REPO/scratch/bin/mem_pattern2 384 > $OUT/${TAG}_mem_pattern2_384.txt 2>&1
 # per-CU rates of the vector memory pipe and of LDS, dependent-chain latencies of the solver's f64 ops, solver stage times
 [ -x $REPO/scratch/bin/cu_rates ] && $REPO/scratch/bin/cu_rates > $OUT/${TAG}_cu_rates.txt 2>&1
 [ -x $REPO/scratch/bin/lds_rates ] && $REPO/scratch/bin/lds_rates > $OUT/${TAG}_lds_rates.txt 2>&1

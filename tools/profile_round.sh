@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>_*: the bench line, kernel-trace stats of the same command, and the PMC passes (separate
 # runs, --pmc never combined with sys/runtime traces) for the roofline kernel's HBM traffic and instruction mix.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WIN=${2:-25_96}
 KERN=${3:-corr_lookup_sheared}
 SFX=""; [ "$WIN" != "25_96" ] && SFX="_$WIN"
