@@ -257,12 +257,15 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
       int nch = env_nch > 0 ? env_nch : (plan.HW + px - 1) / px;
       nch = std::max(1, std::min(nch, (plan.HW + 15) / 16));
       const dim3 grid((unsigned)(plan.T.Mmax * nch + ablocks));
+      // eight waves per workgroup: two per SIMD, whose matrix products and operand loads interleave (with four, one per
+      // SIMD, a wave waited 2.5 us for every 1.6 us of products: 47 us at 64 KF / 512 edges)
+      static const int gram_threads = [] { const char *e = getenv("DBA_SCHUR_WAVES"); return (e && atoi(e) == 4) ? 256 : 512; }();
       if (plan.HW % 4 == 0)
-        hipLaunchKernelGGL((ba_schur_gram_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
-                           plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
+        hipLaunchKernelGGL((ba_schur_gram_kernel<true>), grid, dim3(gram_threads), 0, (hipStream_t)stream, ii, jj,
+                           frame_owned, N, plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
       else
-        hipLaunchKernelGGL((ba_schur_gram_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, ii, jj, frame_owned, N,
-                           plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
+        hipLaunchKernelGGL((ba_schur_gram_kernel<false>), grid, dim3(gram_threads), 0, (hipStream_t)stream, ii, jj,
+                           frame_owned, N, plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
     }
     DBA_LAUNCH_CHECK();
   } else if (ablocks > 0) {

@@ -1276,7 +1276,8 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
   for (int i = 0; i < NT; i++) acc[i] = gram_d4{0.0, 0.0, 0.0, 0.0};
 
   const int ngroups = (c1 - c0 + 15) / 16;
-  const int per = (ngroups + 3) / 4;  // a wave takes a contiguous run of groups: consecutive groups share 128-byte lines
+  const int nw = (int)(blockDim.x >> 6);  // 4 or 8 waves
+  const int per = (ngroups + nw - 1) / nw;  // a wave takes a contiguous run of groups: consecutive groups share 128-byte lines
   const int gbeg = wv * per, gend = min(ngroups, gbeg + per);
   GramStage<T> A[UNR], B[UNR];
 #pragma unroll
@@ -1293,8 +1294,8 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
     for (int u = 0; u < UNR; u++)
       if (g + UNR + u < gend) gram_mac<T>(B[u], acc);
   }
-  // the four waves' tiles, added in wave order (a sum that does not depend on which wave arrives first)
-  for (int w = 0; w < 4; w++) {
+  // the waves' tiles, added in wave order (a sum that does not depend on which wave arrives first)
+  for (int w = 0; w < nw; w++) {
     if (wv == w) {
 #pragma unroll
       for (int i = 0; i < NT; i++)
@@ -1325,7 +1326,7 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
       for (int c = 0; c < 36; c++) acc[c] = 0.f;
 #pragma unroll
       for (int c = 0; c < 6; c++) sv[c] = 0.f;
-      for (int k = c0 + tid; k < c1; k += 256) {
+      for (int k = c0 + tid; k < c1; k += (int)blockDim.x) {
         const float q = qm[k];
         float e1v[6], e2v[6];
 #pragma unroll
@@ -1357,13 +1358,16 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
         }
       }
       __syncthreads();
+      const int nw = (int)(blockDim.x >> 6);
       if (tid < 36) {
-        const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
+        double s = 0.0;
+        for (int w = 0; w < nw; w++) s += (double)red[w * 44 + tid];
         const int x = tid / 6, y = tid % 6;
         if (!self) h_add_pair(W, n6, 6 * tgt1 + x, 6 * tgt2 + y, -s, lower, fixed);
         else if (!lower || x >= y) acc_add(&W.H[(size_t)(6 * tgt1 + x) * n6 + 6 * tgt2 + y], -s, fixed);
       } else if (self && tid < 42) {
-        const double s = (double)red[tid] + (double)red[44 + tid] + (double)red[88 + tid] + (double)red[132 + tid];
+        double s = 0.0;
+        for (int w = 0; w < nw; w++) s += (double)red[w * 44 + tid];
         acc_add(&W.b[6 * tgt1 + (tid - 36)], -s, fixed);
       }
     }
@@ -1373,7 +1377,7 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
 // grid: [0, Mmax * nch) = (frame slot, pixel chunk); blocks after that do the pose-block assembly (as in ba_schur_kernel).
 // lower != 0: only the lower triangle of H is kept up (dba_ba: the solvers read nothing else).
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
+__global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
                                                                const uint8_t *__restrict__ frame_owned, int N, int HW,
                                                                int t0, int P, int nch, int lower, BaTables T, BaBuffers W) {
   __shared__ double red[GRAM_MAX_TILES * 256];
@@ -1381,7 +1385,7 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
   const int tid = threadIdx.x, lane = tid & 63;
   const int frames_blocks = T.Mmax * nch;
   if ((int)blockIdx.x >= frames_blocks) {
-    ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower, T, W);
+    if (tid < 256) ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower, T, W);
     return;
   }
   const int m = (int)blockIdx.x / nch, ch = (int)blockIdx.x - m * nch;
@@ -1420,9 +1424,14 @@ __global__ __launch_bounds__(256, 2) void ba_schur_gram_kernel(const int64_t *__
   // b = (j - 1) / 6 of the list: it belongs to both mirrored positions of H (the two orders of a pair; within a diagonal
   // block G[i][j] serves (i, j) and (j, i)); column 0 is the right-hand side.
   const int ntiles = Tn * (Tn + 1) / 2;
-  const int r = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int r = (tid >> 6) & 3, li = lane & 15, lk = lane >> 4;
+  const int tgroups = (int)(blockDim.x >> 8);   // 256 threads scatter one tile at a time
   int ti = 0, tj = 0;
   for (int idx = 0; idx < ntiles; idx++) {
+    if (idx % tgroups != (tid >> 8)) {
+      if (++tj > ti) ti++, tj = 0;
+      continue;
+    }
     const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
     if (i < R && j <= i && i >= 1) {
       const double s = -red[(idx * 4 + r) * 64 + lane];

@@ -25,7 +25,7 @@ def mfma_16x16x4(a_lanes, b_lanes, acc):
             acc[l, r] += D[(l >> 4) + 4 * r, l & 15]
 
 
-def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False):
+def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False, nw=8):
     """E [nrows_total, 6, HW], rows/tgts = the frame's list; returns the H, b contribution of the frame"""
     n6 = 6 * P
     H = np.zeros((n6, n6)); b = np.zeros(n6)
@@ -40,8 +40,8 @@ def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False):
             continue
         red = np.zeros((NT, 4, 64))
         ngroups = (c1 - c0 + 15) // 16
-        per = (ngroups + 3) // 4
-        for wv in range(4):
+        per = (ngroups + nw - 1) // nw
+        for wv in range(nw):
             acc = np.zeros((NT, 64, 4))
             for g in range(wv * per, min(ngroups, wv * per + per)):
                 # operand of lane (li, lk) for tile t, k-step s: value 16 t + li of pixel c0 + 16 g + 4 lk + s
@@ -121,5 +121,5 @@ def test_gram_scatter_matches_the_pairwise_definition(nrows, HW, nch, seed):
     Hd, bd = definition(E, Q, w, rows, tgts, P)
     assert np.allclose(H, Hd, rtol=0, atol=1e-9 * np.abs(Hd).max())
     assert np.allclose(b, bd, rtol=0, atol=1e-9 * np.abs(bd).max())
-    Hl, bl = gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=True)
+    Hl, bl = gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=True, nw=4)
     assert np.allclose(Hl, np.tril(Hd), rtol=0, atol=1e-9 * np.abs(Hd).max()) and np.allclose(bl, bd)
