@@ -1019,7 +1019,14 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
     const float *hp = W.HpartE + (size_t)n * W.nparts * HPE_STRIDE + l;
     double s = 0.0;
     int part = 0;
-    for (; part + 8 <= W.nparts; part += 8) {  // eight independent loads in flight
+    for (; part + 32 <= W.nparts; part += 32) {  // 32 independent loads in flight: the 64 partials of a 64x64 map are two
+      float v[32];                                // round trips to memory (with 8 in flight this block was the launch's tail)
+#pragma unroll
+      for (int q = 0; q < 32; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
+#pragma unroll
+      for (int q = 0; q < 32; q++) s += (double)v[q];
+    }
+    for (; part + 8 <= W.nparts; part += 8) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
@@ -1058,6 +1065,13 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
   const float *hp = W.HpartF + (size_t)m * W.nparts * HPF_STRIDE + l;
   double s = 0.0;
   int part = 0;
+  for (; part + 32 <= W.nparts; part += 32) {
+    float v[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) v[q] = hp[(size_t)(part + q) * HPF_STRIDE];
+#pragma unroll
+    for (int q = 0; q < 32; q++) s += (double)v[q];
+  }
   for (; part + 8 <= W.nparts; part += 8) {
     float v[8];
 #pragma unroll
