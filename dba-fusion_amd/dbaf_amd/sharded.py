@@ -338,6 +338,7 @@ class HipStages:
         if window.schur_form is None:
             window.schur_form = int(lib.dba_ba_schur_auto_form(int(n_edges), int(n_frames)))
         lib.dba_ba_schur_select_thread(window.schur_form)   # (a per-thread pin: cheap, and other callers keep their choice)
+        self._form_pin = window.schur_form
 
     def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
         lib = _lib.load()
@@ -364,8 +365,19 @@ class HipStages:
                    dsens=disps_sens, targets=targets, weights=weights, eta=eta.contiguous(), ii=ii, jj=jj,
                    owned=owned.contiguous(), alpha=float(alpha),
                    eta_rows=int(eta.reshape(-1, ht * wd).shape[0]))
-        _lib.check(lib.dba_ba_prepare(self._p(ii), self._p(jj), *dims, self._p(ctx["ws"]), ctx["nbytes"], self._s()),
-                   "dba_ba_prepare")
+        # stage 0 depends on (ii, jj, t0, t1, sizes, Schur form) alone: a window that calls ba() again with the very same edge
+        # tensors (same objects, same in-place version -- the workspace is this object's and holds that graph's tables)
+        # skips the launch, as droid_backends.ba does
+        import weakref
+        form = getattr(self, "_form_pin", None)
+        pk = base.get("prepared")
+        same = (pk is not None and pk[0]() is ii and pk[2]() is jj and pk[1] == ii._version and pk[3] == jj._version
+                and pk[4] == (lib.dba_ba_schur_generation(), form))
+        if not same:
+            _lib.check(lib.dba_ba_prepare(self._p(ii), self._p(jj), *dims, self._p(ctx["ws"]), ctx["nbytes"], self._s()),
+                       "dba_ba_prepare")
+            base["prepared"] = (weakref.ref(ii), ii._version, weakref.ref(jj), jj._version,
+                                (lib.dba_ba_schur_generation(), form))
         return ctx
 
     @staticmethod
