@@ -332,13 +332,13 @@ int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, si
 // graph_fpose: a caller-supplied pose-level skyline (device, P ints) for a system summed over ranks whose combined graph
 // the caller knows (the sharded driver); overrides the workspace's table.
 static int ba_solve_stage(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
-                          dba_stream_t stream, bool graph_skyline, const int *graph_fpose = nullptr) {
+                          dba_stream_t stream, bool graph_skyline, const int *graph_fpose = nullptr, int hint = 0) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int *fpose = graph_fpose ? graph_fpose : (graph_skyline ? plan.T.fpose : nullptr);
   return launch_ba_solve(plan.W.H, plan.W.b, fpose, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
-                         plan.W.Lscratch, (hipStream_t)stream);
+                         plan.W.Lscratch, (hipStream_t)stream, nullptr, hint);
 }
 
 int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
@@ -394,7 +394,7 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
                   const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
                   const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
                   float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
-                  dba_stream_t stream, int prepared) {
+                  dba_stream_t stream, int prepared, int solver_hint) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -419,7 +419,7 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
     if (pending) pose_src = pose_dst;
     rc = ba_reduce_stage(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
-    rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true);
+    rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true, nullptr, solver_hint);
     if (rc != DBA_OK) return rc;
     const bool last = (itr == iterations - 1);
     if (fuse && !last) {
@@ -442,16 +442,16 @@ int dba_ba(float *poses, float *disps, const float *intrinsics, const float *dis
            float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
            dba_stream_t stream) {
   return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
-                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 0);
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 0, 0);
 }
 
 int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
                     const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
                     const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
                     float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
-                    dba_stream_t stream) {
+                    dba_stream_t stream, int solver_hint) {
   return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
-                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 1);
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 1, solver_hint);
 }
 
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,

@@ -18,7 +18,7 @@ constexpr int SCHUR_CH = SCHUR_CH_CFG;     // pixel chunks of the Schur grid
 // device index tables (all int32, inside the workspace)
 struct BaTables {
   int *meta;        // [0] = |kx|, [1] = last solve failed, [2] = kx overflowed Mmax (cannot happen), [3] = solved by the
-                    // skyline kernel, [4..6] = its split, [8..15] = handshake flags of its two workgroups (16 ints)
+                    // skyline kernel, [4..6] = its split, [7] = which of its variants solved (1 / 2), [8..15] = handshake flags of its two workgroups (16 ints)
   int *kx;          // [Mmax]   frame id of slot m (sorted unique of arange(t0,t1) U ii)
   int *frame_slot;  // [B]      slot of frame f, -1 if absent
   int *eoff;        // [Mmax+1] CSR offsets of the out-edges of slot m
@@ -94,7 +94,7 @@ __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
 // damped float64 Cholesky solve of H x = b, one workgroup
 // fpose: optional [n/6] skyline of the system at pose granularity (see BaTables); null = measure it from H
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream, long long *prof = nullptr);
+                    double *Lscratch, hipStream_t stream, long long *prof = nullptr, int hint = 0);
 bool ba_solve_fits_lds(int n);
 bool ba_solve_tile_supported(int n);
 bool ba_solve_band_supported(int n);

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     T.meta[0] = min(M, T.Mmax);
     T.meta[1] = 0;
     T.meta[2] = (M > T.Mmax) ? 1 : 0;
+    T.meta[7] = 0;  // (which skyline-solver variant solved this graph: not known yet)
   }
   __syncthreads();
   auto slot_of = [&](int f) { return (f >= 0 && f < B && flag[f] > 0 && flag[f] <= T.Mmax) ? flag[f] - 1 : -1; };

@@ -296,8 +296,12 @@ bool ba_solve_fits_lds(int n) {
 
 size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 
+// hint 1: the one-tile skyline variant is known to take this graph's structure (it solved it in an earlier call on the
+// same edge list): the several-tiles-per-thread variant, which only exists for skylines the first one cannot hold, is not
+// queued (4.6 us per solve even when it returns at once); the general kernel stays behind as the net for a hand-shake that
+// times out
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream, long long *prof) {
+                    double *Lscratch, hipStream_t stream, long long *prof, int hint) {
   if (n <= 0) return DBA_OK;
   // n <= 174 (29 poses): the register-tile kernel (ba_solve_tile.hip).  Above that, up to n = 384, the skyline kernel
   // (ba_solve_band.hip) tries first; a system whose skyline does not fit one workgroup is left to this file's
@@ -320,7 +324,7 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     int rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, single ? nullptr : Lscratch,
                                   (Lscratch && !single) ? ba_solve_scratch_doubles(n) : 0, false, stream);
     if (rc != DBA_OK || single) return rc;
-    if (Lscratch && !ba_solve_fits_lds(n)) {  // wider skylines: several tiles per thread, panels in the global scratch
+    if (Lscratch && !ba_solve_fits_lds(n) && hint != 1) {  // wider skylines: several tiles per thread, panels in the global scratch
       rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, Lscratch, ba_solve_scratch_doubles(n), true, stream);
       if (rc != DBA_OK) return rc;
     }

@@ -680,6 +680,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     // solved here: the general kernel queued behind this one returns at once -- unless the partner workgroup never
     // delivered its verdict (its block of dx is then stale): the system is left to the kernel queued behind
     meta[3] = absent ? 0 : 1;
+    if (!absent) meta[7] = GP ? 2 : 1;  // which variant solved it (the adapter's per-graph solver plan, ba_host.hip)
   }
   BPROF(7);
 }

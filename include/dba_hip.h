@@ -169,7 +169,10 @@ int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const f
                     const float *targets, const float *weights, const float *eta, int eta_rows,
                     const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
                     int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
-                    void *ws, size_t ws_bytes, dba_stream_t stream);
+                    void *ws, size_t ws_bytes, dba_stream_t stream, int solver_hint);
+/* solver_hint: 0 = none; 1 = meta[7] (int32 at layout.meta + 28) read 1 after an earlier call on this graph, i.e. the
+ * one-tile skyline solver took its structure: the several-tiles variant behind it is then not queued (windows of 30-64
+ * poses; the decision depends on the graph alone, a failing pivot is not a reason to fall back). */
 
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
  * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */

@@ -396,6 +396,30 @@ def test_ba_prepared_workspace_is_reused_only_for_the_same_graph():
     assert not _BA_WS.prepared_for(key[0], ii, jj) and _BA_WS.prepared_for(key[0], dd["ii"], dd["jj"])
 
 
+def test_ba_solver_plan_of_a_64_pose_window_is_learnt_from_the_first_solve():
+    """30-64 poses: the adapter reads which skyline-solver variant took the graph (workspace meta[7]) at the second update on the
+    same edge tensors and stops queueing the several-tiles variant behind it; the results do not change"""
+    import droid_backends
+    from droid_backends import _BA_WS
+    W = syn.window_64_512(4)
+    saved = _BA_WS.enabled
+    _BA_WS.enabled = False
+    try:
+        ref = _run_gpu_ba(W)
+    finally:
+        _BA_WS.enabled = saved
+    d0 = to_dev(W)
+    ii, jj = d0["ii"], d0["jj"]
+    for rep in range(4):
+        d = to_dev(W)
+        droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], ii, jj,
+                          W.t0, W.t1, 2, W.lm, W.ep, False)
+        torch.cuda.synchronize()
+        assert np.array_equal(d["poses"].cpu().numpy(), ref[0]) and np.array_equal(d["disps"].cpu().numpy(), ref[1]), rep
+    key = [k for k in _BA_WS.graph if k[-1] == (W.N, W.B, W.h, W.w, W.t0, W.t1)]
+    assert key and _BA_WS.plan.get(key[0]) == 1     # the two-workgroup one-tile variant solved it
+
+
 def test_ba_general_size_solver_path_matches_too():
     """Window-sized systems take the register-tile LDL^T (csrc/ba_solve_tile.hip); the general-size blocked
     Cholesky (csrc/ba_solve.hip) stays reachable with DBA_SOLVE_GENERAL=1 and must pass the same parity cases."""
