@@ -70,6 +70,7 @@ class _BaWorkspaces:
         self.ws = {}        # (device, dims) -> (tensor, nbytes)
         self.graph = {}     # (device, dims) -> (ref(ii), version, ref(jj), version, schur form generation)
         self.plan = {}      # (device, dims) -> which skyline-solver variant solved this graph last time (meta[7])
+        self.kx_count = {}  # (device, dims) -> |kx| of the graph the workspace is prepared for
         self.max_entries = 4
 
     def workspace(self, key, dims, device):
@@ -80,6 +81,7 @@ class _BaWorkspaces:
                 self.ws.pop(old)
                 self.graph.pop(old, None)
                 self.plan.pop(old, None)
+                self.kx_count.pop(old, None)
             ent = _ws(*dims, device)
             self.ws[key] = ent
         return ent
@@ -119,6 +121,11 @@ def _num_kx(eta, ii, t0, t1, ht, wd):
     rows = eta.numel() // (ht * wd)
     if rows > 1:
         return rows
+    ts = torch.arange(t0, t1, device=ii.device, dtype=ii.dtype)
+    return int(torch.unique(torch.cat([ts, ii])).numel())
+
+
+def _num_kx_exact(ii, t0, t1):
     ts = torch.arange(t0, t1, device=ii.device, dtype=ii.dtype)
     return int(torch.unique(torch.cat([ts, ii])).numel())
 
@@ -177,6 +184,18 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
     Mmax = min(B, P + N)
     dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
+    if eta_rows > 1 and key is not None:
+        # eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): the reference raises on any
+        # other row count, the kernels would silently reuse the last row.  |kx| lives on the device; it is counted once per
+        # graph (a stream synchronisation whenever the edge list is new, which is also when the reference's own .item()
+        # calls synchronise) and remembered with the prepared tables.
+        nk = _BA_WS.kx_count.get(key) if prepared else None
+        if nk is None:
+            nk = _num_kx_exact(ii, t0, t1)
+            _BA_WS.kx_count[key] = nk
+        if eta_rows != nk:
+            raise RuntimeError("eta has %d rows; it must have 1 or |unique(arange(t0,t1) U ii)| = %d rows "
+                               "(droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C row by row)" % (eta_rows, nk))
     rc = fn(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
             _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1,
             int(iterations), float(lm), float(ep), int(bool(motion_only)), _ptr(dx),

@@ -305,6 +305,24 @@ def test_ba_eta_broadcast_row():
     check_state(poses, disps, r64["poses"], r64["disps"], W.disps)
 
 
+def test_ba_rejects_an_eta_with_the_wrong_number_of_rows():
+    """1 < rows != |kx|: the reference's eta.view(-1, HW) would fail to broadcast against C (:1476); the kernels would
+    silently reuse the last row -- the adapter counts |kx| once per graph and raises"""
+    import droid_backends
+    W = syn.window_tiny_b(85)
+    d = to_dev(W)
+    assert W.M > 2
+    for rows in (2, W.M - 1, W.M + 1):
+        eta = torch.full((rows, W.h, W.w), 3e-7, device="cuda")
+        with pytest.raises(RuntimeError):
+            droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], eta, d["ii"],
+                              d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    p0 = d["poses"].clone()
+    droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
+                      d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    assert not torch.equal(d["poses"], p0)
+
+
 def test_ba_rejects_cpu_and_noncontiguous():
     import droid_backends
     W = syn.window_tiny_a(71)
