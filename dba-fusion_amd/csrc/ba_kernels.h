@@ -81,7 +81,7 @@ __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint
                                 int t0, int P, int lower, BaTables T, BaBuffers W);
 __global__ void ba_symmetrize_kernel(double *H, int n);
 __global__ void ba_fixed_to_f64_kernel(double *H, double *b, int n);
-constexpr int GRAM_LIST_CAP = 1024;  // rows of one frame the per-source-frame Schur kernel lists in LDS
+constexpr int GRAM_LIST_CAP = 1024;  // edges (+ 1) up to which the prepare kernel builds the frame row table (one thread per edge)
 template <bool VEC>
 __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                      int t0, int P, int nch, int lower, BaTables T, BaBuffers W);

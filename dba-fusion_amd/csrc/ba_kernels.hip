@@ -10,12 +10,17 @@
 //     frame and walks that frame's out-edges, so the per-frame sums C = sum Cii, w = sum bz,
 //     Ei = sum Eii (the reference's three accum_cuda round trips) stay in registers and
 //     Eii is never materialised;
-//   * the 78+12 per-edge J^T W J sums are folded across the wave with DPP row-shift adds
-//     (no LDS, no barriers) and written as per-wave partials;
-//   * index sets (kx, per-frame edge lists) are built once per call on the device: no D2H;
-//   * the reduced camera system is accumulated in float64 with hardware f64 atomics (the reference
-//     sums the same f32 blocks in double on the host) and solved by a single-workgroup
-//     LDS-resident blocked Cholesky in float64.
+//   * the per-edge 12 x 13 block of J^T W [J r] sums runs on the matrix cores (f32 MFMA over the wave's 128
+//     residual rows; an LDS transpose-reduce for the variants with several pixels per lane) and leaves
+//     as per-wave partials; the edge's relative pose is formed in float64 by the lane that resolves it;
+//   * index sets (kx, per-frame edge lists, frame row tables, the pose-level skyline) are built once per
+//     GRAPH on the device: no D2H;
+//   * the Schur products are formed per SOURCE FRAME (every row of E read once, Gram tiles on the float64
+//     matrix cores) on dense windows, on a (row, partner) grid on sparse ones;
+//   * the reduced camera system is accumulated in float64 with hardware f64 atomics, lower triangle only
+//     (the reference sums the same f32 blocks in double on the host; an opt-in fixed-point mode makes the
+//     sums order-independent), and solved on the device (ba_solve*.hip);
+//   * back-substitution + retraction of an iteration ride in the next iteration's linearisation.
 #include "ba_kernels.h"
 
 #include <cstdio>
@@ -1203,7 +1208,9 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
 // reduced system loses nothing to the order of summation -- an f32 accumulation was measured 2.3 x further from the
 // float64 arbiter than the row-pair kernel's tree sums on the small fixtures).  A lane's operand for tile t is value
 // 16 t + (lane & 15) of pixel 4 (lane >> 4) + s of its 16-pixel group, i.e. one 16-byte load per tile and group serves
-// four k-steps.  The four waves' tiles meet in LDS in wave order; the lower triangle leaves as float64 atomics.
+// four k-steps.  The waves' tiles (8 waves; 4 measured equal) meet in LDS in wave order; the lower triangle leaves as
+// float64 atomics.  Bound by the float64 matrix-core time of the densest frames: a chunk of an 11-row frame is 15 tiles x
+// 1024 k-steps x 64 cycles = 25.6 us of its CU's four pipes (47 us per launch at 64 KF / 512 edges against 86 us).
 constexpr int GRAM_MAX_T = 5;                             // 16-value tiles of the stacked vector (15 tiles of G: 120
                                                           // accumulator registers)
 constexpr int GRAM_MAX_ROWS = (16 * GRAM_MAX_T - 1) / 6;  // 13 rows; frames with more take the row-pair path below
@@ -1269,7 +1276,7 @@ __device__ __forceinline__ void gram_mac(const GramStage<T> &S, gram_d4 (&acc)[T
   }
 }
 
-// the frame's Gram tiles over the pixels [c0, c1) -> red[tile][r][lane] (sum of the workgroup's four waves)
+// the frame's Gram tiles over the pixels [c0, c1) -> red[tile][r][lane] (sum of the workgroup's waves)
 template <int T, bool VEC>
 __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, const float *qm, int my_row, int nrows,
                                            int c0, int c1, int HW, double *red) {
