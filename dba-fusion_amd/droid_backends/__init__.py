@@ -184,7 +184,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
     Mmax = min(B, P + N)
     dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
-    if eta_rows > 1 and key is not None:
+    if eta_rows > 1:
         # eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): the reference raises on any
         # other row count, the kernels would silently reuse the last row.  |kx| lives on the device; it is counted once per
         # graph (a stream synchronisation whenever the edge list is new, which is also when the reference's own .item()
@@ -192,7 +192,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         nk = _BA_WS.kx_count.get(key) if prepared else None
         if nk is None:
             nk = _num_kx_exact(ii, t0, t1)
-            _BA_WS.kx_count[key] = nk
+            if key is not None:
+                _BA_WS.kx_count[key] = nk
         if eta_rows != nk:
             raise RuntimeError("eta has %d rows; it must have 1 or |unique(arange(t0,t1) U ii)| = %d rows "
                                "(droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C row by row)" % (eta_rows, nk))
