@@ -12,6 +12,10 @@
 
 #include <algorithm>
 
+#ifndef GRAM_F32_DEFAULT
+#define GRAM_F32_DEFAULT false   // per-frame Schur products: float64 matrix pipe unless DBA_SCHUR_MFMA=f32
+#endif
+
 namespace dba {
 
 static thread_local char g_last_error[512] = "";
@@ -260,12 +264,15 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
       // eight waves per workgroup: two per SIMD, whose matrix products and operand loads interleave (with four, one per
       // SIMD, a wave waited 2.5 us for every 1.6 us of products: 47 us at 64 KF / 512 edges)
       static const int gram_threads = [] { const char *e = getenv("DBA_SCHUR_WAVES"); return (e && atoi(e) == 4) ? 256 : 512; }();
-      if (plan.HW % 4 == 0)
-        hipLaunchKernelGGL((ba_schur_gram_kernel<true>), grid, dim3(gram_threads), 0, (hipStream_t)stream, ii, jj,
-                           frame_owned, N, plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
-      else
-        hipLaunchKernelGGL((ba_schur_gram_kernel<false>), grid, dim3(gram_threads), 0, (hipStream_t)stream, ii, jj,
-                           frame_owned, N, plan.HW, t0, plan.P, nch, lower, plan.T, plan.W);
+      // products on the float64 matrix pipe (exact) or as 16-term float chains flushed into float64 (the row-pair kernel's
+      // precision class, half the pipe time): DBA_SCHUR_MFMA=f64|f32
+      static const bool f32 = [] { const char *e = getenv("DBA_SCHUR_MFMA"); return e ? (e[0] == 'f' && e[1] == '3') : GRAM_F32_DEFAULT; }();
+#define GRAM_LAUNCH(V, F)                                                                                              \
+  hipLaunchKernelGGL((ba_schur_gram_kernel<V, F>), grid, dim3(gram_threads), 0, (hipStream_t)stream, ii, jj, frame_owned, \
+                     N, plan.HW, t0, plan.P, nch, lower, plan.T, plan.W)
+      if (plan.HW % 4 == 0) { if (f32) GRAM_LAUNCH(true, true); else GRAM_LAUNCH(true, false); }
+      else { if (f32) GRAM_LAUNCH(false, true); else GRAM_LAUNCH(false, false); }
+#undef GRAM_LAUNCH
     }
     DBA_LAUNCH_CHECK();
   } else if (ablocks > 0) {
@@ -292,6 +299,7 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
 }
 
 static std::atomic<int> g_schur_generation{0};
+
 
 int dba_ba_schur_select(int form) {
   if (form < 0 || form > 2) return DBA_ERR_ARG;

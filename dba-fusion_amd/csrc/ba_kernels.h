@@ -82,7 +82,7 @@ __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint
 __global__ void ba_symmetrize_kernel(double *H, int n);
 __global__ void ba_fixed_to_f64_kernel(double *H, double *b, int n);
 constexpr int GRAM_LIST_CAP = 1024;  // edges (+ 1) up to which the prepare kernel builds the frame row table (one thread per edge)
-template <bool VEC>
+template <bool VEC, bool F32>
 __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                      int t0, int P, int nch, int lower, BaTables T, BaBuffers W);
 __global__ void ba_update_kernel(float *poses, const float *poses_src, float *disps, const int64_t *jj, const uint8_t *frame_owned,

@@ -1276,8 +1276,31 @@ __device__ __forceinline__ void gram_mac(const GramStage<T> &S, gram_d4 (&acc)[T
   }
 }
 
+// The same products on the float matrix pipe, twice as fast: per 16-pixel group and tile a chain of four
+// v_mfma_f32_16x16x4_f32 (16 products of (q e_i) e_j, the (row, partner) kernel's arithmetic: operand rounded once, fmaf
+// chain) whose result is added to the float64 accumulators right away -- float chains of 16 terms, everything beyond in
+// double, i.e. the precision class of ba_schur_kernel (8-16-term chains + tree) at half the float64 instruction's pipe time.
+// The float instruction's result layout differs (row 4 (lane >> 4) + r instead of (lane >> 4) + 4 r): see the scatter.
+template <int T>
+__device__ __forceinline__ void gram_mac_f32(const GramStage<T> &S, gram_d4 (&acc)[T * (T + 1) / 2]) {
+#pragma unroll
+  for (int ti = 0; ti < T; ti++) {
+    float a[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) a[s] = S.e[ti][s] * S.q[s];
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++) {
+      lin_f4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; s++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], S.e[tj][s], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[ti * (ti + 1) / 2 + tj][r] += (double)c[r];
+    }
+  }
+}
+
 // the frame's Gram tiles over the pixels [c0, c1) -> red[tile][r][lane] (sum of the workgroup's waves)
-template <int T, bool VEC>
+template <int T, bool VEC, bool F32>
 __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, const float *qm, int my_row, int nrows,
                                            int c0, int c1, int HW, double *red) {
   constexpr int NT = T * (T + 1) / 2;
@@ -1309,12 +1332,18 @@ __device__ __forceinline__ void gram_frame(const BaBuffers &W, const float *wm, 
     for (int u = 0; u < UNR; u++) gram_load<T, VEC>(B[u], bp, qm, g + UNR + u, gend, c0, c1, lk);
 #pragma unroll
     for (int u = 0; u < UNR; u++)
-      if (g + u < gend) gram_mac<T>(A[u], acc);
+      if (g + u < gend) {
+        if constexpr (F32) gram_mac_f32<T>(A[u], acc);
+        else gram_mac<T>(A[u], acc);
+      }
 #pragma unroll
     for (int u = 0; u < UNR; u++) gram_load<T, VEC>(A[u], bp, qm, g + 2 * UNR + u, gend, c0, c1, lk);
 #pragma unroll
     for (int u = 0; u < UNR; u++)
-      if (g + UNR + u < gend) gram_mac<T>(B[u], acc);
+      if (g + UNR + u < gend) {
+        if constexpr (F32) gram_mac_f32<T>(B[u], acc);
+        else gram_mac<T>(B[u], acc);
+      }
   }
   // the waves' tiles, added in wave order (a sum that does not depend on which wave arrives first)
   for (int w = 0; w < nw; w++) {
@@ -1398,7 +1427,7 @@ __device__ void gram_frame_pairs(const BaBuffers &W, const float *wm, const floa
 
 // grid: [0, Mmax * nch) = (frame slot, pixel chunk); blocks after that do the pose-block assembly (as in ba_schur_kernel).
 // lower != 0: only the lower triangle of H is kept up (dba_ba: the solvers read nothing else).
-template <bool VEC>
+template <bool VEC, bool F32>
 __global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__restrict__ ii, const int64_t *__restrict__ jj,
                                                                const uint8_t *__restrict__ frame_owned, int N, int HW,
                                                                int t0, int P, int nch, int lower, BaTables T, BaBuffers W) {
@@ -1435,11 +1464,11 @@ __global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__
   if (tid < 64) s_tgt[lane] = my_tgt;
   const int R = 1 + 6 * nrows, Tn = (R + 15) / 16;
   switch (Tn) {
-    case 1: gram_frame<1, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
-    case 2: gram_frame<2, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
-    case 3: gram_frame<3, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
-    case 4: gram_frame<4, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
-    default: gram_frame<5, VEC>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 1: gram_frame<1, VEC, F32>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 2: gram_frame<2, VEC, F32>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 3: gram_frame<3, VEC, F32>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    case 4: gram_frame<4, VEC, F32>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
+    default: gram_frame<5, VEC, F32>(W, wm, qm, my_row, nrows, c0, c1, HW, red); break;
   }
   // scatter: tile (ti, tj <= ti), register r, lane l  <->  G[i][j], i = 16 ti + (l >> 4) + 4 r, j = 16 tj + (l & 15)
   // (the float64 instruction's result layout).  Entry (i, j), i >= j >= 1, is row a = (i - 1) / 6 against row
@@ -1454,7 +1483,7 @@ __global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__
       if (++tj > ti) ti++, tj = 0;
       continue;
     }
-    const int i = 16 * ti + lk + 4 * r, j = 16 * tj + li;
+    const int i = 16 * ti + (F32 ? 4 * lk + r : lk + 4 * r), j = 16 * tj + li;
     if (i < R && j <= i && i >= 1) {
       const double s = -red[(idx * 4 + r) * 64 + lane];
       const int a = (i - 1) / 6, ca = (i - 1) - 6 * a;
@@ -1471,10 +1500,14 @@ __global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__
     if (++tj > ti) ti++, tj = 0;
   }
 }
-template __global__ void ba_schur_gram_kernel<true>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int, int,
-                                                    int, BaTables, BaBuffers);
-template __global__ void ba_schur_gram_kernel<false>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int,
-                                                     int, int, BaTables, BaBuffers);
+#define GRAM_INST(V, F)                                                                                                  \
+  template __global__ void ba_schur_gram_kernel<V, F>(const int64_t *, const int64_t *, const uint8_t *, int, int, int, int, \
+                                                      int, int, BaTables, BaBuffers);
+GRAM_INST(true, true)
+GRAM_INST(true, false)
+GRAM_INST(false, true)
+GRAM_INST(false, false)
+#undef GRAM_INST
 
 // deterministic mode: the 64-bit fixed-point sums of H (n x n) and b (n) back to float64, in place
 __global__ __launch_bounds__(256) void ba_fixed_to_f64_kernel(double *__restrict__ H, double *__restrict__ b, int n) {
