@@ -13,7 +13,8 @@
 #include <algorithm>
 
 #ifndef GRAM_F32_DEFAULT
-#define GRAM_F32_DEFAULT false   // per-frame Schur products: float64 matrix pipe unless DBA_SCHUR_MFMA=f32
+#define GRAM_F32_DEFAULT true   // per-frame Schur products: 16-term float chains flushed into float64 (DBA_SCHUR_MFMA=f64:
+                                // every product on the float64 matrix pipe, 48 instead of 40 us at 64 KF / 512 edges)
 #endif
 
 namespace dba {

@@ -1203,14 +1203,16 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
 //     G = sum_k q_k x_k x_k^T          (column 0 of G holds the right-hand side terms),
 // a SYRK with K = HW.  ba_schur_kernel walks (row, partner) pairs and re-reads every row once per partner (5 x at 64 KF /
 // 512 edges, from L2 / the Infinity Cache: 86 us); here a workgroup owns (frame, pixel chunk), every wave streams its
-// share of the pixels ONCE and accumulates the lower triangle of G in 16 x 16 tiles on the matrix cores, in FLOAT64
-// (v_mfma_f64_16x16x4_f64: the products of two floats are exact in double and so, to all purposes, are the sums: the
-// reduced system loses nothing to the order of summation -- an f32 accumulation was measured 2.3 x further from the
+// share of the pixels ONCE and accumulates the lower triangle of G in 16 x 16 tiles on the matrix cores, into FLOAT64
+// accumulators: either every product on the float64 pipe (v_mfma_f64_16x16x4_f64: products of two floats are exact in
+// double) or -- the default, gram_mac_f32 -- as float chains of 16 products per tile and 16-pixel group that are added to
+// the float64 accumulators at once (a plain f32 accumulation over a wave's pixels was measured 2.3 x further from the
 // float64 arbiter than the row-pair kernel's tree sums on the small fixtures).  A lane's operand for tile t is value
 // 16 t + (lane & 15) of pixel 4 (lane >> 4) + s of its 16-pixel group, i.e. one 16-byte load per tile and group serves
 // four k-steps.  The waves' tiles (8 waves; 4 measured equal) meet in LDS in wave order; the lower triangle leaves as
-// float64 atomics.  Bound by the float64 matrix-core time of the densest frames: a chunk of an 11-row frame is 15 tiles x
-// 1024 k-steps x 64 cycles = 25.6 us of its CU's four pipes (47 us per launch at 64 KF / 512 edges against 86 us).
+// float64 atomics.  Bound by the matrix-core time of the densest frames: a chunk of an 11-row frame is 15 tiles x 1024
+// k-steps x 64 (float64) or 32 (float) cycles = 25.6 / 12.8 us of its CU's four pipes: 48 / 40 us per launch at 64 KF /
+// 512 edges against 86 us for the (row, partner) grid.
 constexpr int GRAM_MAX_T = 5;                             // 16-value tiles of the stacked vector (15 tiles of G: 120
                                                           // accumulator registers)
 constexpr int GRAM_MAX_ROWS = (16 * GRAM_MAX_T - 1) / 6;  // 13 rows; frames with more take the row-pair path below
