@@ -11,10 +11,18 @@ import numpy as np
 import pytest
 
 
+F32_LAYOUT = False   # result rows of the float instruction: 4 (l >> 4) + r; of the float64 one: (l >> 4) + 4 r
+
+
+def _row(l, r):
+    return 4 * (l >> 4) + r if F32_LAYOUT else (l >> 4) + 4 * r
+
+
 def mfma_16x16x4(a_lanes, b_lanes, acc):
     """D = A B + C with the gfx950 operand layout: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
-    register r of lane l holds D[(l >> 4) + 4 r][l & 15] (the FLOAT64 instruction's result layout, the one
-    ba_solve_kernel's trailing update relies on; the f32 instruction has rows 4 (l >> 4) + r)."""
+    register r of lane l holds D[(l >> 4) + 4 r][l & 15] for the FLOAT64 instruction (the layout ba_solve_kernel's
+    trailing update relies on) and D[4 (l >> 4) + r][l & 15] for the float one (ba_linearize_kernel's): the kernel has
+    both forms (gram_mac / gram_mac_f32) and scatters accordingly."""
     A = np.zeros((16, 4)); B = np.zeros((4, 16))
     for l in range(64):
         A[l & 15, l >> 4] = a_lanes[l]
@@ -22,7 +30,7 @@ def mfma_16x16x4(a_lanes, b_lanes, acc):
     D = A @ B
     for l in range(64):
         for r in range(4):
-            acc[l, r] += D[(l >> 4) + 4 * r, l & 15]
+            acc[l, r] += D[_row(l, r), l & 15]
 
 
 def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False, nw=8):
@@ -71,7 +79,7 @@ def gram_kernel_model(E, Q, w, rows, tgts, P, HW, nch, lower=False, nw=8):
         for idx in range(NT):
             for r in range(4):
                 for l in range(64):
-                    i, j = 16 * ti + (l >> 4) + 4 * r, 16 * tj + (l & 15)
+                    i, j = 16 * ti + _row(l, r), 16 * tj + (l & 15)
                     if i < R and j <= i and i >= 1:
                         s = -red[idx, r, l]
                         a, ca = (i - 1) // 6, (i - 1) % 6
@@ -108,7 +116,10 @@ def definition(E, Q, w, rows, tgts, P):
 
 @pytest.mark.parametrize("nrows,HW,nch,seed", [(1, 64, 1, 0), (2, 100, 2, 1), (5, 144, 2, 2), (6, 121, 3, 3), (11, 80, 1, 4),
                                                (15, 48, 2, 5), (3, 37, 4, 6)])
-def test_gram_scatter_matches_the_pairwise_definition(nrows, HW, nch, seed):
+@pytest.mark.parametrize("f32_layout", [False, True])
+def test_gram_scatter_matches_the_pairwise_definition(nrows, HW, nch, seed, f32_layout):
+    global F32_LAYOUT
+    F32_LAYOUT = f32_layout
     rng = np.random.default_rng(seed)
     P = 7
     total = nrows + 3
