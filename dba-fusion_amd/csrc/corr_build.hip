@@ -28,22 +28,50 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 // [n][C][HW] -> [n][C/kb][HW][kb] (kb = 16 everywhere today; blocks of 8 for the target map, so that a half wave's
 // fragment loads are 512 contiguous bytes, were measured and change nothing), value / 4 rounded to half
-// (corr.py:67-68); C is a multiple of 16
+// (corr.py:67-68); C is a multiple of 16.  Reads as 16-byte pieces along the pixels, writes as 16-byte pieces along the
+// channels (round 3; 2-byte accesses before: 23.4 us per 32-edge map, two launches).
 __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
                                                                _Float16 *__restrict__ out, int C, int HW, int kb) {
-  __shared__ _Float16 tile[64][66];
+  __shared__ _Float16 tile[64][72];   // [channel][pixel]; pitch 144 B: the 8 lanes of a channel row write 16 B each
   const int e = blockIdx.z;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const _Float16 *src = in + (size_t)e * C * HW;
   _Float16 *dst = out + (size_t)e * HW * C;
-  for (int r = threadIdx.x >> 6; r < 64; r += 4) {  // r: channel within tile, lane: pixel
-    const int c = c0 + r, p = p0 + (threadIdx.x & 63);
-    tile[r][threadIdx.x & 63] = (c < C && p < HW) ? (_Float16)((float)src[(size_t)c * HW + p] / 4.0f) : (_Float16)0;
+  const int t = threadIdx.x;
+  const bool vec_in = ((HW & 7) == 0) && (p0 + 64 <= HW);
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {  // 32 channel rows per pass: lane -> (row, 8-pixel piece)
+    const int r = pass * 32 + (t >> 3), piece = t & 7;
+    const int c = c0 + r, p = p0 + 8 * piece;
+    half8 v;
+    if (c < C && vec_in) {
+      v = *reinterpret_cast<const half8 *>(src + (size_t)c * HW + p);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = (c < C && p + k < HW) ? src[(size_t)c * HW + p + k] : (_Float16)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) tile[r][8 * piece + k] = (_Float16)((float)v[k] / 4.0f);
   }
   __syncthreads();
-  for (int r = threadIdx.x >> 6; r < 64; r += 4) {  // r: pixel within tile, lane: channel
-    const int p = p0 + r, c = c0 + (threadIdx.x & 63);
-    if (p < HW && c < C) dst[((size_t)(c / kb) * HW + p) * kb + (c % kb)] = tile[threadIdx.x & 63][r];
+  // lane -> (pixel, 8 consecutive channels): kb = 16 keeps the two halves of a pixel's 16-channel block adjacent
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int idx = pass * 256 + t;        // 64 pixels x 8 channel octets
+    const int pl = idx >> 3, oct = idx & 7;
+    const int p = p0 + pl, c = c0 + 8 * oct;
+    if (p < HW && c < C) {
+      half8 v;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = tile[8 * oct + k][pl];
+      if ((kb & 7) == 0 && c + 8 <= C) {
+        *reinterpret_cast<half8 *>(dst + ((size_t)(c / kb) * HW + p) * kb + (c % kb)) = v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (c + k < C) dst[((size_t)((c + k) / kb) * HW + p) * kb + ((c + k) % kb)] = v[k];
+      }
+    }
   }
 }
 
