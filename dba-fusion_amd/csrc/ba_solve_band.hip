@@ -710,7 +710,10 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
     attr_once.done();
   }
   if (!big) {
-    // two workgroups: the second one only works when the band lets the system be split (decided on the device)
+    // two workgroups: the second one only works when the band lets the system be split (decided on the device).
+    // The hand-shake flags carry a per-LAUNCH generation number that is a kernel argument: a launch captured into a
+    // hipGraph would replay with the same number and take the previous replay's flags for this one's -- the two-workgroup
+    // form must not be graph-captured (capture with DBA_SOLVE_SPLIT=0, which keeps one workgroup and no flags).
     static std::atomic<unsigned> generation{1};
     const unsigned gen = generation.fetch_add(1) | 0x40000000u;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
