@@ -279,7 +279,11 @@ def main():
             torch.cuda.synchronize()
             t1 = (time.perf_counter() - t1) / n1
             extras["edges_per_s_1gpu_same_family"] = round(W1.N / t1, 1)
+            extras["value_1gpu_same_family"] = round((1.0 / t1) * (W1.N / 96.0), 3)   # this line's `value` at N = 1
             extras["edge_throughput_vs_1gpu"] = round((N * args.steps / dt) / (W1.N / t1), 3)
+            extras["scaling_note"] = ("weak-scaling efficiency = value / (n_gpus * extra.value_1gpu_same_family): the N = 1 "
+                                      "member of this family (64 KF / 64 edges), measured by rank 0 in the untimed region; the "
+                                      "default N = 1 line is the 25-KF / 96-edge headline window, a different (cheaper) window")
             del cb1
         dist.barrier()
 
