@@ -16,8 +16,8 @@
 //   * accumulators -> f16 (the single rounding of the reference's half GEMM) -> LDS tile T[source][ty][tx];
 //   * stores: every element goes from the tile to Vs_l[(ty_l - (y1 >> l)) mod h2l][dx][pixel] with PER-PIXEL offsets, so
 //     any map width works (a strip may span a row end).  Levels 0 and 1 (94 % of the bytes): a lane owns four
-//     consecutive pixels of one of four (dy, dx) lines and stores 8 bytes (four 2-byte stores for a quad that spans a row
-//     end); levels 2, 3: a lane is one pixel.  The barriers synchronise LDS only (`s_waitcnt lgkmcnt(0); s_barrier`): a
+//     consecutive pixels of one of four (dy, dx) lines and stores 8 bytes (a quad that spans a row end is stored by the
+//     whole wave, 2 bytes per lane, sixteen offsets per instruction); levels 2, 3: a lane is one pixel.  The barriers synchronise LDS only (`s_waitcnt lgkmcnt(0); s_barrier`): a
 //     `__syncthreads()` would drain every outstanding store first;
 //   * levels 1..3: 2x2 averages of the ROUNDED level below (== F.avg_pool2d on half, floor sizes): each thread pools one
 //     8 x 8 block of the tile down to its 4 x 4 + 2 x 2 + 1 values in registers, which then take the dead tile's place in
@@ -309,41 +309,23 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   // an 8-byte one (~13 cycles per wave instruction: 10 B/clk/CU, which capped the store phases), so there a lane owns
   // FOUR consecutive pixels (q = lane & 15) of one of four lines (g = lane >> 4) and stores 8 bytes: one instruction is
   // four full 128-byte lines.  A quad whose pixels do not share a source row (a strip that spans a row end, or the last
-  // pixels of the map) falls back to four 2-byte stores.
+  // pixels of the map) is not stored by its lanes but by the whole wave afterwards (`irregular`).
   const int q4 = (lane & 15) * 4, g = lane >> 4;
   int qx[4], qy[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) pixel_xy(p0 + q4 + i, qx[i], qy[i]);
   const bool quad_regular = (p0 + q4 + 3 < HW1) && (qy[0] == qy[3]);
-  const _Float16 *quad = T + q4 * PITCH;
-  auto store_quad = [&](const __amdgpu_buffer_rsrc_t &rl, int lvl, int tyg, int dx, int h2l, int w2l, _Float16 v0, _Float16 v1,
-                        _Float16 v2, _Float16 v3, bool on) {
-    const _Float16 vv[4] = {v0, v1, v2, v3};
-    if (quad_regular) {
-      int dy = tyg - (qy[0] >> lvl);
-      dy += (dy < 0) ? h2l : 0;
-      const unsigned voff = on ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + q4) : OOR;
-      typedef unsigned u2v __attribute__((ext_vector_type(2)));
-      u2v d;
-      d.x = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
-      d.y = (unsigned)__builtin_bit_cast(unsigned short, v2) | ((unsigned)__builtin_bit_cast(unsigned short, v3) << 16);
-      __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        int dy = tyg - (qy[i] >> lvl);
-        dy += (dy < 0) ? h2l : 0;
-        const bool ok = on && (p0 + q4 + i < HW1);
-        const unsigned voff = ok ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + q4 + i) : OOR;
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, vv[i]), rl, voff, 0, 0);
-      }
-    }
-  };
-
+  // Quads that are not regular are rare (one per row end inside the strip, one at the end of the map) but their four
+  // pixels sit on four different lines: the WHOLE wave takes them, lane = (pixel lane & 3 of the quad, offset lane >> 2),
+  // sixteen offsets per 2-byte store instruction -- w2 / 16 instructions per such quad.  (Left to the quad's own four
+  // lanes, as until round 3, they cost 4 x w2 / 4 instructions issued by a wave with 4 of 64 lanes alive: strips with a
+  // row end took 2.5-3x as long, which is most of what 28x107 and 55x55 lost against 64x64.)
+  const unsigned long long irregular = __ballot(!quad_regular && g == 0 && (p0 + q4 < HW1));  // bit = quad index (wave-uniform)
+  const int ipx = lane & 3, idx16 = lane >> 2;
   // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's own target row.  A lane's
   // quad of pixels reads the tile along a diagonal (pixel + 1, column + 1); with columns 0..3 replicated behind the row
   // only the first column wraps, once per line, and the store offset just advances by four planes: ~10 VALU
-  // instructions per 8-byte store where the general form (kept for quads that span a row end) needs ~70 ----
+  // instructions per 8-byte store where the general form needs ~70 ----
   {
     const int ty = ty0 + wave;
 #ifdef FB_ABLATE_L0STORE
@@ -380,19 +362,23 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           }
         }
       }
-      if (!quad_regular) {
-        const _Float16 *row = quad + wave * RP;
-        for (int dx0 = 0; dx0 < w2; dx0 += 4) {
-          const int dx = dx0 + g;
-          _Float16 v[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            int tx = qx[i] + dx;
-            tx -= (tx >= w2) ? w2 : 0;
-            tx = min(tx, w2 - 1);  // (dx beyond the map in the last group of four: read something valid, store nothing)
-            v[i] = row[i * PITCH + tx];
-          }
-          store_quad(r0, 0, ty, dx, h2, w2, v[0], v[1], v[2], v[3], dx < w2);
+      for (unsigned long long m = irregular; m; m &= m - 1) {
+        const int pl = 4 * (int)__builtin_ctzll(m) + ipx;  // this lane's pixel of the quad, within the strip
+        int xi, yi;
+        pixel_xy(p0 + pl, xi, yi);
+        const bool pok = p0 + pl < HW1;
+        int dy = ty - yi;
+        dy += (dy < 0) ? h2 : 0;
+        const _Float16 *row = T + pl * PITCH + wave * RP;
+        const unsigned vbase = (unsigned)dy * (unsigned)w2 * plane_bytes + 2u * (unsigned)(p0 + pl);
+        for (int dx0 = 0; dx0 < w2; dx0 += 16) {
+          const int dx = dx0 + idx16;
+          int tx = xi + dx;
+          tx -= (tx >= w2) ? w2 : 0;
+          tx = min(tx, w2 - 1);  // (dx beyond the map in the last group: read something valid, store nothing)
+          const _Float16 v = row[tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r0,
+                                                (pok && dx < w2) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, 0);
         }
       }
     }
@@ -495,18 +481,23 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           t -= (t >= w2l) ? w2l : 0;
         }
       }
-      if (!quad_regular) {
-        for (int dx0 = 4 * (wave >> 2); dx0 < w2l; dx0 += 8) {
-          const int dx = dx0 + g;
-          _Float16 v[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            int tx = (qx[i] >> 1) + dx;
-            tx -= (tx >= w2l) ? w2l : 0;
-            tx = min(tx, w2l - 1);
-            v[i] = P1[((q4 + i) * 4 + tyl) * RP1 + tx];
-          }
-          store_quad(rl, 1, tyg, dx, h2l, w2l, v[0], v[1], v[2], v[3], dx < w2l);
+      for (unsigned long long m = irregular; m; m &= m - 1) {  // (the two waves of a row take alternate groups of 16 offsets)
+        const int pl = 4 * (int)__builtin_ctzll(m) + ipx;
+        int xi, yi;
+        pixel_xy(p0 + pl, xi, yi);
+        const bool pok = p0 + pl < HW1;
+        int dy = tyg - (yi >> 1);
+        dy += (dy < 0) ? h2l : 0;
+        const _Float16 *row = P1 + (pl * 4 + tyl) * RP1;
+        const unsigned vbase = (unsigned)dy * (unsigned)w2l * plane_bytes + 2u * (unsigned)(p0 + pl);
+        for (int dx0 = 16 * (wave >> 2); dx0 < w2l; dx0 += 32) {
+          const int dx = dx0 + idx16;
+          int tx = (xi >> 1) + dx;
+          tx -= (tx >= w2l) ? w2l : 0;
+          tx = min(tx, w2l - 1);
+          const _Float16 v = row[tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
+                                                (pok && dx < w2l) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, 0);
         }
       }
     }
