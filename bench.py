@@ -411,9 +411,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
-            "config": {"workload": "synthetic TUM-VI-shape 512x512 -> %dx%d maps, %d-KF window, %d edges, "
+            "config": {"workload": "synthetic %s -> %dx%d maps, %d-KF window, %d edges, "
                                    "reproject + 4-level r=3 lookup + ba(itrs=2) per step; lookups rotate over %d disjoint "
-                                   "pyramid copies (MALL-cold)" % (h, w, W.num_kf, N, ncopies),
+                                   "pyramid copies (MALL-cold)" % (
+                                       {(64, 64): "TUM-VI-shape 512x512", (28, 107): "KITTI-360-shape 224x856",
+                                        (55, 55): "TUM-VI demo 440x440", (48, 64): "384x512 (WHU / TartanAir)"}.get(
+                                           (h, w), "%dx%d frames" % (8 * h, 8 * w)), h, w, W.num_kf, N, ncopies),
                        "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
                        "scaling_mode": scaling,
                        "exchange": ("gloo (host-staged)" if args.backend == "gloo" and world > 1 else
