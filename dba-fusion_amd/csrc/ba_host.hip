@@ -390,8 +390,8 @@ int dba_ba_shard_front(const float *poses, const float *disps, const float *intr
 
 int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
                       int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps,
-                      const int32_t *window_fpose, void *ws, size_t ws_bytes, dba_stream_t stream) {
-  const int rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false, window_fpose);
+                      const int32_t *window_fpose, int solver_hint, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  const int rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false, window_fpose, solver_hint);
   if (rc != DBA_OK) return rc;
   return dba_ba_update(poses, disps, ii, jj, frame_owned, N, B, ht, wd, t0, t1, 1, update_disps, nullptr, ws, ws_bytes,
                        stream);

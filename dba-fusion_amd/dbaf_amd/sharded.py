@@ -94,6 +94,7 @@ class ShardedWindow:
         self.fpose = window_fpose(self.ii_all, self.jj_all, self.t0, self.t1)
         self._dev = {}
         self.schur_form = None   # Schur kernel form of the COMPLETE graph (HipStages asks the library once)
+        self._solver_plan = None  # which skyline-solver variant solved the summed system in the first call (HipStages)
 
     def _on(self, device):
         key = str(device)
@@ -185,6 +186,7 @@ class ShardedWindow:
                            self.t0, self.t1, alpha)
         if isinstance(ctx, dict):
             ctx["fpose"] = d["fpose"]      # the complete graph's skyline for the solver (the summed system has it)
+            ctx["solver_hint"] = 1 if self._solver_plan == 1 else 0
         inplace = getattr(stages, "system_view", None)
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
@@ -207,6 +209,10 @@ class ShardedWindow:
             self.merge_disps(disps, dist)
         if hasattr(dist, "check"):   # the peer-read exchange reports a missing peer through a status word: surface it
             dist.check()
+        # 30-64 poses: the summed system goes to the skyline solver, whose fall-back variants are queued behind it until it
+        # is known that the first one takes this window's structure (one stream synchronisation, after the first call)
+        if self._solver_plan is None and 174 < n6 <= 384 and hasattr(stages, "solver_plan") and int(iterations) > 0:
+            self._solver_plan = stages.solver_plan(ctx)
         assert hb.numel() >= n6 * n6 + n6
         return stages.finish(ctx)
 
@@ -399,8 +405,17 @@ class HipStages:
         p = self._p
         _lib.check(c["lib"].dba_ba_shard_back(p(c["poses"]), p(c["disps"]), p(c["ii"]), p(c["jj"]), p(c["owned"]),
                                               *c["dims"], float(lm), float(ep), int(bool(update_disps)),
-                                              p(c.get("fpose")), p(c["ws"]), c["nbytes"], self._s()),
+                                              p(c.get("fpose")), int(c.get("solver_hint", 0)), p(c["ws"]), c["nbytes"],
+                                              self._s()),
                    "dba_ba_shard_back")
+
+    def solver_plan(self, c):
+        """which skyline-solver variant took the summed system (meta[7] of the workspace; synchronises the stream: the
+        window asks once, after its first call) -> 1: the one-tile-per-thread variant, the fall-back behind it need not be
+        queued"""
+        lay = _lib.BaLayout()
+        c["lib"].dba_ba_get_layout(*c["dims"], ctypes.byref(lay))
+        return int(c["ws"][lay.meta + 28:lay.meta + 32].view(torch.int32).item())
 
     def system_view(self, c):
         return c["hb"] if "hb" in c else None

@@ -145,11 +145,13 @@ int dba_ba_shard_front(const float *poses, const float *disps, const float *intr
                        float alpha, int motion_only, void *ws, size_t ws_bytes, dba_stream_t stream);
 int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned,
                       int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, int update_disps,
-                      const int32_t *window_fpose, void *ws, size_t ws_bytes, dba_stream_t stream);
+                      const int32_t *window_fpose, int solver_hint, void *ws, size_t ws_bytes, dba_stream_t stream);
 /* window_fpose (device, t1 - t0 ints, or NULL): for every pose of the window the first pose it is coupled to in the
  * COMPLETE graph (all ranks' edges: through an edge, or through a common source frame), which lets the solver take the
  * skyline of the summed system from the graph instead of measuring it (dbaf_amd/sharded.py computes it on the host;
- * a table that names a later pose than the true one gives a wrong solve, NULL is always safe). */
+ * a table that names a later pose than the true one gives a wrong solve, NULL is always safe).
+ * solver_hint: as for dba_ba_prepared (0 = none; 1 = meta[7] read 1 after an earlier solve of this window's summed system:
+ * the several-tiles-per-thread skyline variant need not be queued behind the first one). */
 
 /* droid_backends.ba: `iterations` x (stage 1..4), all enqueued on `stream` with no host sync.
  * dx_out [P,6] and dz_out [>=|kx|, ht*wd] receive the last iteration's update (either may be NULL). */

@@ -133,6 +133,31 @@ def test_sharded_hip_ba_matches_single_gpu_ba(mk, world):
     print(check_state(results[0][0], results[0][1], ref_poses, ref_disps, W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
 
 
+def test_sharded_window_learns_the_solver_plan_and_the_hinted_call_gives_the_same_state():
+    """63 poses: the summed system goes to the skyline solver with its fall-back variants queued behind it; after its first
+    call the window knows which variant took the system (meta[7]) and the next calls queue one launch less per solve
+    (dba_ba_shard_back's solver_hint) -- same state"""
+    W = syn.window_64_512(3)
+    world = 2
+
+    def body(rank, dist):
+        sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+        sel = sh.local_edges
+        tg, wt, ii, jj = _t(W.target[sel]), _t(W.weight[sel]), _t(W.ii[sel]), _t(W.jj[sel])
+        out = []
+        for rep in range(2):
+            dd = to_dev(W)
+            sh.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], tg, wt, dd["eta"], ii, jj, 2, W.lm, W.ep, dist)
+            torch.cuda.synchronize()
+            out.append((dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy(), sh._solver_plan))
+        return out
+
+    results, _ = _run_ranks(world, body)
+    for out in results:
+        assert out[0][2] == 1 and out[1][2] == 1, (out[0][2], out[1][2])   # the one-tile-per-thread variant, on two workgroups
+        print(check_state(out[1][0], out[1][1], out[0][0], out[0][1], W.disps, t_tol=2e-6, r_tol=2e-7, d_rtol=2e-5))
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_bacore_matches_single_gpu_bacore(world):
     """fusion path (BASELINE configs[4], depth_video.py:469-559) on a WHU-shaped window with depth measurements: two
