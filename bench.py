@@ -397,7 +397,7 @@ def main():
         achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
         gn_bytes = N * HW * 16 + W.M * HW * 16  # SURVEY 8(d) B_gn: target, weight + disps r/w, eta, disps_sens
         out = {
-            "metric": ("DBA iterations/sec (%d-KF, %d-edge, 512x512) [dba_update/s]" % (W.num_kf, N) if scaling != "weak" else
+            "metric": ("DBA iterations/sec (%d-KF, %d-edge, %dx%d) [dba_update/s]" % (W.num_kf, N, 8 * w, 8 * h) if scaling != "weak" else
                        "DBA iterations/sec, edge-normalised (%d-KF, %d-edge window; x edges/96) [dba_update/s per 96 edges]"
                        % (W.num_kf, N)),
             "value": round(value, 3),

@@ -99,7 +99,8 @@ bool ba_solve_fits_lds(int n);
 bool ba_solve_tile_supported(int n);
 bool ba_solve_band_supported(int n);
 int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
-                         int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream);
+                         int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream,
+                         bool last = false);  // last: nothing is queued behind this launch (a hand-shake that times out fails the solve)
 int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                          hipStream_t stream);
 size_t ba_solve_scratch_doubles(int n);

@@ -297,9 +297,10 @@ bool ba_solve_fits_lds(int n) {
 size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 
 // hint 1: the one-tile skyline variant is known to take this graph's structure (it solved it in an earlier call on the
-// same edge list): the several-tiles-per-thread variant, which only exists for skylines the first one cannot hold, is not
-// queued (4.6 us per solve even when it returns at once); the general kernel stays behind as the net for a hand-shake that
-// times out
+// same edge list, and whether it fits depends on the skyline alone): neither the several-tiles-per-thread variant, which only
+// exists for skylines the first one cannot hold, nor the general kernel is queued behind it (4.6-4.8 us each per solve even
+// when they return at once).  The one thing they were still a net for -- a partner workgroup that does not show up within
+// a second -- then fails the solve (zero update, meta[1] = 1) instead of leaving it to the queue
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof, int hint) {
   if (n <= 0) return DBA_OK;
@@ -321,9 +322,10 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     // n <= 174 (only reached with DBA_SOLVE_KERNEL=band): one workgroup, which cannot bail out -- with the scratch the
     // kernel would run on two workgroups, whose hand-shake can give the system up, and nothing is queued behind it here
     const bool single = ba_solve_tile_supported(n);
+    const bool last = (hint == 1) && fpose != nullptr && !single;
     int rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, single ? nullptr : Lscratch,
-                                  (Lscratch && !single) ? ba_solve_scratch_doubles(n) : 0, false, stream);
-    if (rc != DBA_OK || single) return rc;
+                                  (Lscratch && !single) ? ba_solve_scratch_doubles(n) : 0, false, stream, last);
+    if (rc != DBA_OK || single || last) return rc;
     if (Lscratch && !ba_solve_fits_lds(n) && hint != 1) {  // wider skylines: several tiles per thread, panels in the global scratch
       rc = launch_ba_solve_band(H, b, fpose, n, lm, ep, dx, meta, Lscratch, ba_solve_scratch_doubles(n), true, stream);
       if (rc != DBA_OK) return rc;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
                                                                 const int *__restrict__ fpose, int ng,
                                                                 double lm, double ep, float *__restrict__ dx,
                                                                 int *__restrict__ meta, double *__restrict__ G,
-                                                                int gcap, unsigned gen
+                                                                int gcap, unsigned gen, int nofb
 #ifdef PROFILE_SOLVE
                                                                    , long long *__restrict__ prof
 #endif
@@ -331,8 +331,12 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   for (int e = tid; e < NTILES; e += nt) tinfo[e] = 0;
   __syncthreads();
   if (flags[2]) {  // skyline too large for one workgroup: the general kernel takes the system
+    if (nofb) {  // (cannot happen when the caller's hint is true; should it, the update is zero rather than stale)
+      for (int j = tid; j < ng; j += nt) dx[j] = 0.f;
+    }
     if (tid == 0) {
-      meta[3] = 0;
+      meta[3] = nofb ? 1 : 0;
+      if (nofb) meta[1] = 1;
       if (split) {  // the partner learns it at the exchange and leaves as well
         xflag[2 + role] = 2;
         __threadfence();
@@ -471,7 +475,21 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         __syncthreads();
         const int st = flags[12];
         if (st == 2) {  // partner unsupported / absent: nothing has been written yet, the queue behind takes over
-          if (tid == 0) meta[3] = 0;
+          if (nofb) {
+            // nothing is queued behind (the caller knows this structure fits, so the partner is merely late by > 1 s): the
+            // solve fails as a whole -- zero update, like a non-SPD system (:1263-1266) --, and the partner, should it
+            // still arrive, finds this workgroup's contribution, completes, and learns the verdict at the second handshake
+            for (int j = tid; j < ng; j += nt) dx[j] = 0.f;
+            if (tid == 0) {
+              xflag[6 + role] = 1;
+              __threadfence();
+              __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+              meta[1] = 1;
+              meta[3] = 1;
+            }
+          } else if (tid == 0) {
+            meta[3] = 0;
+          }
           __builtin_amdgcn_endpgm();
         }
         if (st == 1 && tid == 0) *fail = 1;
@@ -656,7 +674,8 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
       other = 2;  // (2 = the partner never reported: its block of dx is unknown)
-      while (wall_clock64() - t0 < 100000000ll) {
+      // (it has passed the exchange, so it is resident and running; with nothing queued behind, the wait is 30x longer)
+      while (wall_clock64() - t0 < (nofb ? 3000000000ll : 100000000ll)) {
         if (__hip_atomic_load(xflag + 4 + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gen) {
           other = __hip_atomic_load(xflag + 6 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
@@ -665,7 +684,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       }
     }
     other = __builtin_amdgcn_readfirstlane(other);
-    absent = (other == 2);
+    absent = (other == 2) && !nofb;  // (nofb: a partner that is still missing counts as a failed solve)
     failed |= (other != 0);
   }
 #pragma unroll
@@ -698,7 +717,7 @@ extern long long *g_band_prof;
 // `scratch` (scratch_doubles >= the packed lower triangle).  Either variant leaves meta[3] = 0 when the skyline
 // does not fit it.
 int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx,
-                         int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream) {
+                         int *meta, double *scratch, size_t scratch_doubles, bool big, hipStream_t stream, bool last) {
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_band_kernel<BD_THREADS, 1, false>),
@@ -720,7 +739,7 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
     static const bool one_wg = [] { const char *e = getenv("DBA_SOLVE_SPLIT"); return e && e[0] == '0'; }();
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3((scratch && !one_wg) ? 2 : 1), dim3(BD_THREADS),
                        SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, scratch ? gcap : 0,
-                       gen BD_PROF_ARG);
+                       gen, last ? 1 : 0 BD_PROF_ARG);
   } else {
     if (!scratch) return DBA_ERR_WORKSPACE;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
@@ -729,11 +748,11 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
     // first one left: it is no longer queued (4.6 us per solve even when it returns at once), only kept for
     // DBA_SOLVE_BAND_BIG=512
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 2, true>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
-                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
+                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u, 0 BD_PROF_ARG);
     static const bool also512 = [] { const char *e = getenv("DBA_SOLVE_BAND_BIG"); return e && e[0] == '5'; }();
     if (also512)
       hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
-                         SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u BD_PROF_ARG);
+                         SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u, 0 BD_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

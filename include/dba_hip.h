@@ -173,8 +173,10 @@ int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const f
                     int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
                     void *ws, size_t ws_bytes, dba_stream_t stream, int solver_hint);
 /* solver_hint: 0 = none; 1 = meta[7] (int32 at layout.meta + 28) read 1 after an earlier call on this graph, i.e. the
- * one-tile skyline solver took its structure: the several-tiles variant behind it is then not queued (windows of 30-64
- * poses; the decision depends on the graph alone, a failing pivot is not a reason to fall back). */
+ * one-tile skyline solver took its structure: the fall-back kernels behind it are then not queued (windows of 30-64
+ * poses; whether it fits depends on the graph alone, a failing pivot is not a reason to fall back.  The only other thing
+ * the queue was a net for, a partner workgroup more than a second late at the hand-shake, then gives a failed solve, i.e. a
+ * zero update, instead of a slower correct one). */
 
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
  * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */
