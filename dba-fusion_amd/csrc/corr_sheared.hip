@@ -394,14 +394,8 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
           if (masked) v &= keep[t * 64];
           *reinterpret_cast<u4v *>(&stage[ldsoff[t]]) = v;  // rows / pieces nobody needs arrive as zeros
         }
-#if defined(SH_PRIO) && (SH_PRIO & 1)   // experiment builds (scratch/): the memory-issuing part of a step at a raised wave priority
-        __builtin_amdgcn_s_setprio(2);
-#endif
 #ifndef SH_ABLATE_LOADS
         request(jy + SH_DEPTH, dnext, regs[r]);
-#endif
-#if defined(SH_PRIO) && (SH_PRIO & 1)
-        __builtin_amdgcn_s_setprio(0);
 #endif
         dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
         // LDS operations of one wave execute in program order: no wait between the row's writes and the tap reads
@@ -411,9 +405,6 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
           const int j = jy - ry;
           const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
           const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
-#if defined(SH_PRIO) && (SH_PRIO & 2)   // ... or the blend + stores
-          __builtin_amdgcn_s_setprio(2);
-#endif
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             h2v acc = prev.e[k] * W00;
@@ -432,9 +423,6 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
               __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, SH_STORE_AUX);
 #endif
           }
-#if defined(SH_PRIO) && (SH_PRIO & 2)
-          __builtin_amdgcn_s_setprio(0);
-#endif
         }
         __builtin_amdgcn_wave_barrier();
       };
