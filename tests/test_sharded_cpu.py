@@ -214,3 +214,62 @@ def test_window_fpose_is_the_first_coupled_pose_of_the_complete_graph():
         want = np.array([int(np.nonzero(coupled[a])[0].min()) for a in range(P)], np.int32)
         got = window_fpose(ii, jj, t0, t1)
         assert np.array_equal(got, want), (trial, got, want)
+
+
+def test_band_index_covers_the_reduced_system_of_the_complete_graph_and_the_exchange_only_moves_it():
+    """The band-only exchange (ShardedWindow.exchange_system on 32 poses and more) sums the entries inside the pose-level
+    skyline of the lower triangle plus b, and nothing else: (i) every entry the reduced system of the COMPLETE graph can
+    have (pose blocks of an edge, Schur fill between the targets of a common source frame) lies inside the index set,
+    (ii) an exchange over a fake two-rank `dist` leaves the entries outside untouched and sums the ones inside."""
+    import torch
+    from dbaf_amd.sharded import ShardedWindow
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        KF = int(rng.integers(34, 48))
+        ii, jj = syn.graph_banded(KF, int(rng.integers(1, 4)), extra=[(0, 5), (7, 2)])
+        t0, t1, B = 1, KF, KF + 1
+        P, n6 = t1 - t0, 6 * (t1 - t0)
+        sh = ShardedWindow(ii, jj, t0, t1, B, 2, 0)
+        pad = 3
+        hb_len = n6 * n6 + pad + n6
+        idx = sh.band_index(torch.device("cpu"), hb_len).numpy()
+        inside = np.zeros(hb_len, bool)
+        inside[idx] = True
+        assert inside[hb_len - n6:].all() and not inside[n6 * n6:hb_len - n6].any()      # all of b, none of the padding
+        # (i) structure of the complete graph's reduced system, lower triangle
+        need = np.zeros((P, P), bool)
+        for f in np.unique(ii):
+            S = set(int(g) - t0 for g in jj[ii == f] if t0 <= g < t1)
+            if t0 <= f < t1:
+                S.add(int(f) - t0)
+            for a in S:
+                for b in S:
+                    need[max(a, b), min(a, b)] = True
+        Hin = inside[:n6 * n6].reshape(n6, n6)
+        for a in range(P):
+            for b in range(a + 1):
+                if need[a, b]:
+                    blk = Hin[6 * a:6 * a + 6, 6 * b:6 * b + 6]
+                    assert (blk[np.tril_indices(6)] if a == b else blk).all(), (trial, a, b)
+        assert not np.triu(Hin, 1).any()                                                  # nothing above the diagonal
+        assert idx.size < 0.5 * n6 * n6                                                   # it IS a band
+
+        # (ii) the exchange
+        class TwoRanks:
+            def __init__(self, other):
+                self.other = other
+
+            def all_reduce(self, t):
+                t += self.other
+
+        mine = torch.from_numpy(rng.standard_normal(hb_len))
+        theirs = torch.from_numpy(rng.standard_normal(hb_len))
+        before = mine.clone()
+        os.environ["DBA_BAND_EXCHANGE"] = "1"
+        try:
+            sh.exchange_system(mine, TwoRanks(theirs.take(torch.from_numpy(idx))))
+        finally:
+            del os.environ["DBA_BAND_EXCHANGE"]
+        want = before.clone()
+        want[torch.from_numpy(idx)] += theirs[torch.from_numpy(idx)]
+        assert torch.equal(mine, want)
