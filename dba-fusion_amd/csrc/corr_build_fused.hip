@@ -595,11 +595,9 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
     const char *e = getenv("DBA_BUILD_KERNEL");
     return !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'l' ? 2 : 0));
   }();
-  // the strip walk pays off where every quad of pixels is regular (rows of the source map a multiple of 4 wide and the
-  // map a whole number of strips: 64x64, 48x64); elsewhere (55x55) the two-workgroups-per-CU form hides the irregular
-  // quads' extra latency better
-  const bool loop_shape = (w1 % 4 == 0) && ((h1 * w1) % 64 == 0);
-  if (w2 <= 64 && C == 128 && force != 1 && (loop_shape || force == 2)) {
+  // the strip walk for every map up to 64 wide at C = 128 (since the row-end quads are stored by the whole wave it also
+  // wins where strips span row ends: 55x55 13.3 against 14.3 us/edge)
+  if (w2 <= 64 && C == 128 && force != 1) {
     // strips per workgroup: as many as leave >= ~512 workgroups (two rounds of the 256 CUs), at most 16
     const int nstrips = HW1p / 64;
     const long long rows = (long long)grid.y * n;
@@ -621,7 +619,7 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
   }
   DBA_LAUNCH_CHECK();
 #ifdef FB_PROF
-  if (w2 <= 64 && C == 128 && force != 1 && (loop_shape || force == 2)) {
+  if (w2 <= 64 && C == 128 && force != 1) {
     (void)hipStreamSynchronize(s);
     const int nstrips = HW1p / 64;
     const size_t nw = (size_t)((nstrips + 15) / 1) * grid.y * n * 8;  // upper bound of wave slots

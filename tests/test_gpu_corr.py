@@ -120,13 +120,14 @@ def test_lookup_non_finite_coords_do_not_fault(layout, lookup_kernel):
 
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64), (3, 32, 24, 64), (1, 16, 8, 64), (2, 128, 28, 107), (1, 32, 55, 55),
                                    (1, 16, 48, 64), (1, 16, 18, 71), (2, 16, 20, 44), (1, 16, 9, 128), (1, 16, 16, 16),
-                                   (2, 16, 8, 8), (1, 16, 9, 10), (1, 32, 11, 13), (1, 16, 8, 65), (1, 16, 33, 36)])
+                                   (2, 16, 8, 8), (1, 16, 9, 10), (1, 32, 11, 13), (1, 16, 8, 65), (1, 16, 33, 36),
+                                   (1, 128, 55, 55), (2, 128, 18, 44), (3, 128, 9, 10), (1, 128, 11, 13), (5, 128, 8, 8)])
 def test_fused_sheared_build_equals_unfused_pipeline(shape):
     """one-pass MFMA build (GEMM + pooling + shear) == GEMM kernel + 3 pooling passes + shear passes, bit for bit, for
     64-wide maps, maps whose strips span row ends (107, 55, 71, 44 wide), heights that are not multiples of 8 (28,
     55, 18, 20, 9: partial target tiles and the floor sizes of avg_pool2d), the widest supported map (128), the
-    smallest ones (8 x 8, 9 x 10, 11 x 13: the store loops' column counters wrap more than once per line there) and
-    widths just past a tile size (65, 36)"""
+    smallest ones (8 x 8, 9 x 10, 11 x 13: the store loops' column counters wrap more than once per line there),
+    widths just past a tile size (65, 36), and C = 128 on irregular maps (the strip-walking form with row-end quads)"""
     from dbaf_amd.corr import CorrBlock
     n, C, h, w = shape
     rng = np.random.default_rng(12)
