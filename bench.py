@@ -3,8 +3,9 @@
 
 A "step" is one `dba_update` = the in-scope part of one CovisibleGraph.update()
 (/root/reference/dbaf/covisible_graph.py:214-342) on one synthetic keyframe window:
-    reproject(N edges) -> 4-level correlation lookup(N edges) -> ba(iterations=2) -> clamp
-(every step works on a pristine copy of the window's poses and inverse depths out of a pool filled before the loop)
+    state reset -> [reprojection + 4-level correlation lookup](N edges, ONE launch) -> ba(iterations=2) -> clamp
+(the BA mutates its inputs, so every step first re-initialises the window's poses and inverse depths from a device copy,
+inside the timed region: SURVEY 8(d); `extra.step_pooled_state_us` is the step without that copy)
 The ConvGRU between lookup and BA is out of scope.
 N=1 workload = BASELINE.json configs[1] shape: 25 KF / 96 edges / 512x512 frames (64x64 maps).
 
@@ -47,8 +48,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r03_pmc_lookup%s.json")   # % "" for the default window, "_<window>" otherwise
-LOOKUP_SOURCES = ("dba-fusion_amd/csrc/corr_sheared.hip",)
+PMC_FILE = os.path.join("profiles", "r04_pmc_lookup%s.json")   # % "" for the default window, "_<window>" otherwise
+LOOKUP_SOURCES = ("dba-fusion_amd/csrc/corr_sheared.hip", "dba-fusion_amd/csrc/reproj.h")
 
 
 def lookup_algorithmic_bytes(n_edges, hw, levels=4, radius=3, elt=2):
@@ -88,6 +89,8 @@ def main():
                          "9_36_55x55 = configs[0]'s TUM-VI demo resolution, 10_54_48x64 = the WHU / TartanAir map shape)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="auto = the headline window on one GPU, weak scaling (64 KF, 64 edges per rank) on several")
+    ap.add_argument("--unfused-reprojection", action="store_true",
+                    help="reproject in its own launch (dba_reproject) and hand the lookup the coordinates, as round 3 did")
     ap.add_argument("--backend", default=os.environ.get("DBA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend of the exchange step (gloo: host-staged, several ranks may share one GPU)")
     args = ap.parse_args()
@@ -152,11 +155,12 @@ def main():
     C = 128
     fmaps = t(syn.make_fmaps(W.B, C, h, w, args.seed + 1000))
 
-    def build_block(layout=None):
+    def build_block(layout=None, spare=0):
         blk = None
-        for c0 in range(0, n_loc, 32):  # volumes of this rank's edges, in chunks like add_factors adds them
-            s_ = slice(c0, min(c0 + 32, n_loc))
-            cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3, layout=layout)
+        for c0 in range(0, n_loc, 32):  # volumes of this rank's edges, in chunks like add_factors adds them: every chunk
+            s_ = slice(c0, min(c0 + 32, n_loc))   # after the first is built straight into free slots of the block (cat)
+            cb = CorrBlock(fmaps[ii[s_]][None], fmaps[jj[s_]][None], num_levels=4, radius=3, layout=layout,
+                           capacity=n_loc + spare)
             blk = cb if blk is None else blk.cat(cb)
         return blk
 
@@ -171,9 +175,9 @@ def main():
     disps = state[npose + pad:].view_as(disps0)
 
     total = args.steps + args.warmup
-    # The BA mutates its inputs, so every step needs the initial state again.  A copy inside the step (round 2: 4.7 us of a
-    # 256 us step) is scaffolding of the benchmark, not part of an update: the steps of a loop take pristine copies out of a
-    # pool that is refilled between the loops, outside the timed region.
+    # The BA mutates its inputs, so every step needs the initial state again: one device copy at the top of the step, inside
+    # the timed region.  The pool of pristine copies serves the extra loop that prices the step WITHOUT that
+    # copy (extra.step_pooled_state_us) and the loops of the untimed extras.
     slen = (state0.numel() + 63) // 64 * 64
     pool = torch.zeros(max(total, 1), slen, dtype=state0.dtype, device=dev)
 
@@ -191,28 +195,41 @@ def main():
     ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
     keep = [None] * ncopies  # the last outputs stay alive: the allocator hands out other lines for the next ones
 
-    def step(i, corr_of=lambda i: corrs[i % ncopies], lookup=None, time_ba=False):
+    K_b4 = K[0]
+    fused = not args.unfused_reprojection
+
+    def step(i, corr_of=lambda i: corrs[i % ncopies], lookup=None, time_ba=False, pooled=False, graph=None):
         if args.step_events:
             ev_step[i].record()
-        poses, disps = pooled_state(i)
-        coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii, jj)
+        if pooled:
+            poses, disps = pooled_state(i)
+        else:
+            state.copy_(state0)                      # the per-step state reset (poses + inverse depths: one copy)
+            poses, disps = state[:npose].view_as(poses0), state[npose + pad:].view_as(disps0)
+        ii_, jj_, target_, weight_ = (ii, jj, target, weight) if graph is None else graph
         # the roofline kernel is timed live, in every timed step, with two HIP events ATTACHED TO ITS DISPATCH on the launch
         # stream (hipExtLaunchKernelGGL through dba_corr_lookup_arm_timing): the dispatch's own start / end timestamps;
         # event.record() around the call would put two marker packets (~5 us of idle each) into every step
         if lookup is not None:
+            coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii_, jj_)
             ev[4 * i].record()
             c = lookup(coords1)
             ev[4 * i + 1].record()
+        elif n_loc == 0:
+            c = None
+        elif fused:     # reprojection in the lookup's prologue: one launch, the coordinates are written for the caller
+            c, coords1, _ = corr_of(i).lookup_reprojected(poses, disps, K_b4, ii_, jj_, timing=(ev[4 * i], ev[4 * i + 1]))
         else:
-            c = corr_of(i)(coords1, timing=(ev[4 * i], ev[4 * i + 1])) if corrs else None
+            coords1, _ = pops.projective_transform(poses[None], disps[None], K, ii_, jj_)
+            c = corr_of(i)(coords1, timing=(ev[4 * i], ev[4 * i + 1]))
         keep[i % ncopies] = c
         if time_ba:
             ev[4 * i + 2].record()
         if shard is None:
-            droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep,
+            droid_backends.ba(poses, disps, intr, dsens, target_, weight_, eta, ii_, jj_, W.t0, W.t1, 2, W.lm, W.ep,
                               False)
         else:
-            shard.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, ba_dist)
+            shard.ba(poses, disps, intr, dsens, target_, weight_, eta, ii_, jj_, 2, W.lm, W.ep, ba_dist)
         if time_ba:
             ev[4 * i + 3].record()
         disps.clamp_(min=0.001)  # depth_video.py:560
@@ -223,15 +240,19 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    ev_loop = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
+    ev_loop[0].record()
     for i in range(args.warmup, total):
         step(i)
+    ev_loop[1].record()
     if args.step_events:
         ev_step[total].record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    loop_event_us = ev_loop[0].elapsed_time(ev_loop[1]) * 1e3 / max(args.steps, 1)   # events around the loop
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -241,10 +262,17 @@ def main():
     look_us = np.array([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in ks]) * 1e3 if corrs and args.steps else np.zeros(1)
     # ba(itrs=2) device time for SURVEY 8(d)'s gn_iter GB/s: a short untimed loop (its two events stay out of the timed steps)
     nb = min(10, total)
-    refill_pool()
     for i in range(nb):
         step(i, time_ba=True)
     torch.cuda.synchronize()
+    # the step without the state reset (round 3's method: pristine copies out of a pool filled outside the timed region)
+    refill_pool()
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i, pooled=True)
+    torch.cuda.synchronize()
+    pooled_us = (time.perf_counter() - tp) / max(args.steps, 1) * 1e6
     ba_us = np.array([ev[4 * i + 2].elapsed_time(ev[4 * i + 3]) for i in range(nb)]) * 1e3
     lookup_ms = float(look_us.mean()) * 1e-3 if corrs and args.steps else float("nan")
 
@@ -264,8 +292,7 @@ def main():
 
             def step1():
                 st1.copy_(st1_0)
-                c1, _ = pops.projective_transform(p1[None], d1[None], K1, ii1, jj1)
-                keep[0] = cb1(c1)
+                keep[0] = cb1.lookup_reprojected(p1, d1, K1[0], ii1, jj1)[0]
                 droid_backends.ba(p1, d1, intr, dsens, tg1, wt1, eta1, ii1, jj1, W1.t0, W1.t1, 2, W1.lm, W1.ep, False)
                 d1.clamp_(min=0.001)
 
@@ -312,8 +339,18 @@ def main():
             state.copy_(state0)
             sh1.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, None)
 
+        def fresh_graph():   # new edge tensors on every call, as after add_factors / rm_factors: stage 0 runs, nothing is cached
+            state.copy_(state0)
+            droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii.clone(), jj.clone(), W.t0, W.t1, 2, W.lm,
+                              W.ep, False)
+
         reps = max(10, args.steps // 2)
-        extras["sharded_x1_overhead_us"] = round(loop(sharded1, reps) - loop(plain, reps), 1)
+        t_plain = loop(plain, reps)
+        extras["sharded_x1_overhead_us"] = round(loop(sharded1, reps) - t_plain, 1)
+        # the timed steps call ba on the SAME edge tensors (CovisibleGraph.update() does, between graph changes): the prepared
+        # workspace is reused.  What a call on a NEW graph costs on top (stage 0 + allocations), wall clock per call:
+        extras["ba_itrs2_cached_graph_wall_us"] = round(t_plain, 1)
+        extras["ba_itrs2_fresh_graph_wall_us"] = round(loop(fresh_graph, reps), 1)
     if rank == 0 and world == 1 and not args.no_extras and corrs and scaling != "weak":
         def timed(fn, reps):
             fn()
@@ -334,7 +371,7 @@ def main():
         # volume build (per add_factors batch of 32 edges): CorrBlock(fmap1, fmap2), MFMA + pooling + flow-aligned store
         nb = min(32, n_loc)
         f1, f2 = fmaps[ii[:nb]][None], fmaps[jj[:nb]][None]
-        b_us = timed(lambda: CorrBlock(f1, f2, num_levels=4, radius=3), 5) / nb
+        b_us = timed(lambda: CorrBlock(f1, f2, num_levels=4, radius=3).build(), 5) / nb
         bbytes, bflops = build_algorithmic_bytes(C, HW)
         extras["build_us_per_edge"] = round(b_us, 2)
         extras["build_GBps"] = round(bbytes / (b_us * 1e-6) / 1e9, 1)
@@ -346,13 +383,13 @@ def main():
         del corrs[1:]
         keep[:] = [None] * ncopies
         torch.cuda.empty_cache()
-        ref_blk = build_block(layout="reference")
+        ref_pyr = list(build_block(layout="reference").corr_pyramid)   # the reference's self.corr_pyramid: [n,h,w,h>>l,w>>l]
 
         def zero_edit_lookup(coords):
             cp = coords[0].permute(0, 3, 1, 2).contiguous()
             outs = []
             for lvl in range(4):
-                o, = droid_backends.corr_index_forward(ref_blk.corr_pyramid[lvl], cp / 2 ** lvl, 3)
+                o, = droid_backends.corr_index_forward(ref_pyr[lvl], cp / 2 ** lvl, 3)
                 outs.append(o.view(1, n_loc, -1, h, w))
             return torch.cat(outs, dim=2)
 
@@ -376,7 +413,7 @@ def main():
 
             def reshear():
                 for lvl in range(4):
-                    v = ref_blk.corr_pyramid[lvl]
+                    v = ref_pyr[lvl]
                     ent = _SHADOWS.seen.get(id(v))
                     if ent is not None and ent[3] is not None:
                         lib_.dba_corr_shear_level(v.data_ptr(), ent[3].data_ptr(), n_loc, h, w, h >> lvl, w >> lvl, lvl,
@@ -385,6 +422,83 @@ def main():
             extras["zero_edit_shadow_bytes"] = int(sum(e[3].numel() * 2 for e in _SHADOWS.seen.values() if e[3] is not None))
         extras["zero_edit_lookup_us"] = round(float(np.mean([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in range(3, 3 + nz)]))
                                               * 1e3, 1)
+
+        # ---- what a KEYFRAME costs: the graph changes every ~6 updates (dbaf_frontend: add_factors /
+        # rm_factors per keyframe, covisible_graph.py:103-170).  One cycle = drop the 6 oldest edges, add 6 (here: the same
+        # frame pairs again, so the window stays the bench window), then 6 updates on the NEW edge tensors (the BA workspace
+        # finds a new graph: stage 0 runs once per cycle).
+        nrot, nupd, ncyc = min(6, n_loc // 2), 6, 4
+
+        def run_cycles(change, lookup_for, order):
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            k = 0
+            for _ in range(ncyc):
+                order = torch.cat([order[nrot:], order[:nrot]])
+                blk = change(order)
+                g = (ii[order].contiguous(), jj[order].contiguous(), target[order].contiguous(), weight[order].contiguous())
+                for _ in range(nupd):
+                    step(k, graph=g, **lookup_for(blk))
+                    k += 1
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tc) / ncyc * 1e6, order
+
+        order0 = torch.arange(n_loc, device=dev)
+        mask = torch.ones(n_loc, dtype=torch.bool, device=dev)
+        mask[:nrot] = False
+        # (a) slot-addressed CorrBlock: rm_factors edits the slot table, add_factors builds into the freed slots
+        state_a = {"blk": corrs[0]}
+
+        def change_slots(order):
+            new = order[-nrot:]
+            state_a["blk"] = state_a["blk"][mask].cat(CorrBlock(fmaps[ii[new]][None], fmaps[jj[new]][None]))
+            return state_a["blk"]
+
+        _, order = run_cycles(change_slots, lambda blk: dict(corr_of=lambda i: blk), order0)      # warm-up
+        t_kf, order = run_cycles(change_slots, lambda blk: dict(corr_of=lambda i: blk), order)
+        extras["keyframe_cycle_us"] = round(t_kf, 1)
+        st = state_a["blk"].stats
+        extras["keyframe_cycle_volumes_moved"] = int(st["copied_edges"] + st["grown"])
+        # (b) the reference's semantics on the same layout: boolean index + torch.cat of the whole pyramid per change
+        state_b = {"pyr": list(state_a["blk"].corr_pyramid)}     # (gathered in the current edge order: new tensors)
+        del state_a, corrs[:]
+        keep[:] = [None] * ncopies
+        torch.cuda.empty_cache()
+
+        def change_legacy(order):
+            new = order[-nrot:]
+            add = CorrBlock.build_sheared_fused(fmaps[ii[new]][None], fmaps[jj[new]][None], 4)
+            state_b["pyr"] = [torch.cat([p[mask], q], 0) for p, q in zip(state_b["pyr"], add)]
+            return CorrBlock.from_pyramid(state_b["pyr"], "sheared", hw=(h, w))
+
+        _, order = run_cycles(change_legacy, lambda blk: dict(corr_of=lambda i: blk), order)
+        t_kf, order = run_cycles(change_legacy, lambda blk: dict(corr_of=lambda i: blk), order)
+        extras["keyframe_cycle_legacy_cat_us"] = round(t_kf, 1)
+        del state_b
+        torch.cuda.empty_cache()
+        # (c) the zero-edit route under the same churn: the reference's own CorrBlock re-creates its level tensors on every
+        # graph change (torch.cat / boolean index), so the flow-aligned shadows start over; DBA_ZERO_EDIT_SHADOW_USES decides
+        # after how many lookups of the same tensors a shadow is built
+        state_c = {"pyr": ref_pyr}
+
+        def change_zero_edit(order):
+            state_c["pyr"] = [torch.cat([p[mask], p[:nrot]], 0) for p in state_c["pyr"]]
+            return state_c["pyr"]
+
+        def ze_lookup(pyr):
+            def look(coords):
+                cp = coords[0].permute(0, 3, 1, 2).contiguous()
+                outs = [droid_backends.corr_index_forward(pyr[lvl], cp / 2 ** lvl, 3)[0].view(1, n_loc, -1, h, w)
+                        for lvl in range(4)]
+                return torch.cat(outs, dim=2)
+            return dict(lookup=look)
+
+        del ref_pyr
+        _, order = run_cycles(change_zero_edit, ze_lookup, order0)
+        t_ze, order = run_cycles(change_zero_edit, ze_lookup, order)
+        extras["zero_edit_churn_dba_update_per_s"] = round(nupd / (t_ze * 1e-6), 1)
+        extras["zero_edit_churn_note"] = "graph change every %d updates, shadow (re)builds included; shadow after %d uses" % (
+            nupd, _SHADOWS.min_uses)
 
     if rank == 0:
         ms_per_step = 1e3 * dt / max(args.steps, 1)
@@ -407,24 +521,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if scaling == "strong" and world > 1 else "weak",
+            # N = 1: the headline window on one GPU (no scaling claim); N > 1: weak (64 edges per rank) or strong
+            "scaling": "headline" if world == 1 and scaling != "weak" else ("strong" if scaling == "strong" else "weak"),
             "vs_baseline": None,
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
             "config": {"workload": "synthetic %s -> %dx%d maps, %d-KF window, %d edges, "
-                                   "reproject + 4-level r=3 lookup + ba(itrs=2) per step; lookups rotate over %d disjoint "
-                                   "pyramid copies (MALL-cold)" % (
+                                   "state reset + [reprojection + 4-level r=3 lookup: %s] + ba(itrs=2) per step; lookups "
+                                   "rotate over %d disjoint pyramid copies (MALL-cold)" % (
                                        {(64, 64): "TUM-VI-shape 512x512", (28, 107): "KITTI-360-shape 224x856",
                                         (55, 55): "TUM-VI demo 440x440", (48, 64): "384x512 (WHU / TartanAir)"}.get(
-                                           (h, w), "%dx%d frames" % (8 * h, 8 * w)), h, w, W.num_kf, N, ncopies),
+                                           (h, w), "%dx%d frames" % (8 * h, 8 * w)), h, w, W.num_kf, N,
+                                       "one launch" if fused else "two launches", ncopies),
                        "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
                        "scaling_mode": scaling,
                        "exchange": ("gloo (host-staged)" if args.backend == "gloo" and world > 1 else
                                     "peer-read" if ba_dist is not dist else "rccl"),
                        "pyramid_copies": ncopies},
             "roofline": {
-                "kernel": "%s (fused 4-level r=3 lookup, f16, %d edges on rank 0, "
-                          "%s)" % ("corr_lookup_sheared_kernel<3>" if w % 64 == 0 else "corr_lookup_resident_kernel<3>", n_loc,
+                "kernel": "%s (fused 4-level r=3 lookup%s, f16, %d edges on rank 0, "
+                          "%s)" % ("corr_lookup_sheared_kernel<3>" if w % 64 == 0 else "corr_lookup_resident_kernel<3>",
+                                   " with the reprojection in its prologue" if fused else "", n_loc,
                                    "MALL-cold: rotating pyramid copies and output buffers" if ncopies > 1
                                    else "MALL-warm: one pyramid copy replayed"),
                 "bound": "hbm",
@@ -435,6 +552,13 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(lookup_ms, 5) if lookup_ms == lookup_ms else None,
+                "timing": "two HIP events attached to the kernel's dispatch on its launch stream, every timed step",
+                "traffic_note": "HBM bytes per launch from COMMITTED rocprofv3 --pmc passes of this command (FETCH_SIZE x 64 B "
+                                "x 2 on gfx950 + WRITE_SIZE, profiles/README.md); not re-measured by this run",
+                "parity_note": "lookups bit-exact vs the CPU oracle; the oracle's fp16 operation ORDER, the alpha / sensor-depth "
+                               "terms of C, w, frame_distance and depth_filter are restatement-only (the reference has no "
+                               "runnable counterpart); volume, projection, Schur algebra and one torch-BA step are pinned by "
+                               "vectors of the reference's own Python, the call-site tensors by tests/golden/caller_dumps.npz",
             },
         }
         pmc_rel = PMC_FILE % ("" if args.window == "25_96" else "_" + args.window)
@@ -455,6 +579,9 @@ def main():
         step_us = (np.array([ev_step[i].elapsed_time(ev_step[i + 1]) for i in ks]) * 1e3
                    if args.steps and args.step_events else np.zeros(1))
         out["extra"] = {"dba_update_per_s": round(updates_per_s, 3),
+                        "step_event_us": round(loop_event_us, 1),          # HIP events around the timed loop / steps
+                        "step_pooled_state_us": round(pooled_us, 1),       # the step without the per-step state reset
+                        "reprojection": "fused into the lookup launch" if fused else "own launch",
                         "gn_iter_per_s": round(2.0 * updates_per_s, 3),
                         "edges_per_s": round(N * updates_per_s, 1),
                         "edge_lookups_per_s": round(N * updates_per_s, 1),

@@ -36,19 +36,24 @@ static std::atomic<int> g_schur_form{[] {
   return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'f' || e[0] == 'g') ? 2 : 0);
 }()};  // 0 = automatic, 1 = (row, partner) grid, 2 = per-source-frame form; dba_ba_schur_select() changes it
 
-static bool schur_auto_frame_form(int N, int Mmax) {
-  const int rows_est = 1 + (Mmax > 0 ? (N + Mmax - 1) / Mmax : 0);
+// rows a source frame couples, estimated from the GRAPH (N edges over the window's P optimised poses + the fixed frame in
+// front of them), not from the size of the video buffer: min(B, P + N) grows with the buffer (the reference's DepthVideo
+// holds 1024 frames) and made the per-frame form unreachable in a real integration
+static bool schur_auto_frame_form(int N, int P) {
+  const int frames = P + 1;
+  const int rows_est = 1 + (N + frames - 1) / frames;
   return rows_est > 6;
 }
 
+static std::atomic<int> g_schur_generation{0};
 static thread_local int t_schur_form = 0;  // per-thread pin (dba_ba_schur_select_thread): the sharded driver's ranks
 
-bool ba_schur_frame_form(int N, int Mmax) {
+bool ba_schur_frame_form(int N, int P) {
   const int forced = g_schur_form.load(std::memory_order_relaxed);
   if (N + 1 > GRAM_LIST_CAP) return false;
   if (forced) return forced == 2;
   if (t_schur_form) return t_schur_form == 2;
-  return schur_auto_frame_form(N, Mmax);
+  return schur_auto_frame_form(N, P);
 }
 
 int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan) {
@@ -188,7 +193,7 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
-                     (int)scan_ints, ba_schur_frame_form(N, plan.T.Mmax) ? 1 : 0, plan.T);
+                     (int)scan_ints, ba_schur_frame_form(N, plan.P) ? 1 : 0, plan.T);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -252,7 +257,7 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
     // per-source-frame form (every row of E read once, Gram tiles on the matrix cores); DBA_SCHUR_KERNEL=rows keeps
     // the (row, partner) grid, which also takes graphs with more edges than the prepare kernel lists per frame
     static const int env_nch = [] { const char *e = getenv("DBA_SCHUR_NCH"); return e ? atoi(e) : 0; }();
-    if (!ba_schur_frame_form(N, plan.T.Mmax)) {
+    if (!ba_schur_frame_form(N, plan.P)) {
       hipLaunchKernelGGL(ba_schur_kernel, dim3(plan.P + N + ablocks, SCHUR_KP, SCHUR_CH), dim3(256), 0,
                          (hipStream_t)stream, ii, jj, frame_owned, N, plan.HW, t0, plan.P, lower, plan.T, plan.W);
     } else {
@@ -299,9 +304,6 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
   return dba_ba_symmetrize(N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
 }
 
-static std::atomic<int> g_schur_generation{0};
-
-
 int dba_ba_schur_select(int form) {
   if (form < 0 || form > 2) return DBA_ERR_ARG;
   g_schur_form.store(form, std::memory_order_relaxed);
@@ -311,11 +313,15 @@ int dba_ba_schur_select(int form) {
 
 int dba_ba_schur_select_thread(int form) {
   if (form < 0 || form > 2) return DBA_ERR_ARG;
+  // (which tables stage 0 builds depends on the form in force -- the frame row table exists only for the per-frame form --,
+  // so whoever skips stage 0 on a prepared workspace must key it on dba_ba_schur_generation() AND dba_ba_schur_thread_form())
   t_schur_form = form;
   return DBA_OK;
 }
 
-int dba_ba_schur_auto_form(int N, int M) { return schur_auto_frame_form(N, M) ? 2 : 1; }
+int dba_ba_schur_thread_form(void) { return t_schur_form; }
+
+int dba_ba_schur_auto_form(int N, int P) { return schur_auto_frame_form(N, P) ? 2 : 1; }
 
 int dba_ba_set_deterministic(int on) {
   g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);

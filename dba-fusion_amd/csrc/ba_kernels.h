@@ -66,7 +66,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
 __global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1, int scan_ints,
                                   int ftable, BaTables T);
 // which Schur kernel a window gets (ba_host.hip): the per-source-frame form on windows whose frames couple many rows
-bool ba_schur_frame_form(int N, int Mmax);
+bool ba_schur_frame_form(int N, int P);
 template <int PPL, bool MF, int EW>
 __global__ void ba_linearize_kernel(const float *poses, const float *disps, const float *intrinsics,
                                     const float *disps_sens, const float *targets, const float *weights,

@@ -83,7 +83,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NT, bool LOOP>
 __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_build_fused_kernel(
     const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm, FusedLevels L, int C, int h1, int w1, int h2, int w2,
-    int HW1p, float inv_w1, int strips_per_wg
+    int HW1p, float inv_w1, int strips_per_wg, const int *__restrict__ oslots
 #ifdef FB_PROF
     , unsigned long long *prof
 #endif
@@ -298,10 +298,13 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   };
   pixel_xy(p, x1, y1);
   constexpr unsigned OOR = 0x80000000u;
-  // level l volume of edge e: [h2l][w2l][HW1p] halves, addressed through a buffer resource (an edge-level is < 2 GB)
+  // level l volume of edge e: [h2l][w2l][HW1p] halves, addressed through a buffer resource (an edge-level is < 2 GB);
+  // oslots: edge e is written into slot oslots[e] of the level stores (the slot-addressed CorrBlock builds new edges
+  // straight into the free slots of its pyramid: nothing is concatenated afterwards)
+  const int eo = oslots ? oslots[e] : e;
   auto level_rsrc = [&](int lvl) {
     const size_t elems = (size_t)(h2 >> lvl) * (w2 >> lvl) * HW1p;
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)e * elems), 0, (int)(2 * elems), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)eo * elems), 0, (int)(2 * elems), 0x00020000);
   };
   const unsigned plane_bytes = 2u * (unsigned)HW1p;
 
@@ -554,6 +557,13 @@ int dba_corr_volume_build_sheared_supported(int C, int h1, int w1, int h2, int w
 int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *const *sheared_levels, int n, int C,
                                   int h1, int w1, int h2, int w2, int num_levels, void *scratch,
                                   size_t scratch_bytes, dba_stream_t stream) {
+  return dba_corr_volume_build_sheared_slots(fmap1, fmap2, sheared_levels, nullptr, n, C, h1, w1, h2, w2, num_levels, scratch,
+                                             scratch_bytes, stream);
+}
+
+int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, void *const *sheared_levels,
+                                        const int *out_slots, int n, int C, int h1, int w1, int h2, int w2, int num_levels,
+                                        void *scratch, size_t scratch_bytes, dba_stream_t stream) {
   if (!dba_corr_volume_build_sheared_supported(C, h1, w1, h2, w2, num_levels)) return DBA_ERR_UNSUPPORTED;
   if (n < 0) return DBA_ERR_ARG;
   if (n == 0) return DBA_OK;
@@ -607,15 +617,15 @@ int dba_corr_volume_build_sheared(const void *fmap1, const void *fmap2, void *co
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
     hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
-                       inv_w1, spw FB_PROF_ARG);
+                       inv_w1, spw, out_slots FB_PROF_ARG);
   } else if (w2 <= 64) {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
     hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
-                       1 FB_PROF_ARG);
+                       1, out_slots FB_PROF_ARG);
   } else {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
     hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
-                       1 FB_PROF_ARG);
+                       1, out_slots FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
 #ifdef FB_PROF

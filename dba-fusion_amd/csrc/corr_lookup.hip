@@ -60,7 +60,7 @@ struct Arith<float> {
 template <typename T, int R, bool COORD_NHW2>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const float *__restrict__ coords,
                                                           T *__restrict__ out, int n, int h1, int w1, int h2,
-                                                          int w2, int num_levels) {
+                                                          int w2, int num_levels, const int *__restrict__ slots) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   const int HW1 = h1 * w1;
   const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const 
   const int ix0 = sane ? (int)fx - R : -(1 << 20);
   const int iy0 = sane ? (int)fy - R : -(1 << 20);
 
-  const T *plane = static_cast<const T *>(L.vol[lvl]) + (size_t)pix * h2l * w2l;
+  // slots: edge e's volumes live in slot slots[e] of the level stores (null: slot e; the slot-addressed CorrBlock)
+  const size_t vpix = slots ? (size_t)slots[e] * HW1 + rem : (size_t)pix;
+  const T *plane = static_cast<const T *>(L.vol[lvl]) + vpix * h2l * w2l;
 
   float win[WN][WN];  // [row j (y)][col i (x)]
   const bool interior = (ix0 >= 0) && (iy0 >= 0) && (ix0 + WN <= w2l) && (iy0 + WN <= h2l);
@@ -180,13 +182,13 @@ __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float *
 
 template <typename T, bool NHW2>
 static int launch_lookup(const LookupLevels &L, const float *coords, void *out, int n, int h1, int w1, int h2,
-                         int w2, int num_levels, int radius, hipStream_t stream) {
+                         int w2, int num_levels, int radius, hipStream_t stream, const int *slots = nullptr) {
   const long total = (long)n * h1 * w1;
   if (total == 0) return DBA_OK;
   dim3 grid((unsigned)((total + 255) / 256), num_levels);
 #define LAUNCH_R(RR)                                                                                     \
   hipLaunchKernelGGL((corr_lookup_kernel<T, RR, NHW2>), grid, dim3(256), 0, stream, L, coords, (T *)out, n, \
-                     h1, w1, h2, w2, num_levels)
+                     h1, w1, h2, w2, num_levels, slots)
   switch (radius) {
     case 1: LAUNCH_R(1); break;
     case 2: LAUNCH_R(2); break;
@@ -221,6 +223,13 @@ int dba_corr_index_forward(const void *volume, const float *coords, void *corr, 
 int dba_corr_lookup_pyramid(const void *const *volumes, const float *coords_nhw2, void *corr, int n, int h1,
                             int w1, int h2, int w2, int num_levels, int radius, int dtype,
                             dba_stream_t stream) {
+  return dba_corr_lookup_pyramid_slots(volumes, nullptr, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius, dtype,
+                                       stream);
+}
+
+int dba_corr_lookup_pyramid_slots(const void *const *volumes, const int *slots, const float *coords_nhw2, void *corr, int n,
+                                  int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                                  dba_stream_t stream) {
   if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > MAX_LEVELS)
     return DBA_ERR_ARG;
   if (n > 0 && (!volumes || !coords_nhw2 || !corr)) return DBA_ERR_ARG;
@@ -228,10 +237,10 @@ int dba_corr_lookup_pyramid(const void *const *volumes, const float *coords_nhw2
   for (int l = 0; l < MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? volumes[l] : nullptr;
   if (dtype == DBA_F16)
     return launch_lookup<_Float16, true>(L, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius,
-                                         (hipStream_t)stream);
+                                         (hipStream_t)stream, slots);
   if (dtype == DBA_F32)
     return launch_lookup<float, true>(L, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, slots);
   return DBA_ERR_UNSUPPORTED;
 }
 

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "reproj.h"
 
 #include <type_traits>
 
@@ -31,6 +32,17 @@ constexpr int SH_MAX_LEVELS = 8;
 
 struct ShLevels {
   const _Float16 *vol[SH_MAX_LEVELS];
+};
+
+// Reprojection taken along by the lookup (cflags bit 2, dba_corr_lookup_reproject_sheared): the kernel computes the
+// coordinates of its pixels from the poses and the source frame's inverse depths (reproj.h, the arithmetic of
+// reproject_kernel) instead of reading them; the waves of pyramid level 0 also write them (and `valid`) out, because the
+// caller needs them for the motion features and the BA targets (dbaf/covisible_graph.py:220-221,237).
+struct ShReproj {
+  const float *poses, *disps, *intr_b4;
+  const int64_t *ii, *jj;
+  float2 *coords_out;  // [n, h1, w1, 2] or null
+  float *valid_out;    // [n, h1, w1, 1] or null
 };
 
 // ---- reference layout -> sheared layout, one pyramid level ------------------------------------------
@@ -204,13 +216,18 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
                                                                           const float2 *__restrict__ coords,
                                                                           _Float16 *__restrict__ out, int n,
                                                                           int h1, int w1, int h2, int w2,
-                                                                          int num_levels, int lvl0, int cflags) {
+                                                                          int num_levels, int lvl0, int cflags,
+                                                                          const int *__restrict__ slots, ShReproj RP) {
+  // slots: edge e's volumes live in slot slots[e] of every level's store (null: slot e) -- the slot-addressed CorrBlock,
+  // whose cat / index operations edit this table instead of moving volumes (dbaf/modules/corr.py:52-60)
   // lvl0 / cflags: a launch may serve a sub-range of levels [lvl0, lvl0 + gridDim.y) of the pyramid (num_levels = levels
   // in `out`, the first of them lvl0), with planar (bit 0) and / or pre-scaled (bit 1) coordinates: the per-level calls of
   // the reference's unmodified CorrBlock (droid_backends.corr_index_forward on a flow-aligned shadow of the level)
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "the streaming lookup is written for radius 3");
   const bool cplanar = (cflags & 1) != 0;
+  const bool reproj = (cflags & 4) != 0;
+  __shared__ __attribute__((aligned(16))) float geom_all[SH_WAVES][EDGE_GEOM_FLOATS];
   __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
   __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];  // tap rows of lanes that touch nothing
   __shared__ u4v keep_all[SH_WAVES][2][64];  // per staging slot: 16-bit keep mask per half (image-border pieces)
@@ -240,6 +257,34 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   const size_t estride = (size_t)num_levels * RD * RD * HW1;
   if (threadIdx.x == 0) ocount = 0;
   for (int i = threadIdx.x; i < WN * 64; i += SH_BLOCK) zero_taps[i] = (_Float16)0.f;
+  // reprojection in the prologue: the geometry of an edge (relative pose, intrinsics: 20 floats) is formed once per
+  // workgroup and edge -- by the first wave of the workgroup that works on the edge -- and shared through LDS; every
+  // wave requests its pixels' inverse depths before the barrier
+  float dsrc = 0.f;
+  int gsrc = 0;
+  if (reproj && rowvalid) {
+    const int ey = rowid / xtiles, e = ey / h1, y1 = ey - e * h1;
+    const int ix = (int)RP.ii[e];
+    const int x1c = min((rowid - ey * xtiles) * 64 + lane, w1 - 1);
+    dsrc = RP.disps[(size_t)ix * HW1 + y1 * w1 + x1c];
+#ifndef SH_NO_XCD_SWIZZLE
+    const int row0 = lb * SH_WAVES;
+#else
+    const int row0 = blockIdx.x * SH_WAVES;
+#endif
+    gsrc = max(0, e * h1 * xtiles - row0);  // the wave of this workgroup that owns the edge's first row here
+    if (wave == gsrc) {
+      const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);
+      if (lane == 0) {
+        float4 *g4 = reinterpret_cast<float4 *>(geom_all[wave]);
+        g4[0] = make_float4(G.R[0], G.R[1], G.R[2], G.R[3]);
+        g4[1] = make_float4(G.R[4], G.R[5], G.R[6], G.R[7]);
+        g4[2] = make_float4(G.R[8], G.t[0], G.t[1], G.t[2]);
+        g4[3] = make_float4(G.ifx, G.ify, G.cxi, G.cyi);
+        g4[4] = make_float4(G.fxj, G.fyj, G.cxj, G.cyj);
+      }
+    }
+  }
   __syncthreads();
 
   if (rowvalid) {
@@ -249,7 +294,24 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     const int x1 = xt * 64 + lane;
     const bool active = x1 < w1;
     const int x1c = min(x1, w1 - 1);
-    const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1c), lvl, x1c, y1, h2l, w2l, active, slvl);
+    float2 cxy;
+    if (reproj) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(geom_all[gsrc]);
+      const float4 a = g4[0], b = g4[1], c = g4[2], d = g4[3], f = g4[4];
+      EdgeGeom G;
+      G.R[0] = a.x; G.R[1] = a.y; G.R[2] = a.z; G.R[3] = a.w; G.R[4] = b.x; G.R[5] = b.y; G.R[6] = b.z; G.R[7] = b.w;
+      G.R[8] = c.x; G.t[0] = c.y; G.t[1] = c.z; G.t[2] = c.w;
+      G.ifx = d.x; G.ify = d.y; G.cxi = d.z; G.cyi = d.w; G.fxj = f.x; G.fyj = f.y; G.cxj = f.z; G.cyj = f.w;
+      float ok;
+      cxy = reproject_pixel(G, (float)x1c, (float)y1, dsrc, ok);
+      if (lvl == 0 && active) {  // one level of the launch hands the coordinates to the caller
+        if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + y1 * w1 + x1] = cxy;
+        if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + y1 * w1 + x1] = ok;
+      }
+    } else {
+      cxy = sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1c);
+    }
+    const ShPixel P = sh_pixel<R>(cxy, lvl, x1c, y1, h2l, w2l, active, slvl);
     const bool touches = P.touches;
     const int ox = P.ox, oy = P.oy, sy = y1 >> lvl;
     _Float16 *obase = olvl + (size_t)e * estride;     // uniform
@@ -349,7 +411,8 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       // instructions, so every step issues the same instruction sequence and the waits on the loads that were
       // issued SH_DEPTH steps earlier are exact counts instead of "everything outstanding".
       constexpr unsigned OOR = 0x80000000u;
-      const _Float16 *vedge = L.vol[lvl] + (size_t)e * h2l * rowstride;  // uniform: this edge, this level
+      const int es = slots ? slots[e] : e;                                // uniform: the edge's slot in the stores
+      const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;  // uniform: this edge, this level
       const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(vedge + (size_t)y1 * w1), 0, (int)((unsigned)h2l * rowbytes - 2u * (unsigned)(y1 * w1)), 0x00020000);
       const __amdgpu_buffer_rsrc_t rout =
@@ -459,8 +522,18 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     const int pix = olist[t];  // (e * h1 + y1) * w1 + x1
     const int x1 = pix % w1, ey = pix / w1;
     const int y1 = ey % h1, e = ey / h1;
-    const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1), lvl, x1, y1, h2l, w2l, true, slvl);
-    const _Float16 *vol = L.vol[lvl] + (size_t)e * h2l * w2l * HW1 + (size_t)y1 * w1 + x1;
+    float2 cxy;
+    if (reproj) {
+      const int ix = (int)RP.ii[e];
+      float ok;
+      cxy = reproject_pixel(edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]), (float)x1, (float)y1,
+                            RP.disps[(size_t)ix * HW1 + y1 * w1 + x1], ok);
+    } else {
+      cxy = sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1);
+    }
+    const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, true, slvl);
+    const int es = slots ? slots[e] : e;
+    const _Float16 *vol = L.vol[lvl] + (size_t)es * h2l * w2l * HW1 + (size_t)y1 * w1 + x1;
     _Float16 *o = olvl + (size_t)e * estride + (size_t)y1 * w1 + x1;
     int dxm[WN];
     bool cok[WN];
@@ -547,7 +620,7 @@ __device__ __forceinline__ int sh2_mod(int v, int n, float inv_n, bool pow2) {
 template <int R>
 __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_resident_kernel(
     ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags) {
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -586,14 +659,29 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
   int x1 = pc - y1 * w1;
   if (x1 < 0) { y1--; x1 += w1; }
   if (x1 >= w1) { y1++; x1 -= w1; }
-  const ShPixel P = sh_pixel<R>(sh_coord(coords, cplanar, (size_t)e, HW1, pc), lvl, x1, y1, h2l, w2l, active, slvl);
+  float2 cxy;
+  if (cflags & 4) {  // the reprojection taken along (see ShReproj): this wave's edge geometry, then one pixel per lane
+    const int ix = (int)RP.ii[e];
+    const float dsrc = RP.disps[(size_t)ix * HW1 + pc];
+    const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);  // uniform
+    float ok;
+    cxy = reproject_pixel(G, (float)x1, (float)y1, dsrc, ok);
+    if (lvl == 0 && active) {
+      if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + p] = cxy;
+      if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + p] = ok;
+    }
+  } else {
+    cxy = sh_coord(coords, cplanar, (size_t)e, HW1, pc);
+  }
+  const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, active, slvl);
   const bool touches = P.touches;
   const int ox = P.ox, oy = P.oy;
 
   _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;  // this edge, this level: [49][HW1]
   const size_t rowstride = (size_t)w2l * HW1p;                              // elements between consecutive dy
   const unsigned rowbytes = (unsigned)(2 * rowstride);
-  const _Float16 *vedge = L.vol[lvl] + (size_t)e * h2l * rowstride;
+  const int es = slots ? slots[e] : e;                                      // the edge's slot in the stores (uniform)
+  const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
   const bool can_stream = ((size_t)h2l * rowbytes < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
   constexpr unsigned OOR = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rin =
@@ -852,7 +940,8 @@ int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int 
 
 // levels [lvl0, lvl0 + nlv) of the pyramid -> corr [n, nlv, 49, h1, w1]
 static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *corr, int n, int h1, int w1, int h2, int w2,
-                                 int lvl0, int nlv, int cflags, dba_stream_t stream) {
+                                 int lvl0, int nlv, int cflags, dba_stream_t stream, const int *slots = nullptr,
+                                 const ShReproj &RP = ShReproj{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
   if ((long)n * h1 * w1 >= 2147483647L) return DBA_ERR_UNSUPPORTED;
   const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
   // Two forms of the kernel (see the comments at each): "streaming" walks the union row by row (2 KB of LDS per wave,
@@ -872,7 +961,7 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
     dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), nlv);
     hipExtLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, e0, e1, 0, L,
                           reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          nlv, lvl0, cflags);
+                          nlv, lvl0, cflags, slots, RP);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
@@ -889,7 +978,7 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   }
   hipExtLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, e0, e1, 0, L,
                         reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags);
+                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -905,6 +994,36 @@ int dba_corr_lookup_pyramid_sheared(const void *const *volumes, const float *coo
   ShLevels L;
   for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
   return lookup_sheared_launch(L, coords_nhw2, corr, n, h1, w1, h2, w2, 0, num_levels, 0, stream);
+}
+
+int dba_corr_lookup_pyramid_sheared_slots(const void *const *volumes, const int *slots, const float *coords_nhw2, void *corr,
+                                          int n, int h1, int w1, int h2, int w2, int num_levels, int radius,
+                                          dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS)
+    return DBA_ERR_ARG;
+  if (radius != 3) return DBA_ERR_UNSUPPORTED;
+  if (n == 0) return DBA_OK;
+  if (!volumes || !coords_nhw2 || !corr) return DBA_ERR_ARG;
+  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
+  ShLevels L;
+  for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
+  return lookup_sheared_launch(L, coords_nhw2, corr, n, h1, w1, h2, w2, 0, num_levels, 0, stream, slots);
+}
+
+int dba_corr_lookup_reproject_sheared(const void *const *volumes, const int *slots, const float *poses, const float *disps,
+                                      const float *intrinsics_b4, const int64_t *ii, const int64_t *jj, float *coords_out,
+                                      float *valid_out, void *corr, int n, int h1, int w1, int h2, int w2, int num_levels,
+                                      int radius, dba_stream_t stream) {
+  if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS)
+    return DBA_ERR_ARG;
+  if (radius != 3) return DBA_ERR_UNSUPPORTED;
+  if (n == 0) return DBA_OK;
+  if (!volumes || !poses || !disps || !intrinsics_b4 || !ii || !jj || !corr) return DBA_ERR_ARG;
+  if ((h2 >> (num_levels - 1)) < 1 || (w2 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
+  ShLevels L;
+  for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l < num_levels) ? static_cast<const _Float16 *>(volumes[l]) : nullptr;
+  const ShReproj RP{poses, disps, intrinsics_b4, ii, jj, reinterpret_cast<float2 *>(coords_out), valid_out};
+  return lookup_sheared_launch(L, nullptr, corr, n, h1, w1, h2, w2, 0, num_levels, 4, stream, slots, RP);
 }
 
 int dba_corr_lookup_level_sheared(const void *sheared_level, const float *coords_n2hw_scaled, void *corr, int n, int h1,

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "reproj.h"
 
 namespace dba {
 
@@ -31,19 +32,13 @@ __global__ __launch_bounds__(256) void reproject_kernel(const float *__restrict_
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= HW) return;
   const int ix = (int)ii[n], jx = (int)jj[n];
-  float tij[3], qij[4];
-  edge_pose(poses, ix, jx, tij, qij);  // stereo edges: (-0.1,0,0), identity (projective_ops.py:105)
-  const Rot3 R = quat_to_rot(qij);
-  const float *Ki = intr_b4 + 4 * ix, *Kj = intr_b4 + 4 * jx;
+  // (reproj.h: the arithmetic the lookup kernels repeat in their prologue when they take the reprojection along --
+  // dba_corr_lookup_reproject_sheared -- so that the fused call equals this kernel + the lookup bit for bit)
+  const EdgeGeom G = edge_geom(poses, intr_b4, ix, jx);  // stereo edges: (-0.1,0,0), identity (projective_ops.py:105)
   const float u = (float)(k % wd), v = (float)(k / wd);
-  const float X0 = (u - Ki[2]) / Ki[0], X1 = (v - Ki[3]) / Ki[1];
-  const float d = disps[(size_t)ix * HW + k];
-  float x, y, z;
-  act_point(R, tij, X0, X1, d, x, y, z);
-  const float Z = (z < 0.5f * 0.2f) ? 1.0f : z;  // proj(): Z < 0.5*MIN_DEPTH -> 1 (projective_ops.py:44)
-  const float iz = 1.0f / Z;
-  coords[(size_t)n * HW + k] = make_float2(fmaf(Kj[0], x * iz, Kj[2]), fmaf(Kj[1], y * iz, Kj[3]));
-  valid[(size_t)n * HW + k] = (z > 0.2f) ? 1.0f : 0.0f;  // X0.z == 1 > MIN_DEPTH always (:112)
+  float ok;
+  coords[(size_t)n * HW + k] = reproject_pixel(G, u, v, disps[(size_t)ix * HW + k], ok);
+  valid[(size_t)n * HW + k] = ok;  // X0.z == 1 > MIN_DEPTH always (:112)
 }
 
 __global__ __launch_bounds__(256) void frame_distance_kernel(const float *__restrict__ poses,

@@ -33,6 +33,7 @@ SYMBOLS = {
     "dba_ba_schur_select": (c_int, [c_int]),
     "dba_ba_schur_select_thread": (c_int, [c_int]),
     "dba_ba_schur_auto_form": (c_int, [c_int, c_int]),
+    "dba_ba_schur_thread_form": (c_int, []),
     "dba_ba_schur_generation": (c_int, []),
     "dba_ba_set_deterministic": (c_int, [c_int]),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
@@ -57,6 +58,10 @@ SYMBOLS = {
     "dba_corr_shear_level": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_lookup_pyramid_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "dba_corr_lookup_level_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "dba_corr_volume_build_sheared_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
+    "dba_corr_lookup_pyramid_sheared_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "dba_corr_lookup_pyramid_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "dba_corr_lookup_reproject_sheared": (c_int, [_P] * 10 + [c_int] * 7 + [_P]),
     "dba_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_volume_scratch_bytes": (c_size_t, [c_int] * 6),
     "dba_corr_volume_build": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
@@ -96,7 +101,10 @@ def load():
 
 
 def schur_generation():
-    return load().dba_ba_schur_generation()
+    """what decides which Schur form (and therefore which stage-0 tables) is in force besides the graph itself: the
+    process-wide selection's generation and the calling thread's pin"""
+    lib = load()
+    return (lib.dba_ba_schur_generation(), lib.dba_ba_schur_thread_form())
 
 
 def check(rc, what):

@@ -1,17 +1,24 @@
-"""MI355X mirror of the reference's correlation operator surface (dbaf/modules/corr.py).
+"""MI355X form of the reference's correlation operator surface (dbaf/modules/corr.py).
 
-`CorrBlock(fmap1, fmap2)(coords)`, `.cat(other)` and `[index]` behave like the reference class
-(/root/reference/dbaf/modules/corr.py:23-71; call sites dbaf/covisible_graph.py:127-132,224 and
-dbaf/motion_filter.py:81), but
-  * the all-pairs volume and its 4-level pyramid come from one MFMA kernel chain
-    (dba_corr_volume_build) instead of torch.matmul + 3x avg_pool2d;
-  * the lookup of all levels is ONE launch that reads the [.., h, w, 2] coords as produced by the
-    reprojection and writes the concatenated [1, n, L*(2r+1)^2, h, w] tensor directly
-    (dba_corr_lookup_pyramid) instead of 4 launches + permute + torch.cat.
-The pyramid tensors keep the reference layout [n, h1, w1, h2>>l, w2>>l], so they remain valid inputs
-to droid_backends.corr_index_forward.
+`CorrBlock(fmap1, fmap2)(coords)`, `.cat(other)` and `[index]` answer like the reference class
+(/root/reference/dbaf/modules/corr.py:23-71; call sites dbaf/covisible_graph.py:127-132,166,224 and
+dbaf/motion_filter.py:81), but the pyramid is **slot-addressed**:
+
+  * every level lives in ONE store of `capacity` edge volumes (flow-aligned layout, csrc/corr_sheared.hip); which slot
+    edge e occupies is a small device table (`slots`) that the lookup kernels read;
+  * `CorrBlock(fmap1, fmap2)` does not build anything yet: the volumes are built on first use -- and when the block is
+    first used as the argument of `cat`, they are built STRAIGHT INTO FREE SLOTS of the receiving block
+    (dba_corr_volume_build_sheared_slots), so `self.corr = self.corr.cat(CorrBlock(...))` (covisible_graph.py:131) moves
+    no volume at all where the reference's torch.cat re-writes the whole pyramid (4.3 GB at 96 edges);
+  * `corr[mask]` (rm_factors, covisible_graph.py:166) edits the table; the slots of the dropped edges are free again;
+  * the all-pairs volume and its 4-level pyramid come from one MFMA kernel (csrc/corr_build_fused.hip) instead of
+    torch.matmul + 3x avg_pool2d, the lookup of all levels is ONE launch that writes the concatenated
+    [1, n, L*(2r+1)^2, h, w] tensor (instead of 4 launches + permute + torch.cat), and `lookup_reprojected` also takes the
+    reprojection (DepthVideo.reproject, depth_video.py:221-229) into that launch.
+Lookups are bit-identical to droid_backends.corr_index_forward on the reference-layout pyramid.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -20,7 +27,7 @@ from . import _lib
 
 
 def _ptr(x):
-    return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.data_ptr()) if x is not None else None
 
 
 def _stream():
@@ -29,12 +36,19 @@ def _stream():
 
 class CorrBlock:
     """layout="sheared" (default when the shapes allow it) keeps every level flow-aligned,
-    Vs_l[n, dy, dx, pixel] with pixel = y1 * w1 + x1 and the pixel axis padded to a multiple of 64
+    Vs_l[slot, dy, dx, pixel] with pixel = y1 * w1 + x1 and the pixel axis padded to a multiple of 64
     (csrc/corr_sheared.hip), so the lookup fetches full cache lines for any map size;
-    layout="reference" keeps the reference's [n, y1, x1, y2, x2] tensors, which are also valid inputs to
-    droid_backends.corr_index_forward.  Both give bit-identical lookups."""
+    layout="reference" keeps the reference's [slot, y1, x1, y2, x2] tensors, which (gathered: `corr_pyramid`) are also
+    valid inputs to droid_backends.corr_index_forward.  Both give bit-identical lookups.
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, layout=None):
+    capacity: slots to allocate when the stores are created (default: `CorrBlock.default_capacity`, i.e. the environment
+    variable DBA_CORR_SLOTS, or the number of edges of the first build); a `cat` that finds no free slot grows the
+    stores by half (one copy of the live pyramid, amortised) -- an integration that knows `max_factors` sets
+    `CorrBlock.default_capacity = max_factors` once and never pays it."""
+
+    default_capacity = int(os.environ.get("DBA_CORR_SLOTS", "0"))
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, layout=None, capacity=None):
         self.num_levels = num_levels
         self.radius = radius
         h1, w1 = fmap1.shape[-2:]
@@ -45,16 +59,112 @@ class CorrBlock:
             layout = "sheared" if can_shear else "reference"
         if layout == "sheared" and not can_shear:
             raise RuntimeError("CorrBlock: sheared layout needs radius 3 and equal feature-map sizes")
+        if not fmap1.is_cuda:
+            raise RuntimeError("CorrBlock (MI355X): feature maps must be HIP device tensors; no CPU path")
         self.layout = layout
         self.h1, self.w1 = int(h1), int(w1)
         self.h2, self.w2 = int(h2), int(w2)
-        if layout == "sheared":
-            fused = CorrBlock.build_sheared_fused(fmap1, fmap2, num_levels)
-            self.corr_pyramid = fused if fused is not None else CorrBlock.shear_pyramid(
-                CorrBlock.build_pyramid(fmap1, fmap2, num_levels))
-        else:
-            self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
+        self.n = int(fmap1.shape[0] * fmap1.shape[1])
+        self._capacity_hint = int(capacity if capacity is not None else CorrBlock.default_capacity)
+        # not built yet: the maps are kept (with their in-place versions: a build after an in-place write would not be the
+        # reference's result any more, so that raises) until first use or until a `cat` absorbs this block
+        self._pending = (fmap1, fmap2, fmap1._version, fmap2._version)
+        self._stores = None        # per level: [capacity, ...] device tensor
+        self._slots = None         # device int32 [n]: slot of edge e
+        self._slots_host = None    # list mirror of _slots, or None when stale (after a device-side index)
+        self._identity = True      # slots == arange(n) and capacity == n: the stores ARE the pyramid
+        self.stats = dict(built_edges=0, copied_edges=0, grown=0)
 
+    # ---- construction ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pyramid(cls, levels, layout, radius=3, hw=None):
+        """wrap existing level tensors without a build (recorded volumes in tests, tools/replay_dump.py): reference layout
+        [n,h1,w1,h2l,w2l], or flow-aligned [n,h2l,w2l,HW1p] with hw = (h1, w1)"""
+        self = cls.__new__(cls)
+        self.num_levels, self.radius, self.layout = len(levels), radius, layout
+        v0 = levels[0]
+        if layout == "reference":
+            self.n, self.h1, self.w1, self.h2, self.w2 = (int(x) for x in v0.shape)
+        else:
+            self.n, self.h2, self.w2 = (int(x) for x in v0.shape[:3])
+            self.h1, self.w1 = (int(x) for x in (hw if hw is not None else (self.h2, self.w2)))
+        self._capacity_hint, self._pending = 0, None
+        self._stores = [v if v.is_contiguous() else v.contiguous() for v in levels]
+        self._slots = torch.arange(self.n, dtype=torch.int32, device=v0.device)
+        self._slots_host, self._identity = list(range(self.n)), True
+        self.stats = dict(built_edges=0, copied_edges=0, grown=0)
+        return self
+
+    @classmethod
+    def from_reference(cls, ref_levels, radius=3):
+        """reference-layout levels -> a flow-aligned block (one re-layout pass per level)"""
+        self = cls.from_pyramid(ref_levels, "reference", radius)
+        self._stores = CorrBlock.shear_pyramid(self._stores)
+        self.layout = "sheared"
+        return self
+
+    def _level_shape(self, lvl, cap):
+        if self.layout == "sheared":
+            hw1p = _lib.load().dba_corr_sheared_plane_elems(self.h1, self.w1)
+            return (cap, self.h2 >> lvl, self.w2 >> lvl, hw1p)
+        return (cap, self.h1, self.w1, self.h2 >> lvl, self.w2 >> lvl)
+
+    def _materialise(self):
+        """build this block's own stores from its pending maps (first use without a `cat` into another block)"""
+        if self._pending is None:
+            return
+        f1, f2 = self._take_pending()
+        cap = max(self.n, self._capacity_hint)
+        dev = f1.device
+        self._stores = [torch.empty(self._level_shape(l, cap), dtype=torch.float16, device=dev)
+                        for l in range(self.num_levels)]
+        self._slots_host = list(range(self.n))
+        self._slots = torch.arange(self.n, dtype=torch.int32, device=dev)
+        self._identity = (cap == self.n)
+        self._build_into(f1, f2, None)
+
+    def build(self):
+        """force the build now (a block is otherwise built at its first lookup, or inside the `cat` that absorbs it)"""
+        self._materialise()
+        return self
+
+    def _take_pending(self):
+        f1, f2, v1, v2 = self._pending
+        if f1._version != v1 or f2._version != v2:
+            raise RuntimeError("CorrBlock: the feature maps were written in place between CorrBlock(...) and the build")
+        self._pending = None
+        return f1, f2
+
+    def _build_into(self, fmap1, fmap2, out_slots):
+        """volumes of the edges (fmap1[k], fmap2[k]) -> slots out_slots[k] (device int32, None: slot k) of self._stores"""
+        lib = _lib.load()
+        batch, num, dim, h1, w1 = fmap1.shape
+        n = batch * num
+        if n == 0:
+            return
+        f1 = fmap1.reshape(n, dim, h1, w1).to(torch.float16).contiguous()
+        f2 = fmap2.reshape(n, dim, self.h2, self.w2).to(torch.float16).contiguous()
+        sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, self.h2, self.w2)
+        scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)
+        self.stats["built_edges"] += n
+        if self.layout == "sheared" and lib.dba_corr_volume_build_sheared_supported(dim, h1, w1, self.h2, self.w2,
+                                                                                    self.num_levels):
+            ptrs = (ctypes.c_void_p * self.num_levels)(*[s.data_ptr() for s in self._stores])
+            _lib.check(lib.dba_corr_volume_build_sheared_slots(_ptr(f1), _ptr(f2), ptrs, _ptr(out_slots), n, dim, h1, w1,
+                                                               self.h2, self.w2, self.num_levels, _ptr(scratch), sbytes,
+                                                               _stream()), "dba_corr_volume_build_sheared_slots")
+            return
+        # shapes the fused kernel does not take, and the reference layout: build compactly, then place
+        levels = CorrBlock.build_pyramid(fmap1, fmap2, self.num_levels)
+        if self.layout == "sheared":
+            levels = CorrBlock.shear_pyramid(levels)
+        for store, lv in zip(self._stores, levels):
+            if out_slots is None:
+                store[:n].copy_(lv)
+            else:
+                store.index_copy_(0, out_slots.long(), lv)
+
+    # ---- the reference's static helpers (compact tensors) --------------------------------------------------------------
     @staticmethod
     def build_pyramid(fmap1, fmap2, num_levels=4):
         """fmap [batch, num, dim, ht, wd] half on the HIP device -> list of [batch*num, h1, w1, h2>>l, w2>>l]."""
@@ -120,35 +230,17 @@ class CorrBlock:
         lvl0 = CorrBlock.build_pyramid(fmap1, fmap2, 1)[0]
         return lvl0.view(batch, num, ht, wd, fmap2.shape[-2], fmap2.shape[-1])
 
-    def __call__(self, coords, timing=None):
-        """timing = (start, stop): two torch.cuda.Event(enable_timing=True) that have been recorded once (so that they
-        exist); they are attached to the lookup kernel's dispatch (sheared layout only), start.elapsed_time(stop) is
-        then the kernel's duration -- a measurement hook for bench.py, without marker packets in the stream"""
-        batch, num, ht, wd, _ = coords.shape
-        n = batch * num
-        vol0 = self.corr_pyramid[0]
-        assert vol0.shape[0] == n, "coords / volume edge count mismatch"
-        c = coords.reshape(n, ht, wd, 2)
-        if c.dtype != torch.float32 or not c.is_contiguous():
-            c = c.float().contiguous()
-        rd = 2 * self.radius + 1
-        out = torch.empty(batch, num, self.num_levels * rd * rd, ht, wd, dtype=vol0.dtype, device=vol0.device)
-        lib = _lib.load()
-        vols = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
-        ptrs = (ctypes.c_void_p * self.num_levels)(*[v.data_ptr() for v in vols])
-        if self.layout == "sheared":
-            assert (ht, wd) == (self.h1, self.w1), "coords / volume map size mismatch"
-            if timing is not None:
-                lib.dba_corr_lookup_arm_timing(ctypes.c_void_p(timing[0].cuda_event), ctypes.c_void_p(timing[1].cuda_event))
-            _lib.check(lib.dba_corr_lookup_pyramid_sheared(ptrs, _ptr(c), _ptr(out), n, ht, wd, self.h2, self.w2,
-                                                           self.num_levels, self.radius, _stream()),
-                       "dba_corr_lookup_pyramid_sheared")
-            return out
-        dt = _lib.DBA_F16 if vol0.dtype == torch.float16 else _lib.DBA_F32
-        _lib.check(lib.dba_corr_lookup_pyramid(ptrs, _ptr(c), _ptr(out), n, ht, wd, int(vol0.shape[3]),
-                                               int(vol0.shape[4]), self.num_levels, self.radius, dt, _stream()),
-                   "dba_corr_lookup_pyramid")
-        return out
+    # ---- the pyramid as the reference exposes it -----------------------------------------------------------------------
+    @property
+    def corr_pyramid(self):
+        """list of per-level tensors with the edges in order, [n, ...] (layout "reference": the reference's
+        [n,h1,w1,h2l,w2l], valid for droid_backends.corr_index_forward).  The stores themselves when the slot table is the
+        identity over a full store (a block that was never cat'ed into / indexed), a gathered copy otherwise."""
+        self._materialise()
+        if self._identity:
+            return self._stores
+        idx = self._slots.long()
+        return [s.index_select(0, idx) for s in self._stores]
 
     def sheared_level(self, lvl):
         """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1] (a view without the plane padding)"""
@@ -156,14 +248,142 @@ class CorrBlock:
         v = self.corr_pyramid[lvl]
         return v[..., :self.h1 * self.w1].unflatten(-1, (self.h1, self.w1))
 
+    @property
+    def capacity(self):
+        self._materialise()
+        return int(self._stores[0].shape[0])
+
+    # ---- lookups -------------------------------------------------------------------------------------------------------
+    def _store_ptrs(self):
+        return (ctypes.c_void_p * self.num_levels)(*[s.data_ptr() for s in self._stores])
+
+    def __call__(self, coords, timing=None):
+        """timing = (start, stop): two torch.cuda.Event(enable_timing=True) that have been recorded once (so that they
+        exist); they are attached to the lookup kernel's dispatch (sheared layout only), start.elapsed_time(stop) is
+        then the kernel's duration -- a measurement hook for bench.py, without marker packets in the stream"""
+        self._materialise()
+        batch, num, ht, wd, _ = coords.shape
+        n = batch * num
+        assert n == self.n, "coords / volume edge count mismatch"
+        c = coords.reshape(n, ht, wd, 2)
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        rd = 2 * self.radius + 1
+        v0 = self._stores[0]
+        out = torch.empty(batch, num, self.num_levels * rd * rd, ht, wd, dtype=v0.dtype, device=v0.device)
+        lib = _lib.load()
+        slots = None if self._identity else self._slots
+        if self.layout == "sheared":
+            assert (ht, wd) == (self.h1, self.w1), "coords / volume map size mismatch"
+            if timing is not None:
+                lib.dba_corr_lookup_arm_timing(ctypes.c_void_p(timing[0].cuda_event), ctypes.c_void_p(timing[1].cuda_event))
+            _lib.check(lib.dba_corr_lookup_pyramid_sheared_slots(self._store_ptrs(), _ptr(slots), _ptr(c), _ptr(out), n, ht,
+                                                                 wd, self.h2, self.w2, self.num_levels, self.radius,
+                                                                 _stream()), "dba_corr_lookup_pyramid_sheared_slots")
+            return out
+        dt = _lib.DBA_F16 if v0.dtype == torch.float16 else _lib.DBA_F32
+        _lib.check(lib.dba_corr_lookup_pyramid_slots(self._store_ptrs(), _ptr(slots), _ptr(c), _ptr(out), n, ht, wd,
+                                                     self.h2, self.w2, self.num_levels, self.radius, dt, _stream()),
+                   "dba_corr_lookup_pyramid_slots")
+        return out
+
+    def lookup_reprojected(self, poses, disps, intrinsics, ii, jj, timing=None):
+        """DepthVideo.reproject(ii, jj) (depth_video.py:221-229 -> pops.projective_transform, projective_ops.py:96-125) and
+        CorrBlock.__call__ in ONE launch: the lookup kernel computes its pixels' coordinates in its prologue.
+        poses [B,7] (or [1,B,7] / an SE3), disps [B,h,w] (or [1,B,h,w]), intrinsics [B,4] / [1,B,4] / [4]; ii, jj [n].
+        Returns (corr [1,n,L*49,h,w], coords [1,n,h,w,2], valid [1,n,h,w,1]) -- corr and coords bit-identical to
+        projective_transform followed by __call__."""
+        if self.layout != "sheared":
+            raise RuntimeError("lookup_reprojected needs the flow-aligned layout")
+        self._materialise()
+        pdata = poses.data if hasattr(poses, "data") and not isinstance(poses, torch.Tensor) else poses
+        pdata = pdata.reshape(-1, 7).float().contiguous()
+        d = disps.reshape(-1, disps.shape[-2], disps.shape[-1]).float().contiguous()
+        B, ht, wd = d.shape
+        K = intrinsics.reshape(-1, 4).float()
+        K = (K.expand(B, 4) if K.shape[0] == 1 else K).contiguous()
+        ii = ii.to(device=d.device, dtype=torch.int64).contiguous()
+        jj = jj.to(device=d.device, dtype=torch.int64).contiguous()
+        n = int(ii.shape[0])
+        assert n == self.n and (ht, wd) == (self.h1, self.w1), "edge count / map size mismatch"
+        coords = torch.empty(1, n, ht, wd, 2, dtype=torch.float32, device=d.device)
+        valid = torch.empty(1, n, ht, wd, 1, dtype=torch.float32, device=d.device)
+        rd = 2 * self.radius + 1
+        out = torch.empty(1, n, self.num_levels * rd * rd, ht, wd, dtype=torch.float16, device=d.device)
+        lib = _lib.load()
+        if timing is not None:
+            lib.dba_corr_lookup_arm_timing(ctypes.c_void_p(timing[0].cuda_event), ctypes.c_void_p(timing[1].cuda_event))
+        slots = None if self._identity else self._slots
+        _lib.check(lib.dba_corr_lookup_reproject_sheared(self._store_ptrs(), _ptr(slots), _ptr(pdata), _ptr(d), _ptr(K),
+                                                         _ptr(ii), _ptr(jj), _ptr(coords), _ptr(valid), _ptr(out), n, ht, wd,
+                                                         self.h2, self.w2, self.num_levels, self.radius, _stream()),
+                   "dba_corr_lookup_reproject_sheared")
+        return out, coords, valid
+
+    # ---- cat / index: table edits --------------------------------------------------------------------------------------
+    def _host_slots(self):
+        if self._slots_host is None:   # after a device-side index: one small copy (n ints), at the next graph change
+            self._slots_host = [int(v) for v in self._slots.cpu().tolist()]
+        return self._slots_host
+
+    def _grow(self, need):
+        self._materialise()
+        cap = int(self._stores[0].shape[0])
+        new_cap = max(cap + (cap + 1) // 2, need, self._capacity_hint)
+        new = []
+        for lvl, s in enumerate(self._stores):
+            t = torch.empty(self._level_shape(lvl, new_cap), dtype=s.dtype, device=s.device)
+            t[:cap].copy_(s)        # slot numbers stay valid
+            new.append(t)
+        self._stores = new
+        self._identity = False
+        self.stats["grown"] += 1
+
     def cat(self, other):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+        """append the edges of `other` (corr.py:52-55).  A block that has not been used yet is built straight into this
+        block's free slots; a built one has its volumes copied there (the new edges' bytes only)."""
+        assert (other.num_levels, other.radius, other.h1, other.w1, other.h2, other.w2) == (
+            self.num_levels, self.radius, self.h1, self.w1, self.h2, self.w2), "CorrBlock.cat: different shapes"
+        self._materialise()
+        k = other.n
+        if k == 0:
+            return self
+        used = self._host_slots()
+        cap = int(self._stores[0].shape[0])
+        if len(used) + k > cap:
+            self._grow(len(used) + k)
+            cap = int(self._stores[0].shape[0])
+        taken = set(used)
+        free = [s for s in range(cap) if s not in taken][:k]
+        new_slots = torch.tensor(free, dtype=torch.int32, device=self._slots.device)
+        if other._pending is not None and other.layout == self.layout:
+            f1, f2 = other._take_pending()
+            self._build_into(f1, f2, new_slots)
+        else:
+            other._materialise()
+            src = other.corr_pyramid
+            if other.layout != self.layout:
+                raise RuntimeError("CorrBlock.cat: different layouts")
+            for store, lv in zip(self._stores, src):
+                store.index_copy_(0, new_slots.long(), lv)
+            self.stats["copied_edges"] += k
+        self._slots = torch.cat([self._slots, new_slots])
+        self._slots_host = used + free
+        self.n += k
+        self._identity = (self._slots_host == list(range(cap)))
         return self
 
     def __getitem__(self, index):
-        for i in range(self.num_levels):
-            self.corr_pyramid[i] = self.corr_pyramid[i][index]
+        """keep / re-order edges (corr.py:57-60; rm_factors passes a boolean mask): the slot table is indexed, nothing
+        else moves; dropped edges' slots are found free at the next `cat`"""
+        self._materialise()
+        self._slots = self._slots[index.to(self._slots.device) if isinstance(index, torch.Tensor) else index]
+        if self._slots.dim() == 0:
+            self._slots = self._slots.reshape(1)
+        self._slots = self._slots.contiguous()
+        self.n = int(self._slots.shape[0])
+        self._slots_host = None
+        self._identity = False
         return self
 
 
@@ -208,43 +428,47 @@ class CorrLayer(torch.autograd.Function):
 
 
 class AltCorrBlock:
-    """dbaf/modules/corr.py:91-139: the memory-saving variant that never materialises the volume; keeps a channels-last
-    pyramid of the (pre-scaled) feature maps and correlates on the fly per lookup.  Same constructor, corr_fn and
-    __call__ as the reference class; the per-level work is droid_backends.altcorr_forward (csrc/altcorr.hip)."""
+    """The memory-saving correlation of the reference (dbaf/modules/corr.py:91-139; dead at runtime there): no volume, the
+    windowed correlation is formed on the fly from the feature maps at every lookup.
+
+    The feature pyramid is kept ONCE, channels-last and in float32 -- [B, N, H >> l, W >> l, C] of fmaps / 4, level l + 1
+    the 2x2 average of level l --, which is what the reference's per-lookup `.float()` of its half pyramid produces, so a
+    lookup converts nothing; a lookup is one altcorr launch per level (csrc/altcorr.hip) writing into its 49-channel slice
+    of the output.  Gradients flow through `CorrLayer`."""
 
     def __init__(self, fmaps, num_levels=4, radius=3):
         self.num_levels = num_levels
         self.radius = radius
         B, N, C, H, W = fmaps.shape
-        fmaps = fmaps.view(B * N, C, H, W) / 4.0
+        level = fmaps.reshape(B * N, C, H, W) / 4.0
         self.pyramid = []
-        for i in range(self.num_levels):
-            sz = (B, N, H // 2 ** i, W // 2 ** i, C)
-            fmap_lvl = fmaps.permute(0, 2, 3, 1).contiguous()
-            self.pyramid.append(fmap_lvl.view(*sz))
-            fmaps = F.avg_pool2d(fmaps, 2, stride=2)
+        for lvl in range(num_levels):
+            if lvl > 0:
+                level = F.avg_pool2d(level, 2, stride=2)
+            self.pyramid.append(level.permute(0, 2, 3, 1).reshape(B, N, H >> lvl, W >> lvl, C).contiguous())
+        self._f32 = None   # float32 twins of the levels, made at the first lookup (one conversion per block, not per call)
+
+    def _float_pyramid(self):
+        if self._f32 is None:
+            self._f32 = [p if p.dtype == torch.float32 else p.float() for p in self.pyramid]
+        return self._f32
 
     def corr_fn(self, coords, ii, jj):
+        """coords [B, N, H, W, S, 2] -> [B, N, L * 49, H, W, S]"""
         B, N, H, W, S, _ = coords.shape
-        coords = coords.permute(0, 1, 4, 2, 3, 5)
-        corr_list = []
-        for i in range(self.num_levels):
-            fmap1_i = self.pyramid[0][:, ii]
-            fmap2_i = self.pyramid[i][:, jj]
-            coords_i = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
-            fmap1_i = fmap1_i.reshape((B * N,) + fmap1_i.shape[2:])
-            fmap2_i = fmap2_i.reshape((B * N,) + fmap2_i.shape[2:])
-            corr = CorrLayer.apply(fmap1_i.float(), fmap2_i.float(), coords_i, self.radius)
-            corr = corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2)
-            corr_list.append(corr)
-        return torch.cat(corr_list, dim=2)
+        rd2 = (2 * self.radius + 1) ** 2
+        pyr = self._float_pyramid()
+        src = pyr[0][:, ii].reshape(B * N, H, W, -1)                       # level-0 maps of the source frames
+        cs = coords.movedim(4, 2).reshape(B * N, S, H, W, 2)               # the S coordinate sets in front of the pixels
+        out = coords.new_empty(B, N, self.num_levels * rd2, H, W, S, dtype=src.dtype)
+        for lvl, tgt_all in enumerate(pyr):
+            tgt = tgt_all[:, jj]
+            tgt = tgt.reshape((B * N,) + tuple(tgt.shape[2:]))
+            c = CorrLayer.apply(src, tgt, (cs / 2 ** lvl).contiguous(), self.radius)          # [B*N, S, 49, H, W]
+            out[:, :, lvl * rd2:(lvl + 1) * rd2] = c.reshape(B, N, S, rd2, H, W).movedim(2, -1)
+        return out
 
     def __call__(self, coords, ii, jj):
-        squeeze_output = False
-        if len(coords.shape) == 5:
-            coords = coords.unsqueeze(dim=-2)
-            squeeze_output = True
-        corr = self.corr_fn(coords, ii, jj)
-        if squeeze_output:
-            corr = corr.squeeze(dim=-1)
-        return corr.contiguous()
+        if coords.dim() == 5:   # [B, N, H, W, 2]: one coordinate set
+            return self.corr_fn(coords[..., None, :], ii, jj)[..., 0].contiguous()
+        return self.corr_fn(coords, ii, jj).contiguous()

@@ -172,16 +172,20 @@ class ShardedWindow:
            stages=None, alpha=0.05, motion_only=False):
         """In-place sharded BA.  targets/weights/ii/jj are THIS rank's edges; eta is the global
         [|kx|,h,w] (or [1,h,w]) damping; poses/disps are replicated and stay coherent on return."""
-        d = self._on(poses.device)
         if stages is None:
             if getattr(self, "_hip_stages", None) is None:
                 self._hip_stages = HipStages()
             stages = self._hip_stages
+        with _FormPin(stages, self):   # the form the complete graph would get, on every rank, for this call only
+            return self._ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, iterations, lm, ep, dist,
+                            stages, alpha, motion_only)
+
+    def _ba(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, iterations, lm, ep, dist, stages,
+            alpha, motion_only):
+        d = self._on(poses.device)
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         n6 = 6 * (self.t1 - self.t0)
-        if hasattr(stages, "select_schur_form"):   # the form the complete graph would get, on every rank
-            stages.select_schur_form(self, len(self.ii_all), len(self.kx_global))
         ctx = stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
                            self.t0, self.t1, alpha)
         if isinstance(ctx, dict):
@@ -247,10 +251,9 @@ class ShardedBACore:
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         self.poses, self.disps = poses, disps
-        if hasattr(self.stages, "select_schur_form"):
-            self.stages.select_schur_form(win, len(win.ii_all), len(win.kx_global))
-        self.ctx = self.stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
-                                     win.t0, win.t1, 0.001)
+        with _FormPin(self.stages, win):
+            self.ctx = self.stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
+                                         win.t0, win.t1, 0.001)
         n = 6 * (win.t1 - win.t0)
         self.n = n
         pin = poses.is_cuda
@@ -259,7 +262,8 @@ class ShardedBACore:
 
     def hessian(self, H, v):
         st, c, n = self.stages, self.ctx, self.n
-        st.linearize_reduce(c, False)
+        with _FormPin(st, self.win):
+            st.linearize_reduce(c, False)
         hb = st.system_view(c) if hasattr(st, "system_view") else None
         if hb is None:
             hb = st.get_system(c)
@@ -330,21 +334,44 @@ class HostStagedDist:
         return getattr(self._dist, name)
 
 
+class _FormPin:
+    """`with _FormPin(stages, window):` -- the Schur kernel form of the window's COMPLETE graph is pinned on this thread for
+    the duration of a sharded call (stage executors without kernels of their own -- the CPU stages of the tests -- have
+    nothing to pin)"""
+
+    def __init__(self, stages, window):
+        self.stages, self.window = stages, window
+
+    def __enter__(self):
+        if hasattr(self.stages, "select_schur_form"):
+            w = self.window
+            self.stages.select_schur_form(w, len(w.ii_all), w.t1 - w.t0)
+
+    def __exit__(self, *exc):
+        if hasattr(self.stages, "release_schur_form"):
+            self.stages.release_schur_form()
+        return False
+
+
 class HipStages:
     """Stage executor over the C ABI (include/dba_hip.h): dba_ba_prepare / linearize / reduce / solve / update."""
 
     def __init__(self):
         self._cache = {}   # (dims, device) -> workspace, layout and views: one allocation per window shape, not per call
 
-    def select_schur_form(self, window, n_edges, n_frames):
+    def select_schur_form(self, window, n_edges, n_poses):
         """A rank's share of the graph has the complete graph's rows per frame (all out-edges of a frame live on its owner)
         but few edges over all the window's frames, so the library's automatic choice would differ from a single GPU's:
         ask it with the complete graph's numbers and pin that form (every rank of a job asks the same question)."""
         lib = _lib.load()
         if window.schur_form is None:
-            window.schur_form = int(lib.dba_ba_schur_auto_form(int(n_edges), int(n_frames)))
+            window.schur_form = int(lib.dba_ba_schur_auto_form(int(n_edges), int(n_poses)))
         lib.dba_ba_schur_select_thread(window.schur_form)   # (a per-thread pin: cheap, and other callers keep their choice)
         self._form_pin = window.schur_form
+
+    def release_schur_form(self):
+        """the pin lasts for one sharded call: single-GPU calls of the same thread get the automatic choice back"""
+        _lib.load().dba_ba_schur_select_thread(0)
 
     def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
         lib = _lib.load()

@@ -95,6 +95,7 @@ class _BaWorkspaces:
         import weakref
         self.graph[key] = (weakref.ref(ii), ii._version, weakref.ref(jj), jj._version, _lib.schur_generation())
         self.plan.pop(key, None)
+        self.kx_count.pop(key, None)    # |kx| belongs to the graph the tables were prepared for
 
     def solver_hint(self, key, dims):
         """windows of 30-64 poses: which skyline-solver variant took this graph's structure in the previous call (meta[7] of
@@ -192,8 +193,6 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         nk = _BA_WS.kx_count.get(key) if prepared else None
         if nk is None:
             nk = _num_kx_exact(ii, t0, t1)
-            if key is not None:
-                _BA_WS.kx_count[key] = nk
         if eta_rows != nk:
             raise RuntimeError("eta has %d rows; it must have 1 or |unique(arange(t0,t1) U ii)| = %d rows "
                                "(droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C row by row)" % (eta_rows, nk))
@@ -204,6 +203,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     _lib.check(rc, "dba_ba")
     if key is not None and not prepared:
         _BA_WS.note(key, ii, jj)
+    if key is not None and eta_rows > 1:
+        _BA_WS.kx_count[key] = nk       # (after note(): a new graph dropped the previous graph's count)
     if motion_only:
         return [dx, None]
     return [dx, dz_full[:_num_kx(eta, ii, t0, t1, ht, wd)]]
@@ -420,17 +421,42 @@ class _VolumeShadows:
     def __init__(self):
         import os
         self.enabled = os.environ.get("DBA_ZERO_EDIT_SHADOW", "1") != "0"
-        self.seen = {}     # id(volume) -> [weakref, version, uses, shadow or None, lvl]
+        self.seen = {}     # id(volume) -> [weakref, version, uses, shadow or None, lvl, build event, last use]
         self.builds = 0
         self.hits = 0
+        self.evictions = 0
+        self.tick = 0
+        # the shadows double the pyramid's memory: a budget (bytes; DBA_ZERO_EDIT_SHADOW_BYTES, default 16 GiB -- three
+        # 96-edge pyramids at 64x64), least recently used shadows go first
+        self.budget = int(float(os.environ.get("DBA_ZERO_EDIT_SHADOW_BYTES", 16 * 2 ** 30)))
+        self.min_uses = max(2, int(os.environ.get("DBA_ZERO_EDIT_SHADOW_USES", "2")))
 
     @staticmethod
     def level_of(volume):
+        """pyramid level of a reference-layout tensor [n, h1, w1, h2 >> lvl, w2 >> lvl] -- inferred from the shapes, which
+        is only possible when source and target maps have the same size (h2 == h1, w2 == w1: CorrBlock's only use in the
+        reference, covisible_graph.py:127-131); anything else gets no shadow"""
         n, h1, w1, h2l, w2l = volume.shape
         for lvl in range(8):
-            if (h1 >> lvl) == h2l and (w1 >> lvl) == w2l:
+            if (h1 >> lvl) == h2l and (w1 >> lvl) == w2l and h2l >= 1 and w2l >= 1:
                 return lvl
         return None
+
+    def bytes_held(self):
+        return sum(e[3].numel() * e[3].element_size() for e in self.seen.values() if e[3] is not None)
+
+    def _make_room(self, need):
+        if need > self.budget:
+            return False
+        held = self.bytes_held()
+        for key, e in sorted(((k, e) for k, e in self.seen.items() if e[3] is not None), key=lambda ke: ke[1][6]):
+            if held + need <= self.budget:
+                break
+            held -= e[3].numel() * e[3].element_size()
+            e[3] = None
+            e[2] = 0          # it has to earn a new shadow
+            self.evictions += 1
+        return held + need <= self.budget
 
     def lookup(self, volume, radius):
         """-> (sheared shadow, lvl) when this call should be served from a shadow, else None"""
@@ -446,22 +472,31 @@ class _VolumeShadows:
                 return None
             import weakref
             seen = self.seen
-            ent = [weakref.ref(volume, lambda _r, k=key: seen.pop(k, None)), volume._version, 0, None, lvl]
+            ent = [weakref.ref(volume, lambda _r, k=key: seen.pop(k, None)), volume._version, 0, None, lvl, None, 0]
             self.seen[key] = ent
         ent[2] += 1
+        self.tick += 1
+        ent[6] = self.tick
         if ent[3] is None:
-            if ent[2] < 2:      # a level looked up once (motion_filter's one-edge block) is not worth a re-layout
+            if ent[2] < self.min_uses:   # a level looked up once (motion_filter's one-edge block) is not worth a re-layout
                 return None
             n, h1, w1, h2l, w2l = volume.shape
             lib = _lib.load()
-            vs = torch.empty(n, h2l, w2l, lib.dba_corr_sheared_plane_elems(int(h1), int(w1)), dtype=volume.dtype,
-                             device=volume.device)
+            hw1p = lib.dba_corr_sheared_plane_elems(int(h1), int(w1))
+            if not self._make_room(n * h2l * w2l * hw1p * volume.element_size()):
+                return None
+            vs = torch.empty(n, h2l, w2l, hw1p, dtype=volume.dtype, device=volume.device)
             _lib.check(lib.dba_corr_shear_level(_ptr(volume), _ptr(vs), int(n), int(h1), int(w1), int(h2l), int(w2l),
                                                 ent[4], _stream()), "dba_corr_shear_level")
             ent[3] = vs
+            ent[5] = (torch.cuda.current_stream(), torch.cuda.Event())
+            ent[5][1].record(ent[5][0])
             self.builds += 1
         else:
             self.hits += 1
+            if ent[5] is not None and ent[5][0] != torch.cuda.current_stream():
+                torch.cuda.current_stream().wait_event(ent[5][1])   # built on another stream: order this lookup behind it
+                ent[3].record_stream(torch.cuda.current_stream())
         return ent[3], ent[4]
 
 

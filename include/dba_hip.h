@@ -99,9 +99,12 @@ int dba_ba_reduce(const int64_t *ii, const int64_t *jj, const uint8_t *frame_own
 int dba_ba_schur_select(int form);
 int dba_ba_schur_select_thread(int form); /* the same choice for the calling host thread only (0 = none); the process-wide
                                            * dba_ba_schur_select wins when both are set */
-int dba_ba_schur_auto_form(int N, int M); /* the form (1 or 2) the automatic choice gives a graph of N edges over M frames:
-                                           * the sharded driver asks with the COMPLETE graph's numbers and selects that form
-                                           * on every rank (a rank's share has the same rows per frame, but few edges) */
+int dba_ba_schur_thread_form(void);        /* the calling thread's pin (0 = none): part of the key of a prepared workspace */
+int dba_ba_schur_auto_form(int N, int P); /* the form (1 or 2) the automatic choice gives a graph of N edges over a window of
+                                           * P optimised poses (rows per source frame ~ 1 + N / (P + 1); a function of the
+                                           * graph, not of the video buffer's size): the sharded driver asks with the
+                                           * COMPLETE graph's numbers and pins that form on every rank for the duration of
+                                           * the call (a rank's share has the same rows per frame, but few edges) */
 int dba_ba_schur_generation(void); /* number of dba_ba_schur_select calls so far: tables prepared under another generation
                                     * may lack what the form in force needs (callers of dba_ba_prepared compare it) */
 
@@ -247,6 +250,33 @@ int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int 
 int dba_corr_lookup_pyramid_sheared(const void *const *volumes /* host array of L device ptrs */,
                                     const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2,
                                     int w2, int num_levels, int radius, dba_stream_t stream);
+
+/* Slot-addressed pyramid (the MI355X form of CorrBlock.cat / CorrBlock.__getitem__, dbaf/modules/corr.py:52-60, which the
+ * reference runs as torch.cat / boolean indexing of the WHOLE pyramid on every add_factors / rm_factors,
+ * dbaf/covisible_graph.py:131,166).  A level store holds `capacity` edge volumes; edge e of a lookup lives in slot
+ * slots[e] (device int32 [n]; NULL = slot e).  New edges are built straight into free slots (out_slots[e]: where edge e of
+ * this build goes), removing or re-ordering edges edits the table: no volume is moved. */
+int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, void *const *level_stores,
+                                        const int *out_slots /* device [n] or NULL */, int n, int C, int h1, int w1, int h2,
+                                        int w2, int num_levels, void *scratch, size_t scratch_bytes, dba_stream_t stream);
+int dba_corr_lookup_pyramid_sheared_slots(const void *const *level_stores, const int *slots /* device [n] or NULL */,
+                                          const float *coords_nhw2, void *corr, int n, int h1, int w1, int h2, int w2,
+                                          int num_levels, int radius, dba_stream_t stream);
+int dba_corr_lookup_pyramid_slots(const void *const *level_stores, const int *slots, const float *coords_nhw2, void *corr,
+                                  int n, int h1, int w1, int h2, int w2, int num_levels, int radius, int dtype,
+                                  dba_stream_t stream);
+
+/* The lookup with the reprojection in its prologue: pops.projective_transform (dbaf/geom/projective_ops.py:96-125, via
+ * DepthVideo.reproject, dbaf/depth_video.py:221-229) + CorrBlock.__call__ (dbaf/modules/corr.py:40-50) in ONE launch.
+ * poses [B,7], disps [B,h1,w1], intrinsics_b4 [B,4] (per frame), ii, jj [n] int64; the coordinates are computed per pixel
+ * (csrc/reproj.h: the arithmetic of dba_reproject, bit for bit) and never read back; coords_out [n,h1,w1,2] and valid_out
+ * [n,h1,w1,1] (either may be NULL) receive what dba_reproject would have written -- the caller needs them for the motion
+ * features and the BA targets (dbaf/covisible_graph.py:220-221,237).  corr is bit-identical to dba_reproject followed by
+ * dba_corr_lookup_pyramid_sheared_slots. */
+int dba_corr_lookup_reproject_sheared(const void *const *level_stores, const int *slots, const float *poses,
+                                      const float *disps, const float *intrinsics_b4, const int64_t *ii, const int64_t *jj,
+                                      float *coords_out, float *valid_out, void *corr, int n, int h1, int w1, int h2, int w2,
+                                      int num_levels, int radius, dba_stream_t stream);
 
 /* ONE level of the flow-aligned pyramid looked up with the arguments droid_backends.corr_index_forward receives from the
  * reference's unmodified CorrBlock.__call__ (dbaf/modules/corr.py:40-50): coords [n, 2, h1, w1] ALREADY divided by 2^lvl,
