@@ -189,10 +189,10 @@ def main():
         return st[:npose].view_as(poses0), st[npose + pad:npose + pad + disps0.numel()].view_as(disps0)
 
     refill_pool()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * total)]   # lookup: [4i, 4i+1]; ba (untimed loop): [4i+2, 4i+3]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * max(total, 32))]   # (the extras' loops index up to 24)   # lookup: [4i, 4i+1]; ba (untimed loop): [4i+2, 4i+3]
     for e_ in ev:
         e_.record()   # (creates the underlying hipEvent_t; the lookup's pair is re-recorded by the kernel dispatch itself)
-    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
+    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(max(total, 32) + 1)]
     keep = [None] * ncopies  # the last outputs stay alive: the allocator hands out other lines for the next ones
 
     K_b4 = K[0]

@@ -66,8 +66,11 @@ def test_cat_and_index_edit_the_slot_table_and_lookups_stay_bit_identical(layout
     assert torch.equal(a(c5), fresh(sel)(c5))
     # the pyramid as the reference exposes it (gathered), level by level
     want = fresh(sel)
-    for have, ref in zip(a.corr_pyramid, want.corr_pyramid):
-        assert torch.equal(have, ref)
+    for lvl in range(4):
+        if layout == "sheared":    # (without the plane padding, which nobody writes)
+            assert torch.equal(a.sheared_level(lvl), want.sheared_level(lvl))
+        else:
+            assert torch.equal(a.corr_pyramid[lvl], want.corr_pyramid[lvl])
 
     # no free slot left: the stores grow (one copy), slot numbers stay valid
     big = CorrBlock(fm[ii[:8]][None], fm[jj[:8]][None], layout=layout)

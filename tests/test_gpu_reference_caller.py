@@ -143,13 +143,17 @@ def test_mfma_volume_build_matches_the_recorded_pyramid(dumps):
     fm = _t(dumps.z["fmaps"])
     _, b = dumps.updates()[2]
     ii, jj = _t(b["ii"]), _t(b["jj"])
-    pyr = CorrBlock.build_pyramid(fm[ii][None], fm[jj][None], 4)
-    for lvl in range(4):
-        got = pyr[lvl].cpu().numpy()
-        ref = dumps.pyr12[lvl]
-        ulp = np.spacing(np.abs(ref)).astype(np.float64)
-        d = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / np.maximum(ulp, 2.0 ** -24)
-        assert (d > 0).mean() < 0.01 and d[np.abs(ref.astype(np.float32)) > 0.01].max() <= 1.0, lvl
+    pyr = [p.cpu().numpy() for p in CorrBlock.build_pyramid(fm[ii][None], fm[jj][None], 4)]
+    # level 0: the matrix cores' float accumulation order differs from any sequential one -> identical to the recorded
+    # volume but for rare ties of the final rounding (one fp16 ulp)
+    ref = dumps.pyr12[0]
+    ulp = np.maximum(np.spacing(np.abs(ref)).astype(np.float64), 2.0 ** -24)
+    d = np.abs(pyr[0].astype(np.float64) - ref.astype(np.float64)) / ulp
+    assert (d > 0).mean() < 0.01 and d[np.abs(ref.astype(np.float32)) > 0.01].max() <= 1.0
+    # levels 1-3: the 2x2 average of the ROUNDED level below (F.avg_pool2d on half, corr.py:38), bit for bit
+    orc = _oracle()
+    for lvl in range(1, 4):
+        assert np.array_equal(orc.avg_pool2(pyr[lvl - 1]).view(np.uint16), pyr[lvl].view(np.uint16)), lvl
     # and a block built from the maps answers the recorded lookups to the last bit wherever its volume equals the recorded one
     blk = CorrBlock(fm[ii][None], fm[jj][None])
     look, _ = dumps.updates()[2]
