@@ -395,6 +395,9 @@ def main():
 
         nz = min(max(5, args.steps // 4), max(total - 3, 1))
         refill_pool()
+        from droid_backends import _SHADOWS as _SH
+        uses_default = _SH._min_uses
+        _SH.min_uses = 2     # the steady state of a graph that stands: its levels have their shadows (churn: see below)
         for i in range(3):
             step(i, lookup=zero_edit_lookup)
         torch.cuda.synchronize()
@@ -404,22 +407,25 @@ def main():
         torch.cuda.synchronize()
         tz = time.perf_counter() - tz
         extras["zero_edit_dba_update_per_s"] = round(nz / tz, 1)
+        _SH._min_uses = uses_default
         # what the flow-aligned shadow of the zero-edit route costs: one re-layout pass per level whenever the level
         # tensors are new (every graph change: torch.cat / boolean index create new tensors), and the pyramid's memory
         # a second time
         from droid_backends import _SHADOWS
         if _SHADOWS.enabled:
             lib_ = _lib.load()
+            tmp = [torch.empty(n_loc, h >> lvl, w >> lvl, lib_.dba_corr_sheared_plane_elems(h, w), dtype=torch.float16, device=dev)
+                   for lvl in range(4)]
 
             def reshear():
                 for lvl in range(4):
-                    v = ref_pyr[lvl]
-                    ent = _SHADOWS.seen.get(id(v))
-                    if ent is not None and ent[3] is not None:
-                        lib_.dba_corr_shear_level(v.data_ptr(), ent[3].data_ptr(), n_loc, h, w, h >> lvl, w >> lvl, lvl,
-                                                  torch.cuda.current_stream().cuda_stream)
+                    lib_.dba_corr_shear_level(ref_pyr[lvl].data_ptr(), tmp[lvl].data_ptr(), n_loc, h, w, h >> lvl, w >> lvl, lvl,
+                                              torch.cuda.current_stream().cuda_stream)
             extras["zero_edit_shadow_build_us_per_edge"] = round(timed(reshear, 3) / n_loc, 2)
-            extras["zero_edit_shadow_bytes"] = int(sum(e[3].numel() * 2 for e in _SHADOWS.seen.values() if e[3] is not None))
+            extras["zero_edit_shadow_bytes"] = int(_SHADOWS.bytes_held())
+            extras["zero_edit_shadow_policy"] = "match new tensors' edges by signature" if _SHADOWS.match else (
+                "whole tensor after %d uses" % _SHADOWS.min_uses)
+            del tmp
         extras["zero_edit_lookup_us"] = round(float(np.mean([ev[4 * i].elapsed_time(ev[4 * i + 1]) for i in range(3, 3 + nz)]))
                                               * 1e3, 1)
 
@@ -494,11 +500,17 @@ def main():
             return dict(lookup=look)
 
         del ref_pyr
-        _, order = run_cycles(change_zero_edit, ze_lookup, order0)
-        t_ze, order = run_cycles(change_zero_edit, ze_lookup, order)
-        extras["zero_edit_churn_dba_update_per_s"] = round(nupd / (t_ze * 1e-6), 1)
-        extras["zero_edit_churn_note"] = "graph change every %d updates, shadow (re)builds included; shadow after %d uses" % (
-            nupd, _SHADOWS.min_uses)
+        order = order0
+        for pol, mt in (("default", False), ("match", True)):
+            _SH.match = mt
+            _, order = run_cycles(change_zero_edit, ze_lookup, order)
+            t_ze, order = run_cycles(change_zero_edit, ze_lookup, order)
+            extras["zero_edit_churn_dba_update_per_s" + ("" if pol == "default" else "_match")] = round(nupd / (t_ze * 1e-6), 1)
+        _SH.match = os.environ.get("DBA_ZERO_EDIT_SHADOW_MATCH", "0") == "1"
+        extras["zero_edit_churn_note"] = ("graph change every %d updates: the reference's own torch.cat / index of its level "
+                                          "tensors + shadow work included; default = a new tensor's shadow after %d uses (never, "
+                                          "at this cadence: the direct kernel serves), _match = DBA_ZERO_EDIT_SHADOW_MATCH=1: only "
+                                          "unseen edges are re-laid out" % (nupd, _SH.min_uses))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / max(args.steps, 1)

@@ -50,18 +50,22 @@ struct ShReproj {
 // 64 contiguous halves of plane (dy, dx).
 __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restrict__ V,
                                                          _Float16 *__restrict__ Vs, int h1, int w1, int h2l,
-                                                         int w2l, int lvl, int HW1p) {
+                                                         int w2l, int lvl, int HW1p, const int *__restrict__ src_idx,
+                                                         const int *__restrict__ dst_slots) {
   extern __shared__ _Float16 tile[];  // [64][w2l + 2]
   const int pitch = w2l + 2;
   const int x0 = blockIdx.x * 64;
   const int ty = blockIdx.y;
   const int ey = blockIdx.z;  // n * h1 + y1
   const int y1 = ey % h1, e = ey / h1;
+  // (src_idx / dst_slots: edge e of this pass is edge src_idx[e] of V and goes to slot dst_slots[e] of Vs -- the
+  // slot-addressed shadows of droid_backends.corr_index_forward re-lay only the edges they have not seen)
+  const int es = src_idx ? src_idx[e] : e, ed = dst_slots ? dst_slots[e] : e;
   const int nx = min(64, w1 - x0);
   const size_t plane = (size_t)h2l * w2l;
   for (int idx = threadIdx.x; idx < nx * w2l; idx += blockDim.x) {
     const int xi = idx / w2l, tx = idx - xi * w2l;
-    tile[xi * pitch + tx] = V[((size_t)ey * w1 + x0 + xi) * plane + (size_t)ty * w2l + tx];
+    tile[xi * pitch + tx] = V[(((size_t)es * h1 + y1) * w1 + x0 + xi) * plane + (size_t)ty * w2l + tx];
   }
   __syncthreads();
   int dy = ty - (y1 >> lvl);
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restr
   for (int idx = threadIdx.x; idx < nx * w2l; idx += blockDim.x) {
     const int dx = idx / nx, xi = idx - dx * nx;
     const int tx = (((x0 + xi) >> lvl) + dx) % w2l;
-    Vs[(((size_t)e * h2l + dy) * w2l + dx) * HW1 + (size_t)y1 * w1 + x0 + xi] = tile[xi * pitch + tx];
+    Vs[(((size_t)ed * h2l + dy) * w2l + dx) * HW1 + (size_t)y1 * w1 + x0 + xi] = tile[xi * pitch + tx];
   }
 }
 
@@ -925,6 +929,11 @@ int dba_corr_sheared_plane_elems(int h1, int w1) {
 
 int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int h1, int w1, int h2l, int w2l,
                          int lvl, dba_stream_t stream) {
+  return dba_corr_shear_level_slots(ref_level, sheared_level, nullptr, nullptr, n, h1, w1, h2l, w2l, lvl, stream);
+}
+
+int dba_corr_shear_level_slots(const void *ref_level, void *sheared_store, const int *src_idx, const int *dst_slots, int n,
+                               int h1, int w1, int h2l, int w2l, int lvl, dba_stream_t stream) {
   if (n < 0 || h1 <= 0 || w1 <= 0 || h2l <= 0 || w2l <= 0 || lvl < 0) return DBA_ERR_ARG;
   if (n == 0) return DBA_OK;
   if ((long)n * h1 > 2147483647L / 1) return DBA_ERR_ARG;
@@ -932,8 +941,8 @@ int dba_corr_shear_level(const void *ref_level, void *sheared_level, int n, int 
   if (lds > 64 * 1024) return DBA_ERR_UNSUPPORTED;
   dim3 grid((w1 + 63) / 64, h2l, n * h1);
   hipLaunchKernelGGL(corr_shear_kernel, grid, dim3(256), lds, (hipStream_t)stream,
-                     static_cast<const _Float16 *>(ref_level), static_cast<_Float16 *>(sheared_level), h1, w1, h2l,
-                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1));
+                     static_cast<const _Float16 *>(ref_level), static_cast<_Float16 *>(sheared_store), h1, w1, h2l,
+                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1), src_idx, dst_slots);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -1028,13 +1037,20 @@ int dba_corr_lookup_reproject_sheared(const void *const *volumes, const int *slo
 
 int dba_corr_lookup_level_sheared(const void *sheared_level, const float *coords_n2hw_scaled, void *corr, int n, int h1,
                                   int w1, int h2, int w2, int lvl, int radius, dba_stream_t stream) {
+  return dba_corr_lookup_level_sheared_slots(sheared_level, nullptr, coords_n2hw_scaled, corr, n, h1, w1, h2, w2, lvl, radius,
+                                             stream);
+}
+
+int dba_corr_lookup_level_sheared_slots(const void *sheared_level, const int *slots, const float *coords_n2hw_scaled,
+                                        void *corr, int n, int h1, int w1, int h2, int w2, int lvl, int radius,
+                                        dba_stream_t stream) {
   if (n < 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || lvl < 0 || lvl >= SH_MAX_LEVELS) return DBA_ERR_ARG;
   if (radius != 3) return DBA_ERR_UNSUPPORTED;
   if (n == 0) return DBA_OK;
   if (!sheared_level || !coords_n2hw_scaled || !corr || (h2 >> lvl) < 1 || (w2 >> lvl) < 1) return DBA_ERR_ARG;
   ShLevels L;
   for (int l = 0; l < SH_MAX_LEVELS; l++) L.vol[l] = (l == lvl) ? static_cast<const _Float16 *>(sheared_level) : nullptr;
-  return lookup_sheared_launch(L, coords_n2hw_scaled, corr, n, h1, w1, h2, w2, lvl, 1, 3, stream);
+  return lookup_sheared_launch(L, coords_n2hw_scaled, corr, n, h1, w1, h2, w2, lvl, 1, 3, stream, slots);
 }
 
 }  // extern "C"

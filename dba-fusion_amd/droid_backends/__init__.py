@@ -405,31 +405,93 @@ def _vol_dtype(t):
     raise RuntimeError("corr_index: volume dtype %s not supported on the MI355X path (half / float)" % t.dtype)
 
 
+class _ShadowStore:
+    """flow-aligned shadow volumes of ONE pyramid level shape on one device: a slot-addressed store (like CorrBlock's), the
+    sampled signature of the edge each slot holds, and who refers to it"""
+
+    def __init__(self, lvl, h1, w1, h2l, w2l, dtype, device, nsig):
+        self.lvl, self.h1, self.w1, self.h2l, self.w2l = lvl, h1, w1, h2l, w2l
+        self.dtype, self.device = dtype, device
+        self.hw1p = _lib.load().dba_corr_sheared_plane_elems(int(h1), int(w1))
+        self.store = None                    # [cap, h2l, w2l, hw1p]
+        self.sig = None                      # [cap, nsig] int16: sampled elements of the edge in the slot
+        self.ref = []                        # per slot: live tensors that use it
+        self.filled = []                     # per slot: holds an edge (its signature is valid)
+        self.last = []                       # per slot: tick of the last use (eviction order among unreferenced slots)
+        self.nsig = nsig
+        self.event = None                    # (stream, event) of the last re-layout pass
+
+    def slot_bytes(self):
+        return self.h2l * self.w2l * self.hw1p * 2
+
+    def bytes_held(self):
+        return 0 if self.store is None else self.store.numel() * self.store.element_size()
+
+    def capacity(self):
+        return 0 if self.store is None else int(self.store.shape[0])
+
+    def grow(self, cap):
+        new = torch.empty(cap, self.h2l, self.w2l, self.hw1p, dtype=self.dtype, device=self.device)
+        sig = torch.zeros(cap, self.nsig, dtype=torch.int16, device=self.device)
+        old = self.capacity()
+        if old:
+            new[:old].copy_(self.store)
+            sig[:old].copy_(self.sig)
+        self.store, self.sig = new, sig
+        self.ref += [0] * (cap - old)
+        self.filled += [False] * (cap - old)
+        self.last += [0] * (cap - old)
+
+
 class _VolumeShadows:
     """Flow-aligned shadows of reference-layout pyramid levels, for callers that run the reference's OWN CorrBlock
     (dbaf/modules/corr.py:24-50, no import swapped) against this module.
 
     In the reference layout [n, y1, x1, y2, x2] a lookup touches 512 different cache lines per wave and level (0.08 of the
     HBM roofline); in the flow-aligned layout of csrc/corr_sheared.hip it streams (0.47).  CorrBlock.__call__ looks the
-    SAME level tensors up once per update() for as long as the graph stands, so the second time a level is asked about a
-    shadow of it is built (one pass of corr_shear_kernel: the level read and written once) and every later lookup is served
-    from the shadow -- bit for bit the same result.  A shadow belongs to one tensor object at one `_version`: it dies with
-    the tensor (torch.cat in add_factors and the boolean index of rm_factors create new ones) or with an in-place write.
-    Cost: the memory of the pyramid once more, and one re-layout pass per graph change (reported by bench.py as
-    extra.zero_edit_shadow_build_us_per_edge).  DBA_ZERO_EDIT_SHADOW=0 switches it off."""
+    SAME level tensors up once per update() for as long as the graph stands, so a level that keeps being asked about gets
+    a shadow (one pass of corr_shear_kernel over the edges that need it) and later lookups are served from it -- bit for bit
+    the same result.  The shadows of a level shape live in ONE slot-addressed store; a tensor's entry is its slot table.
+
+    What a keyframe does to this: torch.cat in add_factors and the boolean index in rm_factors hand over NEW tensors, whose
+    edges are mostly the old ones.  Two policies:
+      * default: a new tensor starts over; its shadow is built when it has been looked up `min_uses` times (13: the
+        re-layout of a whole 96-edge window costs what 13 lookups save, so a window that changes every 6 updates never
+        pays for one -- the ski-rental rule; DBA_ZERO_EDIT_SHADOW_USES);
+      * DBA_ZERO_EDIT_SHADOW_MATCH=1 (`match`): the edges of a new tensor are matched to the shadows already held by a
+        SIGNATURE -- 128 elements sampled per edge and level, compared exactly -- and only the unmatched (new) edges are
+        re-laid out, at the tensor's second use.  A matched edge is trusted to be the same volume: true for anything
+        cat / index produce, and for two different correlation volumes to agree in 128 sampled half values is not a
+        practical event, but it is a sampled comparison, not a proof -- hence opt-in.  In-place writes are never matched
+        (the tensor's entry is dropped and its edges are re-laid out).
+    Memory: the stores double the pyramid; a byte budget (DBA_ZERO_EDIT_SHADOW_BYTES, default 16 GiB) bounds them, slots no
+    live tensor refers to are reused least-recently-used first.  DBA_ZERO_EDIT_SHADOW=0 switches everything off."""
+
+    NSIG = 128
 
     def __init__(self):
         import os
         self.enabled = os.environ.get("DBA_ZERO_EDIT_SHADOW", "1") != "0"
-        self.seen = {}     # id(volume) -> [weakref, version, uses, shadow or None, lvl, build event, last use]
-        self.builds = 0
-        self.hits = 0
-        self.evictions = 0
-        self.tick = 0
-        # the shadows double the pyramid's memory: a budget (bytes; DBA_ZERO_EDIT_SHADOW_BYTES, default 16 GiB -- three
-        # 96-edge pyramids at 64x64), least recently used shadows go first
+        self.match = os.environ.get("DBA_ZERO_EDIT_SHADOW_MATCH", "0") == "1"
+        uses = os.environ.get("DBA_ZERO_EDIT_SHADOW_USES")
+        self._min_uses = max(2, int(uses)) if uses else None
         self.budget = int(float(os.environ.get("DBA_ZERO_EDIT_SHADOW_BYTES", 16 * 2 ** 30)))
-        self.min_uses = max(2, int(os.environ.get("DBA_ZERO_EDIT_SHADOW_USES", "2")))
+        self.seen = {}      # id(volume) -> entry (see _entry)
+        self.stores = {}    # (device, dtype, lvl, h1, w1) -> _ShadowStore
+        self.builds = 0     # re-layout passes
+        self.built_edges = 0
+        self.matched_edges = 0
+        self.hits = 0
+        self.tick = 0
+        self._sig_idx = {}
+
+    @property
+    def min_uses(self):
+        return self._min_uses if self._min_uses is not None else (2 if self.match else 13)
+
+    @min_uses.setter
+    def min_uses(self, v):
+        self._min_uses = None if v is None else max(2, int(v))
 
     @staticmethod
     def level_of(volume):
@@ -443,61 +505,115 @@ class _VolumeShadows:
         return None
 
     def bytes_held(self):
-        return sum(e[3].numel() * e[3].element_size() for e in self.seen.values() if e[3] is not None)
+        return sum(st.bytes_held() for st in self.stores.values())
 
-    def _make_room(self, need):
-        if need > self.budget:
-            return False
-        held = self.bytes_held()
-        for key, e in sorted(((k, e) for k, e in self.seen.items() if e[3] is not None), key=lambda ke: ke[1][6]):
-            if held + need <= self.budget:
-                break
-            held -= e[3].numel() * e[3].element_size()
-            e[3] = None
-            e[2] = 0          # it has to earn a new shadow
-            self.evictions += 1
-        return held + need <= self.budget
+    def _release(self, key):
+        ent = self.seen.pop(key, None)
+        if ent is not None and ent["slots_host"] is not None:
+            st = ent["store"]
+            for sl in ent["slots_host"]:
+                st.ref[sl] -= 1
+
+    def _signature(self, volume):
+        """[n, NSIG] int16: the elements of every edge at NSIG fixed positions spread over its level volume"""
+        n = volume.shape[0]
+        per = volume[0].numel()
+        key = (per, volume.device)
+        idx = self._sig_idx.get(key)
+        if idx is None:
+            k = torch.arange(self.NSIG, dtype=torch.int64)
+            idx = ((k * 2654435761 + 97) % per).to(volume.device)
+            self._sig_idx[key] = idx
+        return volume.reshape(n, per).index_select(1, idx).view(torch.int16)
+
+    def _slots_for(self, st, need):
+        """`need` slots no live tensor refers to: empty ones first, then the least recently used; grows the store inside
+        the byte budget (old and new store coexist while one is copied into the other); None if there is no room"""
+        free = [s for s in range(st.capacity()) if st.ref[s] == 0]
+        if len(free) < need:
+            short = need - len(free)
+            want = st.capacity() + max(short, st.capacity() // 4)
+            others = self.bytes_held() - st.bytes_held()
+            cap = min(want, int((self.budget - others) // st.slot_bytes()))
+            if cap < st.capacity() + short:
+                return None
+            st.grow(cap)
+            free = [s for s in range(st.capacity()) if st.ref[s] == 0]
+        free.sort(key=lambda s: (st.filled[s], st.last[s]))
+        return free[:need]
 
     def lookup(self, volume, radius):
-        """-> (sheared shadow, lvl) when this call should be served from a shadow, else None"""
+        """-> (shadow store, slots int32 [n] on the device, lvl) when this call should be served from shadows, else None"""
         if not self.enabled or int(radius) != 3 or volume.dtype != torch.float16 or volume.dim() != 5:
             return None
         key = id(volume)
         ent = self.seen.get(key)
-        if ent is not None and (ent[0]() is not volume or ent[1] != volume._version):
-            ent = None
+        if ent is not None and (ent["ref"]() is not volume or ent["version"] != volume._version):
+            self._release(key)        # another object behind a recycled id, or written in place: nothing of it is trusted
+            ent, fresh_object = None, False
+        else:
+            fresh_object = ent is None
         if ent is None:
             lvl = self.level_of(volume)
             if lvl is None:
                 return None
             import weakref
-            seen = self.seen
-            ent = [weakref.ref(volume, lambda _r, k=key: seen.pop(k, None)), volume._version, 0, None, lvl, None, 0]
+            ent = dict(ref=weakref.ref(volume, lambda _r, k=key: self._release(k)), version=volume._version, uses=0,
+                       slots=None, slots_host=None, store=None, lvl=lvl, matchable=fresh_object)
             self.seen[key] = ent
-        ent[2] += 1
+        ent["uses"] += 1
         self.tick += 1
-        ent[6] = self.tick
-        if ent[3] is None:
-            if ent[2] < self.min_uses:   # a level looked up once (motion_filter's one-edge block) is not worth a re-layout
+        n, h1, w1, h2l, w2l = (int(x) for x in volume.shape)
+        if ent["slots"] is None:
+            if ent["uses"] < self.min_uses:   # a level looked up once (motion_filter's one-edge block) is not worth a re-layout
                 return None
-            n, h1, w1, h2l, w2l = volume.shape
-            lib = _lib.load()
-            hw1p = lib.dba_corr_sheared_plane_elems(int(h1), int(w1))
-            if not self._make_room(n * h2l * w2l * hw1p * volume.element_size()):
-                return None
-            vs = torch.empty(n, h2l, w2l, hw1p, dtype=volume.dtype, device=volume.device)
-            _lib.check(lib.dba_corr_shear_level(_ptr(volume), _ptr(vs), int(n), int(h1), int(w1), int(h2l), int(w2l),
-                                                ent[4], _stream()), "dba_corr_shear_level")
-            ent[3] = vs
-            ent[5] = (torch.cuda.current_stream(), torch.cuda.Event())
-            ent[5][1].record(ent[5][0])
-            self.builds += 1
+            skey = (volume.device, volume.dtype, ent["lvl"], h1, w1)
+            st = self.stores.get(skey)
+            if st is None:
+                st = self.stores[skey] = _ShadowStore(ent["lvl"], h1, w1, h2l, w2l, volume.dtype, volume.device, self.NSIG)
+            sig = self._signature(volume)
+            mapping = [-1] * n
+            if self.match and ent["matchable"] and st.capacity():
+                filled = torch.tensor(st.filled, device=volume.device)
+                eq = (sig[:, None, :] == st.sig[None, :, :]).all(-1) & filled[None, :]          # [n, cap]
+                hit = eq.any(1)
+                first = eq.float().argmax(1)
+                mapping = [int(s) if h else -1 for s, h in zip(first.tolist(), hit.tolist())]   # (one small D2H per new tensor)
+            todo = [e for e in range(n) if mapping[e] < 0]
+            if todo:
+                for s_ in set(m for m in mapping if m >= 0):
+                    st.ref[s_] += 1                     # (held while slots are chosen: a matched slot must not be handed out)
+                slots_new = self._slots_for(st, len(todo))
+                for s_ in set(m for m in mapping if m >= 0):
+                    st.ref[s_] -= 1
+                if slots_new is None:
+                    return None                          # over budget: the direct kernel serves this tensor
+                src = torch.tensor(todo, dtype=torch.int32, device=volume.device)
+                dst = torch.tensor(slots_new, dtype=torch.int32, device=volume.device)
+                _lib.check(_lib.load().dba_corr_shear_level_slots(_ptr(volume), _ptr(st.store), _ptr(src), _ptr(dst),
+                                                                   len(todo), h1, w1, h2l, w2l, ent["lvl"], _stream()),
+                           "dba_corr_shear_level_slots")
+                st.sig.index_copy_(0, dst.long(), sig.index_select(0, src.long()))
+                st.event = (torch.cuda.current_stream(), torch.cuda.Event())
+                st.event[1].record(st.event[0])
+                for e, sl in zip(todo, slots_new):
+                    mapping[e] = sl
+                    st.filled[sl] = True
+                self.builds += 1
+                self.built_edges += len(todo)
+            self.matched_edges += n - len(todo)
+            for sl in mapping:
+                st.ref[sl] += 1
+            ent["slots_host"], ent["store"] = mapping, st
+            ent["slots"] = torch.tensor(mapping, dtype=torch.int32, device=volume.device)
         else:
             self.hits += 1
-            if ent[5] is not None and ent[5][0] != torch.cuda.current_stream():
-                torch.cuda.current_stream().wait_event(ent[5][1])   # built on another stream: order this lookup behind it
-                ent[3].record_stream(torch.cuda.current_stream())
-        return ent[3], ent[4]
+        st = ent["store"]
+        for sl in ent["slots_host"]:
+            st.last[sl] = self.tick
+        if st.event is not None and st.event[0] != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(st.event[1])   # re-laid out on another stream: order this lookup behind it
+        return st.store, ent["slots"], ent["lvl"]
 
 
 _SHADOWS = _VolumeShadows()
@@ -512,10 +628,10 @@ def corr_index_forward(volume, coords, radius):
     corr = torch.empty(n, 2 * r + 1, 2 * r + 1, h1, w1, dtype=volume.dtype, device=volume.device)
     sh = _SHADOWS.lookup(volume, r) if n > 0 else None
     if sh is not None:
-        vs, lvl = sh
-        _lib.check(_lib.load().dba_corr_lookup_level_sheared(_ptr(vs), _ptr(coords), _ptr(corr), int(n), int(h1), int(w1),
-                                                             int(h1), int(w1), lvl, r, _stream()),
-                   "dba_corr_lookup_level_sheared")
+        store, slots, lvl = sh
+        _lib.check(_lib.load().dba_corr_lookup_level_sheared_slots(_ptr(store), _ptr(slots), _ptr(coords), _ptr(corr), int(n),
+                                                                   int(h1), int(w1), int(h1), int(w1), lvl, r, _stream()),
+                   "dba_corr_lookup_level_sheared_slots")
         return [corr]
     _lib.check(_lib.load().dba_corr_index_forward(_ptr(volume), _ptr(coords), _ptr(corr), int(n), int(h1), int(w1),
                                                   int(h2), int(w2), r, _vol_dtype(volume), _stream()),

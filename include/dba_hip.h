@@ -286,6 +286,16 @@ int dba_corr_lookup_reproject_sheared(const void *const *level_stores, const int
 int dba_corr_lookup_level_sheared(const void *sheared_level, const float *coords_n2hw_scaled, void *corr, int n, int h1,
                                   int w1, int h2, int w2, int lvl, int radius, dba_stream_t stream);
 
+/* the same on a slot-addressed shadow store (slots[e]: where edge e of the call lives), and the re-layout pass that fills
+ * it: edge e of the pass is edge src_idx[e] of ref_level and goes to slot dst_slots[e] (either NULL: e).  Used by the
+ * adapter when it matches the edges of a NEW reference-layout tensor (torch.cat / boolean index of the previous one:
+ * dbaf/modules/corr.py:52-60) to shadows it already holds and re-lays only the edges it has not seen. */
+int dba_corr_lookup_level_sheared_slots(const void *sheared_store, const int *slots, const float *coords_n2hw_scaled,
+                                        void *corr, int n, int h1, int w1, int h2, int w2, int lvl, int radius,
+                                        dba_stream_t stream);
+int dba_corr_shear_level_slots(const void *ref_level, void *sheared_store, const int *src_idx, const int *dst_slots, int n,
+                               int h1, int w1, int h2l, int w2l, int lvl, dba_stream_t stream);
+
 /* corr_index_backward (src/correlation_kernels.cu:73-124,157-185): adjoint of the lookup;
  * volume_grad [n,h1,w1,h2,w2] must be zero-initialised by the caller. f32 only. */
 int dba_corr_index_backward(const float *coords, const float *corr_grad, float *volume_grad, int n,

@@ -136,3 +136,71 @@ def test_lookup_with_the_reprojection_in_its_launch(h, w, lookup_kernel):
     assert torch.equal(coords2, c3) and torch.equal(valid2, v3) and torch.equal(out2, corr(c3))
     sel = torch.cat([torch.nonzero(keep).view(-1), torch.arange(2, device="cuda")])
     assert torch.equal(out2, out[:, sel])
+
+
+def test_zero_edit_shadows_match_the_edges_of_new_tensors():
+    """droid_backends.corr_index_forward under DBA_ZERO_EDIT_SHADOW_MATCH: the level tensors a graph change creates
+    (torch.cat / boolean index of the old ones, /root/reference/dbaf/modules/corr.py:52-60) find the shadows of the edges
+    they kept; only unseen edges are re-laid out; an in-place write is never matched; results equal the direct kernel"""
+    import droid_backends
+    from droid_backends import _SHADOWS
+    from dbaf_amd.corr import CorrBlock
+    h, w = 24, 40
+    fm = _fmaps(6, 32, h, w, 12)
+    ii = torch.tensor([0, 1, 1, 2, 2, 3, 3, 4, 4, 5], device="cuda")
+    jj = torch.tensor([1, 0, 2, 1, 3, 2, 4, 3, 5, 4], device="cuda")
+    pyr = CorrBlock.build_pyramid(fm[ii][None], fm[jj][None], 4)
+    saved = (_SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses)
+
+    def look(levels, c):
+        cp = c[0].permute(0, 3, 1, 2).contiguous()
+        return [droid_backends.corr_index_forward(levels[l], cp / 2 ** l, 3)[0] for l in range(4)]
+
+    def direct(levels, c):
+        _SHADOWS.enabled = False
+        try:
+            return look(levels, c)
+        finally:
+            _SHADOWS.enabled = True
+
+    try:
+        _SHADOWS.enabled, _SHADOWS.match = True, True
+        _SHADOWS.min_uses = 2
+        a = [p[:7].contiguous() for p in pyr]
+        c7 = _coords(7, h, w, 1)
+        want = direct(a, c7)
+        e0 = _SHADOWS.built_edges
+        for _ in range(3):
+            for g, r in zip(look(a, c7), want):
+                assert torch.equal(g, r)
+        assert _SHADOWS.built_edges == e0 + 4 * 7
+        # add_factors: cat of three new edges -> new tensors; their second lookup re-lays out 3 edges per level, not 10
+        b = [torch.cat([x, p[7:]], 0) for x, p in zip(a, pyr)]
+        del a
+        c10 = _coords(10, h, w, 2)
+        want = direct(b, c10)
+        e1, m1 = _SHADOWS.built_edges, _SHADOWS.matched_edges
+        for _ in range(3):
+            for g, r in zip(look(b, c10), want):
+                assert torch.equal(g, r)
+        assert _SHADOWS.built_edges == e1 + 4 * 3 and _SHADOWS.matched_edges == m1 + 4 * 7
+        # rm_factors: boolean index -> new tensors, every edge known
+        mask = torch.tensor([1, 0, 1, 1, 0, 1, 1, 1, 0, 1], dtype=torch.bool, device="cuda")
+        cc = [x[mask] for x in b]
+        del b
+        c7b = _coords(7, h, w, 3)
+        want = direct(cc, c7b)
+        e2 = _SHADOWS.built_edges
+        for _ in range(2):
+            for g, r in zip(look(cc, c7b), want):
+                assert torch.equal(g, r)
+        assert _SHADOWS.built_edges == e2
+        # an in-place write: the tensor's entry is dropped, nothing is matched, the new content is what comes back
+        cc[0][2].mul_(0.5)
+        want = direct(cc, c7b)
+        for _ in range(3):
+            for g, r in zip(look(cc, c7b), want):
+                assert torch.equal(g, r)
+        assert _SHADOWS.built_edges == e2 + 7
+    finally:
+        _SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses = saved

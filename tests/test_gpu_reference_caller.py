@@ -40,20 +40,36 @@ def _sha(t):
     return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
 
 
-def test_recorded_corr_index_forward_calls_bit_identical(dumps):
+@pytest.mark.parametrize("policy", ["direct", "shadow_at_second_use", "match"])
+def test_recorded_corr_index_forward_calls_bit_identical(dumps, policy):
+    """the 20 recorded calls in order, on one tensor object per (graph state, level) like the caller holds them: through
+    the direct kernel, through shadows built at a tensor's second use, and with the edges of the tensors the graph changes
+    created (cat of 4 edges, boolean index) matched to the shadows already held"""
     import droid_backends
     from droid_backends import _SHADOWS
-    vols = {}   # one tensor object per (state, level), as the caller holds them between graph changes
-    b0, h0 = _SHADOWS.builds, _SHADOWS.hits
-    for k, c in dumps.calls("corr_index_forward"):
-        key = (int(c["volume_state"]), int(c["lvl"]))
-        if key not in vols:
-            vols[key] = _t(dumps.volume(c))
-        out, = droid_backends.corr_index_forward(vols[key], _t(c["coords"]), 3)
-        assert out.shape == (vols[key].shape[0], 7, 7, 16, 16) and out.dtype == torch.float16
-        assert _sha(out) == str(c["out_sha256"]), "recorded lookup call %d" % k
-    if _SHADOWS.enabled:     # state 1 is looked up twice per level: the second time from a shadow
-        assert _SHADOWS.builds > b0 and _SHADOWS.hits >= h0
+    saved = (_SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses)
+    _SHADOWS.enabled, _SHADOWS.match = policy != "direct", policy == "match"
+    _SHADOWS.min_uses = 2
+    try:
+        vols = {}
+        b0, e0, m0 = _SHADOWS.builds, _SHADOWS.built_edges, _SHADOWS.matched_edges
+        for k, c in dumps.calls("corr_index_forward"):
+            key = (int(c["volume_state"]), int(c["lvl"]))
+            if key not in vols:
+                vols[key] = _t(dumps.volume(c))
+            out, = droid_backends.corr_index_forward(vols[key], _t(c["coords"]), 3)
+            assert out.shape == (vols[key].shape[0], 7, 7, 16, 16) and out.dtype == torch.float16
+            assert _sha(out) == str(c["out_sha256"]), "recorded lookup call %d (%s)" % (k, policy)
+        if policy == "shadow_at_second_use":
+            # states 1 (8 edges: updates 0, 1) and 2 (8 edges: updates 3, 4) are looked up twice per level, state 0 once
+            assert _SHADOWS.builds == b0 + 8 and _SHADOWS.built_edges == e0 + 64
+        if policy == "match":
+            # state 2's tensors are new objects holding 8 of the 12 edges -- but state 0's were looked up only once and
+            # never got shadows, so what can match are state 1's 8 edges: the 4 that survive rm_factors are found, the 4
+            # edges of the second add_factors are re-laid out
+            assert _SHADOWS.built_edges == e0 + 4 * (8 + 4) and _SHADOWS.matched_edges == m0 + 4 * 4
+    finally:
+        _SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses = saved
 
 
 @pytest.mark.parametrize("layout", ["sheared", "reference"])
