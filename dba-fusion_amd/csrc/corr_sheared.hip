@@ -895,14 +895,327 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
   }
 }
 
+
+// =====================================================================================================================
+// Lookup, third form ("pair"): the resident form with TWO ADJACENT PIXELS PER LANE.
+//
+//   * a wave = 128 consecutive pixels of the flattened (y1, x1) index (two aligned 128-byte lines of every plane); lane l
+//     owns the pixels 2 l and 2 l + 1 and keeps their taps in ONE register per tap column -- low half: pixel 2 l, high half:
+//     pixel 2 l + 1 -- so that the blend is `v_pk_*_f16` over PIXELS with per-pixel packed weights: 49 packed operations
+//     per tap row and pixel pair (the channel-pair forms need 28 + 3 re-alignments per pixel), and an output channel
+//     leaves as ONE 4-byte store per lane (256 bytes per instruction): half the store instructions per pixel of the
+//     resident form, 0.4 of the streaming form's;
+//   * everything per wave (coordinates -> window origins -> union -> addresses) is paid once per 128 pixels;
+//   * the union of the 128 pixels' windows is held in LDS (exec-masked LDS-DMA of the 16-byte pieces some 8-pixel group
+//     needs), lanes walk their own tap rows in lock-step; lanes far from the others go to later passes, then to a gather.
+// Needs an even map width and an even number of 64-pixel strips per plane (64x64 and 48x64 maps; others use the other
+// forms).  Arithmetic: each half of a packed operation rounds like the scalar operation -- identical to the other forms
+// and to the reference, bit for bit (same order w00, w01, w10, w11: correlation_kernels.cu:55-65).
+#ifndef SH3_LCAP_CFG
+#define SH3_LCAP_CFG 288
+#endif
+constexpr int SH3_LCAP = SH3_LCAP_CFG;                 // lines (128 B) of staging per wave
+constexpr int SH3_WAVE_BYTES = SH3_LCAP * 128 + 2048;  // + 8 zero line pairs
+constexpr int SH3_MAXPASS = 3;
+
+template <bool IS_MIN>
+__device__ __forceinline__ int group4_minmax(int x) {  // result in all 4 lanes of the quad
+  x = dpp_minmax<0xB1, 0xf, IS_MIN>(x);  // quad_perm [1,0,3,2]
+  x = dpp_minmax<0x4E, 0xf, IS_MIN>(x);  // quad_perm [2,3,0,1]
+  return x;
+}
+
+template <int R>
+__global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
+    ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  static_assert(WN == 8, "written for radius 3");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int HW1 = h1 * w1;
+  const int pstrips = HW1p >> 7;  // 128-pixel strips per edge
+  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
+  const int sid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);  // XCD-contiguous order (see the streaming form)
+  const int lvl = blockIdx.y + lvl0;
+  const int slvl = (cflags & 2) ? 0 : lvl;
+  const bool cplanar = (cflags & 1) != 0;
+  if (sid >= n * pstrips) return;
+  const int e = sid / pstrips, p0 = (sid - e * pstrips) << 7;
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+  const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
+  const float inv_w2l = 1.0f / (float)w2l, inv_h2l = 1.0f / (float)h2l;
+
+  unsigned char *const stage = smem;                    // [row][nxa][128 pixels] halves
+  unsigned char *const zeros = stage + SH3_LCAP * 128;  // 8 line pairs of zeros
+  {
+    u4v z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u4v *>(zeros + lane * 16) = z;
+    *reinterpret_cast<u4v *>(zeros + 1024 + lane * 16) = z;
+  }
+
+  // ---- this lane's two pixels (same row: w1 is even and pA is even)
+  const int pA = p0 + 2 * lane;
+  const bool active = pA < HW1;  // (HW1 is even: both pixels or none)
+  const int pc = min(pA, HW1 - 2);
+  int y1 = (int)(((float)pc + 0.5f) * inv_w1);
+  int x1 = pc - y1 * w1;
+  if (x1 < 0) { y1--; x1 += w1; }
+  if (x1 >= w1) { y1++; x1 -= w1; }
+  float2 cA, cB;
+  if (cflags & 4) {  // the reprojection taken along (ShReproj)
+    const int ix = (int)RP.ii[e];
+    const float2 d2 = *reinterpret_cast<const float2 *>(RP.disps + (size_t)ix * HW1 + pc);
+    const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);  // uniform
+    float okA, okB;
+    cA = reproject_pixel(G, (float)x1, (float)y1, d2.x, okA);
+    cB = reproject_pixel(G, (float)(x1 + 1), (float)y1, d2.y, okB);
+    if (lvl == 0 && active) {
+      if (RP.coords_out) *reinterpret_cast<float4 *>(RP.coords_out + (size_t)e * HW1 + pA) = make_float4(cA.x, cA.y, cB.x, cB.y);
+      if (RP.valid_out) *reinterpret_cast<float2 *>(RP.valid_out + (size_t)e * HW1 + pA) = make_float2(okA, okB);
+    }
+  } else if (!cplanar) {
+    const float4 c4 = *reinterpret_cast<const float4 *>(coords + (size_t)e * HW1 + pc);
+    cA = make_float2(c4.x, c4.y);
+    cB = make_float2(c4.z, c4.w);
+  } else {
+    cA = sh_coord(coords, true, (size_t)e, HW1, pc);
+    cB = sh_coord(coords, true, (size_t)e, HW1, pc + 1);
+  }
+  const ShPixel PA = sh_pixel<R>(cA, lvl, x1, y1, h2l, w2l, active, slvl);
+  const ShPixel PB = sh_pixel<R>(cB, lvl, x1 + 1, y1, h2l, w2l, active, slvl);
+  const bool tA = PA.touches, tB = PB.touches, tany = tA || tB;
+
+  _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;  // this edge, this level: [49][HW1]
+  const size_t rowstride = (size_t)w2l * HW1p;
+  const unsigned rowbytes = (unsigned)(2 * rowstride);
+  const int es = slots ? slots[e] : e;
+  const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
+  const bool can_stream = ((size_t)h2l * rowbytes < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
+  constexpr unsigned OOR = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, can_stream ? (int)((unsigned)h2l * rowbytes) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout =
+      __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, can_stream ? (int)(2u * RD * RD * (unsigned)HW1) : 0, 0x00020000);
+
+  // pixel-packed weights: low half pixel A, high half pixel B
+  h2v W00, W01, W10, W11;
+  W00.x = PA.h00; W00.y = PB.h00;
+  W01.x = PA.h01; W01.y = PB.h01;
+  W10.x = PA.h10; W10.y = PB.h10;
+  W11.x = PA.h11; W11.y = PB.h11;
+
+  // validity of the taps (image border), per pixel: columns i in [ia, ib), rows j in [ja, jb); as packed keep masks
+  const int iaA = max(0, -PA.ix0), ibA = min(WN, w2l - PA.ix0), jaA = max(0, -PA.iy0), jbA = min(WN, h2l - PA.iy0);
+  const int iaB = max(0, -PB.ix0), ibB = min(WN, w2l - PB.ix0), jaB = max(0, -PB.iy0), jbB = min(WN, h2l - PB.iy0);
+  const bool clipA = tA && (iaA > 0 || ibA < WN || jaA > 0 || jbA < WN);
+  const bool clipB = tB && (iaB > 0 || ibB < WN || jaB > 0 || jbB < WN);
+
+  unsigned long long todo = can_stream ? __ballot(tany) : 0ull;
+  unsigned long long never_ = 0ull;
+  const unsigned long long untouched = __ballot(active && !tany);
+  bool first = true;
+  const int big = 1 << 28;
+
+  for (int pass = 0; pass < SH3_MAXPASS && (todo != 0ull || (first && untouched != 0ull)); pass++) {
+    const bool mine = ((todo >> lane) & 1ull) != 0ull;
+    bool in = mine;
+    int bx0 = 0, by0 = 0, nxa = 8, ny = 8;
+    // this lane's origin range over its touching pixels
+    const int lox0 = min(tA ? PA.ox : big, tB ? PB.ox : big), lox1 = max(tA ? PA.ox : -big, tB ? PB.ox : -big);
+    const int loy0 = min(tA ? PA.oy : big, tB ? PB.oy : big), loy1 = max(tA ? PA.oy : -big, tB ? PB.oy : -big);
+    if (todo != 0ull) {
+      const int fl = __ffsll((long long)todo) - 1;
+      const int refx = __builtin_amdgcn_readlane(lox0, fl), refy = __builtin_amdgcn_readlane(loy0, fl);
+      int band = 64;
+      for (;;) {
+        in = mine && (lox0 - refx >= -band) && (lox1 - refx <= band) && (loy0 - refy >= -band) && (loy1 - refy <= band);
+        bx0 = wave_minmax<true>(in ? lox0 : big);
+        by0 = wave_minmax<true>(in ? loy0 : big);
+        const int bx1 = wave_minmax<false>(in ? lox1 : -big), by1 = wave_minmax<false>(in ? loy1 : -big);
+        nxa = bx1 - bx0 + WN;
+        ny = by1 - by0 + WN;
+        if (nxa <= 16 && ny <= 16 && 2 * nxa * ny <= SH3_LCAP) break;
+        band = (band > 4) ? 4 : (band >> 1);  // 64 -> 4 -> 2 -> 1 -> 0 (band 0 with one lane: <= 9 x 9 offsets)
+        if (band == 0) {  // the reference lane alone (its two windows may differ: it still has to fit)
+          in = mine && (lane == fl);
+          bx0 = refx;
+          by0 = refy;
+          nxa = __builtin_amdgcn_readlane(lox1, fl) - refx + WN;
+          ny = __builtin_amdgcn_readlane(loy1, fl) - refy + WN;
+          if (!(nxa <= 16 && ny <= 16 && 2 * nxa * ny <= SH3_LCAP)) in = false;  // two far-apart windows: gather
+          break;
+        }
+      }
+    } else {
+      in = false;
+    }
+    const unsigned long long inmask = __ballot(in);
+    unsigned long long drop = 0ull;  // lanes that can never stream (band-0 lane whose own two windows are too far apart)
+    if (todo != 0ull && inmask == 0ull) drop = 1ull << (__ffsll((long long)todo) - 1);
+
+    // ---- staging --------------------------------------------------------------------------------------------------
+    if (inmask != 0ull) {
+      const int rx0 = in ? lox0 - bx0 : 31, rx1 = in ? lox1 - bx0 : -1, ry0 = in ? loy0 - by0 : 31, ry1 = in ? loy1 - by0 : -1;
+      const int gx0 = group4_minmax<true>(rx0), gx1 = group4_minmax<false>(rx1);
+      const int gy0 = group4_minmax<true>(ry0), gy1 = group4_minmax<false>(ry1);
+      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
+      const int sub = lane & 15;                                       // 16-byte piece of a 256-byte line pair
+      const int pg = __builtin_amdgcn_ds_bpermute(sub * 16, packed);   // from lane 4 * sub
+      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
+      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
+      unsigned goff[4], jlen[4];
+      const unsigned jlo = (unsigned)py0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int jx = (lane >> 4) + 4 * t;
+        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN) && (jx < nxa);
+        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
+        const int m = sh2_mod(bx0 + jx, w2l, inv_w2l, pow2);
+        goff[t] = 2u * ((unsigned)m * (unsigned)HW1p + (unsigned)p0 + (unsigned)sub * 8u);
+      }
+      int dym = __builtin_amdgcn_readfirstlane(sh2_mod(by0, h2l, inv_h2l, pow2));
+      const int nt = (nxa + 3) >> 2;  // staging instructions per row
+      unsigned ldsrow = 0u;
+      const unsigned ldspitch = (unsigned)nxa * 256u;
+      for (int row = 0; row < ny; row++) {
+        const unsigned soff = (unsigned)dym * rowbytes;
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (t < nt) {
+            if (((unsigned)row - jlo) < jlen[t])
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow + 1024u * t),
+                                                       16, goff[t], soff, 0, SH_LOAD_AUX);
+          }
+        }
+        ldsrow += ldspitch;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- compute: tap rows j = 0..7 of both pixels of every lane in lock-step -----------------------------------------
+    const bool zero_lane = first && active && !tany;
+    const bool writes = in || zero_lane;
+    const unsigned long long wm = __ballot(writes);
+    const bool masked = __ballot(in && (clipA || clipB)) != 0ull;
+    const bool useA = in && tA, useB = in && tB;
+    const unsigned zb = (unsigned)(zeros - smem) + 4u * (unsigned)lane;
+    const unsigned tbA = useA ? (unsigned)(((PA.oy - by0) * nxa + (PA.ox - bx0)) * 256) + 4u * (unsigned)lane : zb;
+    const unsigned tbB = useB ? (unsigned)(((PB.oy - by0) * nxa + (PB.ox - bx0)) * 256) + 4u * (unsigned)lane + 2u : zb + 2u;
+    const unsigned radvA = useA ? (unsigned)nxa * 256u : 0u, radvB = useB ? (unsigned)nxa * 256u : 0u;
+    const unsigned voff = writes ? 2u * (unsigned)pA : OOR;
+    const unsigned chb = 2u * (unsigned)HW1;
+
+    unsigned cmask[WN];  // per tap column: keep mask of (pixel A | pixel B)
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < WN; i++)
+        cmask[i] = ((!useA || !clipA || (i >= iaA && i < ibA)) ? 0x0000ffffu : 0u) |
+                   ((!useB || !clipB || (i >= iaB && i < ibB)) ? 0xffff0000u : 0u);
+    }
+    struct Row { h2v t[WN]; };
+    auto load_row = [&](int j, Row &T) {
+      const _Float16 *a = reinterpret_cast<const _Float16 *>(smem + tbA + (unsigned)j * radvA);
+      const _Float16 *b = reinterpret_cast<const _Float16 *>(smem + tbB + (unsigned)j * radvB);
+#pragma unroll
+      for (int i = 0; i < WN; i++) {
+        h2v v;
+        v.x = a[i * 128];
+        v.y = b[i * 128];
+        T.t[i] = v;
+      }
+      if (masked) {
+        const unsigned rmask = ((!useA || !clipA || (j >= jaA && j < jbA)) ? 0x0000ffffu : 0u) |
+                               ((!useB || !clipB || (j >= jaB && j < jbB)) ? 0xffff0000u : 0u);
+#pragma unroll
+        for (int i = 0; i < WN; i++)
+          T.t[i] = __builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, T.t[i]) & cmask[i] & rmask);
+      }
+    };
+    auto emit = [&](int b, const Row &prev, const Row &cur) {  // output row b of all 7 columns a, both pixels
+#pragma unroll
+      for (int a = 0; a < RD; a++) {
+        h2v acc = prev.t[a] * W00;
+        acc = acc + cur.t[a] * W01;
+        acc = acc + prev.t[a + 1] * W10;
+        acc = acc + cur.t[a + 1] * W11;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc), rout, voff, (unsigned)(a * RD + b) * chb,
+                                              SH_STORE_AUX);
+      }
+    };
+    if (wm != 0ull) {
+      Row A_, B_;
+      load_row(0, A_);
+      load_row(1, B_); emit(0, A_, B_);
+      load_row(2, A_); emit(1, B_, A_);
+      load_row(3, B_); emit(2, A_, B_);
+      load_row(4, A_); emit(3, B_, A_);
+      load_row(5, B_); emit(4, A_, B_);
+      load_row(6, A_); emit(5, B_, A_);
+      load_row(7, B_); emit(6, A_, B_);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next pass overwrites the staging area
+    todo &= ~(inmask | drop);
+    never_ |= drop;  // (these lanes go to the gather below)
+    first = false;
+  }
+
+  // ---- what no pass took (or could take): per-pixel gather straight from the sheared volume --------------------------
+  const bool left = can_stream ? ((((todo | never_) >> lane) & 1ull) != 0ull) : active;
+  if (left) {
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+      const ShPixel &P = q ? PB : PA;
+      const int p = pA + q;
+      const _Float16 *vol = vedge + p;
+      _Float16 *o = obase + p;
+      if (!P.touches) {
+#pragma unroll
+        for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
+      } else {
+        int dxm[WN];
+        bool cok[WN];
+#pragma unroll
+        for (int i = 0; i < WN; i++) {
+          dxm[i] = sh2_mod(P.ox + i, w2l, inv_w2l, pow2);
+          const int tx = P.ix0 + i;
+          cok[i] = (tx >= 0) && (tx < w2l);
+        }
+        int dym = sh2_mod(P.oy, h2l, inv_h2l, pow2);
+        _Float16 prev[WN];
+#pragma unroll
+        for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
+        for (int j = 0; j < WN; j++) {
+          const int ty = P.iy0 + j;
+          const bool rok = (ty >= 0) && (ty < h2l);
+          _Float16 cur[WN];
+#pragma unroll
+          for (int i = 0; i < WN; i++)
+            cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1p] : (_Float16)0.f;
+          if (j >= 1) {
+#pragma unroll
+            for (int a = 0; a < RD; a++)
+              o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
+          }
+#pragma unroll
+          for (int i = 0; i < WN; i++) prev[i] = cur[i];
+          dym = (dym + 1 == h2l) ? 0 : dym + 1;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace dba
 
 using namespace dba;
 
-// 0 = automatic, 1 = streaming form, 2 = resident form (initialised from DBA_LOOKUP_KERNEL)
+// 0 = automatic, 1 = streaming form, 2 = resident form, 3 = pair form (initialised from DBA_LOOKUP_KERNEL)
 static std::atomic<int> g_lookup_select{[] {
   const char *e = getenv("DBA_LOOKUP_KERNEL");
-  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : 0;
+  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : (e && e[0] == 'p') ? 3 : 0;
 }()};
 
 // events armed for the next lookup launch of this thread (dba_corr_lookup_arm_timing)
@@ -917,7 +1230,7 @@ int dba_corr_lookup_arm_timing(void *start_event, void *stop_event) {
 }
 
 int dba_corr_lookup_select(int kernel) {
-  if (kernel < 0 || kernel > 2) return DBA_ERR_ARG;
+  if (kernel < 0 || kernel > 3) return DBA_ERR_ARG;
   g_lookup_select.store(kernel, std::memory_order_relaxed);
   return DBA_OK;
 }
@@ -964,6 +1277,17 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
   hipEvent_t e0 = g_time_start, e1 = g_time_stop;
   g_time_start = g_time_stop = nullptr;
+  // "pair" form (two adjacent pixels per lane, 4-byte stores): even map width, whole 128-pixel strips
+  const bool pair_ok = ((w1 & 1) == 0) && ((HW1p & 127) == 0) && (((h1 * w1) & 1) == 0);
+  if (sel == 3 && pair_ok) {
+    const long pst = (long)n * (HW1p / 128);
+    dim3 grid((unsigned)pst, nlv);
+    hipExtLaunchKernelGGL((corr_lookup_pair_kernel<3>), grid, dim3(64), (size_t)SH3_WAVE_BYTES, (hipStream_t)stream, e0, e1, 0, L,
+                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
+                          nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP);
+    DBA_LAUNCH_CHECK();
+    return DBA_OK;
+  }
   if (want_stream && stream_ok) {
     const int xtiles = (w1 + 63) / 64;
     const long rows = (long)n * h1 * xtiles;

@@ -59,7 +59,7 @@ SYMBOLS = {
     "dba_corr_lookup_pyramid_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "dba_corr_lookup_level_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "dba_corr_lookup_level_sheared_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
-    "dba_corr_shear_level_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "dba_corr_shear_level_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_volume_build_sheared_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_corr_lookup_pyramid_sheared_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     "dba_corr_lookup_pyramid_slots": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),

@@ -507,6 +507,11 @@ class _VolumeShadows:
     def bytes_held(self):
         return sum(st.bytes_held() for st in self.stores.values())
 
+    def clear(self):
+        """drop every shadow and every entry (tests; a caller that wants the memory back)"""
+        self.seen.clear()
+        self.stores.clear()
+
     def _release(self, key):
         ent = self.seen.pop(key, None)
         if ent is not None and ent["slots_host"] is not None:
@@ -565,21 +570,26 @@ class _VolumeShadows:
         self.tick += 1
         n, h1, w1, h2l, w2l = (int(x) for x in volume.shape)
         if ent["slots"] is None:
-            if ent["uses"] < self.min_uses:   # a level looked up once (motion_filter's one-edge block) is not worth a re-layout
-                return None
             skey = (volume.device, volume.dtype, ent["lvl"], h1, w1)
             st = self.stores.get(skey)
+            can_match = self.match and ent["matchable"] and st is not None and st.capacity() > 0
+            # a level looked up once (motion_filter's one-edge block) is not worth a re-layout -- unless most of it is
+            # already here (match mode: the tensors a graph change creates are served from shadows at their first use)
+            if ent["uses"] < self.min_uses and not (can_match and ent["uses"] == 1):
+                return None
             if st is None:
                 st = self.stores[skey] = _ShadowStore(ent["lvl"], h1, w1, h2l, w2l, volume.dtype, volume.device, self.NSIG)
             sig = self._signature(volume)
             mapping = [-1] * n
-            if self.match and ent["matchable"] and st.capacity():
+            if can_match:
                 filled = torch.tensor(st.filled, device=volume.device)
                 eq = (sig[:, None, :] == st.sig[None, :, :]).all(-1) & filled[None, :]          # [n, cap]
                 hit = eq.any(1)
                 first = eq.float().argmax(1)
                 mapping = [int(s) if h else -1 for s, h in zip(first.tolist(), hit.tolist())]   # (one small D2H per new tensor)
             todo = [e for e in range(n) if mapping[e] < 0]
+            if ent["uses"] < self.min_uses and 4 * len(todo) > n:
+                return None       # more than a quarter unknown: this tensor waits for its min_uses-th lookup like any other
             if todo:
                 for s_ in set(m for m in mapping if m >= 0):
                     st.ref[s_] += 1                     # (held while slots are chosen: a matched slot must not be handed out)

@@ -166,6 +166,7 @@ def test_zero_edit_shadows_match_the_edges_of_new_tensors():
     try:
         _SHADOWS.enabled, _SHADOWS.match = True, True
         _SHADOWS.min_uses = 2
+        _SHADOWS.clear()
         a = [p[:7].contiguous() for p in pyr]
         c7 = _coords(7, h, w, 1)
         want = direct(a, c7)

@@ -50,6 +50,7 @@ def test_recorded_corr_index_forward_calls_bit_identical(dumps, policy):
     saved = (_SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses)
     _SHADOWS.enabled, _SHADOWS.match = policy != "direct", policy == "match"
     _SHADOWS.min_uses = 2
+    _SHADOWS.clear()
     try:
         vols = {}
         b0, e0, m0 = _SHADOWS.builds, _SHADOWS.built_edges, _SHADOWS.matched_edges
@@ -64,9 +65,9 @@ def test_recorded_corr_index_forward_calls_bit_identical(dumps, policy):
             # states 1 (8 edges: updates 0, 1) and 2 (8 edges: updates 3, 4) are looked up twice per level, state 0 once
             assert _SHADOWS.builds == b0 + 8 and _SHADOWS.built_edges == e0 + 64
         if policy == "match":
-            # state 2's tensors are new objects holding 8 of the 12 edges -- but state 0's were looked up only once and
-            # never got shadows, so what can match are state 1's 8 edges: the 4 that survive rm_factors are found, the 4
-            # edges of the second add_factors are re-laid out
+            # state 1 (8 edges) gets its shadows at its second lookup; state 0's tensors (the cat: those 8 + 4 new edges, a
+            # third of them unknown) are looked up once and go to the direct kernel; state 2's (the boolean index: 4 of
+            # state 1's edges + the 4 never re-laid out) match 4 and re-lay out 4 per level at their second lookup
             assert _SHADOWS.built_edges == e0 + 4 * (8 + 4) and _SHADOWS.matched_edges == m0 + 4 * 4
     finally:
         _SHADOWS.enabled, _SHADOWS.match, _SHADOWS._min_uses = saved
