@@ -15,6 +15,9 @@
 
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 // bit-exact parity with the reference arithmetic: no mul+add fusion anywhere in this file
 #pragma clang fp contract(off)
 
@@ -57,8 +60,11 @@ struct Arith<float> {
 };
 
 // COORD_NHW2: coords laid out [n,h1,w1,2] (projective_transform output) instead of [n,2,h1,w1]
+#ifndef CL_OCC_CFG
+#define CL_OCC_CFG 1
+#endif
 template <typename T, int R, bool COORD_NHW2>
-__global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const float *__restrict__ coords,
+__global__ __launch_bounds__(256, CL_OCC_CFG) void corr_lookup_kernel(LookupLevels L, const float *__restrict__ coords,
                                                           T *__restrict__ out, int n, int h1, int w1, int h2,
                                                           int w2, int num_levels, const int *__restrict__ slots) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
@@ -145,6 +151,146 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupLevels L, const 
   }
 }
 
+// ---- half volumes, radius 3: one 16-byte load per window row ---------------------------------------------------------------
+// The generic kernel above reads a border window tap by tap (64 predicated 2-byte loads per lane), and at pyramid levels 2
+// and 3 (16- and 8-wide planes) nearly every window touches the border: 94-105 us per level at 96 edges for 50-100 MB of
+// traffic.  Here a wave owns 64 consecutive pixels of ONE edge and addresses the edge's level volume through a raw buffer
+// resource: every window row is ONE 16-byte load at the window's own (2-byte aligned) offset, rows and columns outside the
+// plane are dropped by the bounds check (rows: an out-of-range offset) or masked (columns: the load then covers a neighbouring
+// row of the plane), so interior and border pixels run the same branch-free code.  The blend is the packed-f16 arithmetic of
+// csrc/corr_sheared.hip (channel pairs; each half rounds like the scalar operation): bit-identical to the generic kernel.
+typedef _Float16 h2q __attribute__((ext_vector_type(2)));
+typedef unsigned u4q __attribute__((ext_vector_type(4)));
+
+template <bool COORD_NHW2>
+__global__ __launch_bounds__(256) void corr_lookup_rows_kernel(LookupLevels L, const float *__restrict__ coords,
+                                                               _Float16 *__restrict__ out, int n, int h1, int w1, int h2,
+                                                               int w2, int num_levels, const int *__restrict__ slots) {
+  constexpr int R = 3, RD = 7, WN = 8;
+  const int HW1 = h1 * w1;
+  const int strips = (HW1 + 63) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int sid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (edge, 64-pixel strip)
+  if (sid >= n * strips) return;
+  const int lvl = blockIdx.y;
+  const int e = sid / strips, rem = ((sid - e * strips) << 6) + lane;
+  const bool active = rem < HW1;
+  const int remc = min(rem, HW1 - 1);
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+  float cx, cy;
+  if constexpr (COORD_NHW2) {
+    const float2 c = reinterpret_cast<const float2 *>(coords)[(size_t)e * HW1 + remc];
+    cx = c.x;
+    cy = c.y;
+  } else {
+    cx = coords[((size_t)e * 2 + 0) * HW1 + remc];
+    cy = coords[((size_t)e * 2 + 1) * HW1 + remc];
+  }
+  const float scale = 1.0f / (float)(1 << lvl);
+  const float x0 = cx * scale, y0 = cy * scale;
+  const float fx = floorf(x0), fy = floorf(y0);
+  const float dx = x0 - fx, dy = y0 - fy;
+  const bool sane = (fabsf(x0) < 1.0e6f) && (fabsf(y0) < 1.0e6f);
+  const int ix0 = sane ? (int)fx - R : -(1 << 20);
+  const int iy0 = sane ? (int)fy - R : -(1 << 20);
+  const bool touches = active && sane && (ix0 + WN > 0) && (ix0 < w2l) && (iy0 + WN > 0) && (iy0 < h2l);
+
+  // this edge's level volume: [HW1][h2l][w2l] halves
+  const int es = slots ? slots[e] : e;
+  const size_t plane = (size_t)h2l * w2l;
+  const _Float16 *vedge = static_cast<const _Float16 *>(L.vol[lvl]) + (size_t)es * HW1 * plane;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)(2u * (unsigned)(HW1 * plane)), 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  const int base = (int)((size_t)remc * plane) + ix0;   // halves; + ty * w2l per row (may be negative at the first pixel)
+
+  // column keep masks per channel pair (tap 2k | tap 2k+1)
+  unsigned cm[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    cm[k] = ((ix0 + 2 * k >= 0 && ix0 + 2 * k < w2l) ? 0x0000ffffu : 0u) |
+            ((ix0 + 2 * k + 1 >= 0 && ix0 + 2 * k + 1 < w2l) ? 0xffff0000u : 0u);
+  u4q rows[WN];
+#pragma unroll
+  for (int j = 0; j < WN; j++) {
+    const int ty = iy0 + j;
+    const int off = base + ty * w2l;
+    const bool ok = touches && (ty >= 0) && (ty < h2l) && (off >= 0);
+    rows[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? 2u * (unsigned)off : OOR, 0, 0);
+  }
+  // The first and the last pixel of an edge can have a window row whose 16 bytes start before the volume (first pixel, row
+  // 0, ix0 < 0) or whose last dword straddles its end (last pixel, last row, odd offset): the range check drops those dwords
+  // whole, valid columns included.  Those (at most a few) lanes per edge and level re-read their window tap by tap.
+  const int row_first = base + max(iy0, 0) * w2l, row_last = base + min(iy0 + WN - 1, h2l - 1) * w2l;
+  const bool slow = touches && (row_first < 0 || row_last + WN > (int)(HW1 * plane));
+  if (__ballot(slow) != 0ull) {
+    if (slow) {
+      const _Float16 *pl = vedge + (size_t)remc * plane;
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        const int ty = iy0 + j;
+        const bool rok = (ty >= 0) && (ty < h2l);
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int xa = ix0 + 2 * k, xb = xa + 1;
+          const _Float16 va = (rok && xa >= 0 && xa < w2l) ? pl[(size_t)ty * w2l + xa] : (_Float16)0.f;
+          const _Float16 vb = (rok && xb >= 0 && xb < w2l) ? pl[(size_t)ty * w2l + xb] : (_Float16)0.f;
+          h2q v;
+          v.x = va;
+          v.y = vb;
+          w[k] = __builtin_bit_cast(unsigned, v);
+        }
+        rows[j][0] = w[0]; rows[j][1] = w[1]; rows[j][2] = w[2]; rows[j][3] = w[3];
+      }
+    }
+  }
+
+  // weights: scalar_t(f32 product), see Arith<_Float16>::weight
+  float w00 = (1.0f - dx) * (1.0f - dy), w01 = (1.0f - dx) * dy, w10 = dx * (1.0f - dy), w11 = dx * dy;
+  if (!touches) w00 = w01 = w10 = w11 = 0.f;
+  asm volatile("" : "+v"(w00), "+v"(w01), "+v"(w10), "+v"(w11));
+  h2q W00, W01, W10, W11;
+  W00.x = W00.y = (_Float16)w00;
+  W01.x = W01.y = (_Float16)w01;
+  W10.x = W10.y = (_Float16)w10;
+  W11.x = W11.y = (_Float16)w11;
+
+  _Float16 *o = out + ((size_t)e * num_levels * RD * RD + (size_t)lvl * RD * RD) * HW1 + rem;
+  auto pairs = [&](int j, h2q (&ev)[4], h2q (&od)[4]) {   // row j as channel pairs: ev[k] = (tap 2k, 2k+1), od[k] = (2k+1, 2k+2)
+    const u4q r = rows[j];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned lo = r[k] & cm[k];
+      ev[k] = __builtin_bit_cast(h2q, lo);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned lo = __builtin_bit_cast(unsigned, ev[k]);
+      const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, ev[k < 3 ? k + 1 : 3]) : 0u;
+      od[k] = __builtin_bit_cast(h2q, __builtin_amdgcn_alignbit(hi, lo, 16));
+    }
+  };
+  h2q pe[4], po[4], ce[4], co[4];
+  pairs(0, pe, po);
+#pragma unroll
+  for (int b = 0; b < RD; b++) {
+    pairs(b + 1, ce, co);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      h2q acc = pe[k] * W00;
+      acc = acc + ce[k] * W01;
+      acc = acc + po[k] * W10;
+      acc = acc + co[k] * W11;
+      if (active) {
+        o[(size_t)((2 * k) * RD + b) * HW1] = acc.x;
+        if (k < 3) o[(size_t)((2 * k + 1) * RD + b) * HW1] = acc.y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) pe[k] = ce[k], po[k] = co[k];
+  }
+}
+
 // adjoint (training only): every (pixel, tap) owns its volume_grad element, no atomics needed
 template <int R>
 __global__ __launch_bounds__(256) void corr_lookup_backward_kernel(const float *__restrict__ coords,
@@ -185,6 +331,17 @@ static int launch_lookup(const LookupLevels &L, const float *coords, void *out, 
                          int w2, int num_levels, int radius, hipStream_t stream, const int *slots = nullptr) {
   const long total = (long)n * h1 * w1;
   if (total == 0) return DBA_OK;
+  if constexpr (std::is_same<T, _Float16>::value) {
+    static const bool generic_only = [] { const char *e = getenv("DBA_REF_LOOKUP_KERNEL"); return e && e[0] == 'g'; }();
+    const size_t edge_bytes = (size_t)h1 * w1 * h2 * w2 * 2;   // level 0: the largest
+    if (radius == 3 && !generic_only && edge_bytes < ((size_t)1 << 31) && (long)n * ((h1 * w1 + 63) / 64) < (1L << 31)) {
+      const long strips = (long)n * ((h1 * w1 + 63) / 64);
+      hipLaunchKernelGGL((corr_lookup_rows_kernel<NHW2>), dim3((unsigned)((strips + 3) / 4), num_levels), dim3(256), 0, stream, L,
+                         coords, (_Float16 *)out, n, h1, w1, h2, w2, num_levels, slots);
+      DBA_LAUNCH_CHECK();
+      return DBA_OK;
+    }
+  }
   dim3 grid((unsigned)((total + 255) / 256), num_levels);
 #define LAUNCH_R(RR)                                                                                     \
   hipLaunchKernelGGL((corr_lookup_kernel<T, RR, NHW2>), grid, dim3(256), 0, stream, L, coords, (T *)out, n, \
