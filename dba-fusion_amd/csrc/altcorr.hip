@@ -53,21 +53,41 @@ struct AltT<_Float16> {
   static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
 };
 
+// Pyramid mode (num_levels > 0; AltCorrBlock.corr_fn, /root/reference/dbaf/modules/corr.py:107-125, in ONE launch): the grid's
+// z index is (edge, coordinate set, level); level l reads fmap2 from Lv.f2[l] ([F, H1 >> l, W1 >> l, C]), the level-0
+// coordinates divided by 2^l (exact), source / target frames through ii / jj (no gathered copies of the maps), and writes
+// its 49 channels behind the lower levels' in corr [B, S, L * 49, H1, W1].
+struct AltLevels {
+  const void *f2[8];
+};
+
 template <int R, typename T>
 __global__ __launch_bounds__(64) void altcorr_forward_kernel(const T *__restrict__ fmap1, const T *__restrict__ fmap2,
                                                              const float *__restrict__ coords, T *__restrict__ corr,
-                                                             int B, int S, int H1, int W1, int H2, int W2, int C) {
+                                                             int B, int S, int H1, int W1, int H2, int W2, int C,
+                                                             AltLevels Lv, int num_levels, const int64_t *__restrict__ ii,
+                                                             const int64_t *__restrict__ jj) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2, KS = AltT<T>::KS;
   __shared__ __attribute__((aligned(16))) unsigned char stage[ALT_UMAX * ALT_PITCH];
   const int lane = threadIdx.x;
-  const int bs = blockIdx.z, b = bs / S;
+  int bs = blockIdx.z, lvl = 0;
+  if (num_levels > 0) {
+    lvl = bs % num_levels;
+    bs /= num_levels;
+    H2 = H1 >> lvl;
+    W2 = W1 >> lvl;
+    fmap2 = static_cast<const T *>(Lv.f2[lvl]);
+  }
+  const int b = bs / S;
+  const int b1 = ii ? (int)ii[b] : b, b2 = jj ? (int)jj[b] : b;   // frames of the edge's source / target maps
   const int h1 = blockIdx.y * ALT_TH + (lane >> 4), w1 = blockIdx.x * ALT_TW + (lane & 15);
   const bool inb = (h1 < H1) && (w1 < W1);
   const int HW1 = H1 * W1;
   const int pix = min(h1, H1 - 1) * W1 + min(w1, W1 - 1);
 
   const float *cp = coords + ((size_t)bs * HW1 + pix) * 2;
-  const float x2 = cp[0], y2 = cp[1];
+  const float cscale = 1.0f / (float)(1 << lvl);   // coords / 2**i (corr.py:116): exact
+  const float x2 = cp[0] * cscale, y2 = cp[1] * cscale;
   const float fxf = floorf(x2), fyf = floorf(y2);
   const float dx = x2 - fxf, dy = y2 - fyf;
   const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);   // the reference's float -> int cast is undefined beyond
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(64) void altcorr_forward_kernel(const T *__restrict
 #pragma unroll
   for (int i = 0; i < RD * RD; i++) acc[i] = AltT<T>::from_float(0.f);
 
-  const T *f1 = fmap1 + ((size_t)b * HW1 + pix) * C;
-  const T *f2b = fmap2 + (size_t)b * H2 * W2 * C;
+  const T *f1 = fmap1 + ((size_t)b1 * HW1 + pix) * C;
+  const T *f2b = fmap2 + (size_t)b2 * H2 * W2 * C;
   for (int c0 = 0; c0 < C; c0 += 32) {
     T sdot[WN * WN];
 #pragma unroll
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(64) void altcorr_forward_kernel(const T *__restrict
     }
   }
   if (inb) {
-    T *o = corr + ((size_t)bs * RD * RD) * HW1 + pix;
+    T *o = corr + ((size_t)(bs * max(num_levels, 1) + lvl) * RD * RD) * HW1 + pix;
 #pragma unroll
     for (int i = 0; i < RD * RD; i++) o[(size_t)i * HW1] = acc[i];
   }
@@ -259,11 +279,14 @@ using namespace dba;
 
 template <typename T>
 static int altcorr_forward_launch(const void *fmap1, const void *fmap2, const float *coords, void *corr, int B, int S, int H1,
-                                  int W1, int H2, int W2, int C, int radius, hipStream_t stream) {
-  dim3 grid((W1 + ALT_TW - 1) / ALT_TW, (H1 + ALT_TH - 1) / ALT_TH, B * S);
+                                  int W1, int H2, int W2, int C, int radius, hipStream_t stream,
+                                  const AltLevels &Lv = AltLevels{}, int num_levels = 0, const int64_t *ii = nullptr,
+                                  const int64_t *jj = nullptr) {
+  dim3 grid((W1 + ALT_TW - 1) / ALT_TW, (H1 + ALT_TH - 1) / ALT_TH, B * S * (num_levels > 0 ? num_levels : 1));
 #define LAUNCH_R(RR)                                                                                             \
   hipLaunchKernelGGL((altcorr_forward_kernel<RR, T>), grid, dim3(64), 0, stream, static_cast<const T *>(fmap1),  \
-                     static_cast<const T *>(fmap2), coords, static_cast<T *>(corr), B, S, H1, W1, H2, W2, C)
+                     static_cast<const T *>(fmap2), coords, static_cast<T *>(corr), B, S, H1, W1, H2, W2, C, Lv,  \
+                     num_levels, ii, jj)
   switch (radius) {
     case 1: LAUNCH_R(1); break;
     case 2: LAUNCH_R(2); break;
@@ -287,6 +310,25 @@ extern "C" int dba_altcorr_forward_t(const void *fmap1, const void *fmap2, const
   if (dtype == DBA_F16)
     return altcorr_forward_launch<_Float16>(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius,
                                             (hipStream_t)stream);
+  return DBA_ERR_UNSUPPORTED;
+}
+
+extern "C" int dba_altcorr_pyramid_forward(const void *fmap1, const void *const *fmap2_levels, const int64_t *ii,
+                                           const int64_t *jj, const float *coords, void *corr, int B, int S, int H1, int W1,
+                                           int C, int num_levels, int radius, int dtype, dba_stream_t stream) {
+  if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || C <= 0 || num_levels < 1 || num_levels > 8) return DBA_ERR_ARG;
+  if ((long)B * S == 0) return DBA_OK;
+  if ((long)B * S * num_levels > 65535) return DBA_ERR_UNSUPPORTED;
+  if (!fmap1 || !fmap2_levels || !coords || !corr) return DBA_ERR_ARG;
+  if ((H1 >> (num_levels - 1)) < 1 || (W1 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
+  AltLevels Lv;
+  for (int l = 0; l < 8; l++) Lv.f2[l] = (l < num_levels) ? fmap2_levels[l] : nullptr;
+  if (dtype == DBA_F32)
+    return altcorr_forward_launch<float>(fmap1, nullptr, coords, corr, B, S, H1, W1, H1, W1, C, radius, (hipStream_t)stream, Lv,
+                                         num_levels, ii, jj);
+  if (dtype == DBA_F16)
+    return altcorr_forward_launch<_Float16>(fmap1, nullptr, coords, corr, B, S, H1, W1, H1, W1, C, radius, (hipStream_t)stream,
+                                            Lv, num_levels, ii, jj);
   return DBA_ERR_UNSUPPORTED;
 }
 

@@ -69,6 +69,7 @@ SYMBOLS = {
     "dba_corr_volume_build": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P]),
     "dba_altcorr_forward_t": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),
+    "dba_altcorr_pyramid_forward": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
     "dba_altcorr_backward": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
     "dba_reproject": (c_int, [_P] * 5 + [c_int] * 3 + [_P, _P, _P]),
     "dba_frame_distance": (c_int, [_P] * 5 + [c_int] * 3 + [c_float, _P, _P]),

@@ -431,10 +431,12 @@ class AltCorrBlock:
     """The memory-saving correlation of the reference (dbaf/modules/corr.py:91-139; dead at runtime there): no volume, the
     windowed correlation is formed on the fly from the feature maps at every lookup.
 
-    The feature pyramid is kept ONCE, channels-last and in float32 -- [B, N, H >> l, W >> l, C] of fmaps / 4, level l + 1
-    the 2x2 average of level l --, which is what the reference's per-lookup `.float()` of its half pyramid produces, so a
-    lookup converts nothing; a lookup is one altcorr launch per level (csrc/altcorr.hip) writing into its 49-channel slice
-    of the output.  Gradients flow through `CorrLayer`."""
+    The feature pyramid is kept ONCE, channels-last -- [B, N, H >> l, W >> l, C] of fmaps / 4, level l + 1 the 2x2 average of
+    level l -- with float32 twins made at the first lookup (what the reference's per-lookup `.float()` of its half pyramid
+    produces, so a lookup converts nothing).  Without autograd a lookup is ONE launch for all levels
+    (dba_altcorr_pyramid_forward: the kernel indexes the maps by ii / jj, divides the coordinates by 2^l itself and writes
+    every level's 49 channels into its slice of the output: no gathered copies of the maps, no scaled copies of the
+    coordinates); when a gradient is wanted the levels go through `CorrLayer` one by one -- same arithmetic, same bits."""
 
     def __init__(self, fmaps, num_levels=4, radius=3):
         self.num_levels = num_levels
@@ -446,7 +448,7 @@ class AltCorrBlock:
             if lvl > 0:
                 level = F.avg_pool2d(level, 2, stride=2)
             self.pyramid.append(level.permute(0, 2, 3, 1).reshape(B, N, H >> lvl, W >> lvl, C).contiguous())
-        self._f32 = None   # float32 twins of the levels, made at the first lookup (one conversion per block, not per call)
+        self._f32 = None
 
     def _float_pyramid(self):
         if self._f32 is None:
@@ -458,8 +460,25 @@ class AltCorrBlock:
         B, N, H, W, S, _ = coords.shape
         rd2 = (2 * self.radius + 1) ** 2
         pyr = self._float_pyramid()
-        src = pyr[0][:, ii].reshape(B * N, H, W, -1)                       # level-0 maps of the source frames
         cs = coords.movedim(4, 2).reshape(B * N, S, H, W, 2)               # the S coordinate sets in front of the pixels
+        wants_grad = torch.is_grad_enabled() and (coords.requires_grad or any(p.requires_grad for p in pyr))
+        F_ = pyr[0].shape[1]                                               # frames per batch entry
+        if not wants_grad and cs.is_cuda and (H >> (self.num_levels - 1)) >= 1 and (W >> (self.num_levels - 1)) >= 1 \
+                and B * N * S * self.num_levels <= 65535:
+            ii_ = torch.as_tensor(ii, device=cs.device).to(torch.int64).reshape(-1)
+            jj_ = torch.as_tensor(jj, device=cs.device).to(torch.int64).reshape(-1)
+            if B > 1:   # frame index inside the flattened [B * F] maps
+                off = (torch.arange(B, device=cs.device) * F_)[:, None]
+                ii_, jj_ = (off + ii_[None]).reshape(-1), (off + jj_[None]).reshape(-1)
+            c = cs if (cs.dtype == torch.float32 and cs.is_contiguous()) else cs.float().contiguous()
+            out = torch.empty(B * N, S, self.num_levels * rd2, H, W, dtype=torch.float32, device=cs.device)
+            lib = _lib.load()
+            ptrs = (ctypes.c_void_p * self.num_levels)(*[p.data_ptr() for p in pyr])
+            _lib.check(lib.dba_altcorr_pyramid_forward(_ptr(pyr[0]), ptrs, _ptr(ii_.contiguous()), _ptr(jj_.contiguous()), _ptr(c),
+                                                       _ptr(out), B * N, S, H, W, int(pyr[0].shape[-1]), self.num_levels,
+                                                       self.radius, _lib.DBA_F32, _stream()), "dba_altcorr_pyramid_forward")
+            return out.reshape(B, N, S, self.num_levels * rd2, H, W).movedim(2, -1)
+        src = pyr[0][:, ii].reshape(B * N, H, W, -1)                       # level-0 maps of the source frames
         out = coords.new_empty(B, N, self.num_levels * rd2, H, W, S, dtype=src.dtype)
         for lvl, tgt_all in enumerate(pyr):
             tgt = tgt_all[:, jj]

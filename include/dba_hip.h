@@ -321,6 +321,15 @@ int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coo
 int dba_altcorr_forward_t(const void *fmap1, const void *fmap2, const float *coords, void *corr, int B, int S,
                           int H1, int W1, int H2, int W2, int C, int radius, int dtype, dba_stream_t stream);
 
+/* AltCorrBlock.corr_fn (dbaf/modules/corr.py:107-125) in ONE launch: for every edge n (source frame ii[n], target frame
+ * jj[n]; NULL = frame n), coordinate set and pyramid level l < num_levels, the on-the-fly correlation of fmap1 [F,H1,W1,C]
+ * (level 0 of the pyramid) with fmap2_levels[l] [F,H1>>l,W1>>l,C] at coords / 2^l; corr [B,S,num_levels*(2r+1)^2,H1,W1].
+ * Same arithmetic as dba_altcorr_forward_t per level (bit-identical), no gathered copies of the maps, no scaled copies of the
+ * coordinates.  B * S * num_levels <= 65535. */
+int dba_altcorr_pyramid_forward(const void *fmap1, const void *const *fmap2_levels /* host array of L device ptrs */,
+                                const int64_t *ii, const int64_t *jj, const float *coords, void *corr, int B, int S, int H1,
+                                int W1, int C, int num_levels, int radius, int dtype, dba_stream_t stream);
+
 /* altcorr_backward (src/droid.cpp:266-278, src/altcorr_kernel.cu:152-286,321-356; training only):
  * gradients wrt the feature maps; fmap1_grad [B,H1,W1,C], fmap2_grad [B,H2,W2,C] must be zero-initialised
  * by the caller (fmap2_grad is accumulated with float atomics like the reference); the reference's

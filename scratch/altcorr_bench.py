@@ -45,3 +45,28 @@ for dt in (torch.float32, torch.float16):
             str(dt).split(".")[1], lvl, us, W.N, us / W.N, flops / us / 1e6), flush=True)
     print("%s 4 levels: %.1f us (the volume lookup of the same window: ~95 us + 24 us/edge once for the volume)" % (
         str(dt).split(".")[1], tot), flush=True)
+
+# the whole AltCorrBlock lookup as the caller issues it (round 4: one launch for the four levels, maps indexed by ii / jj in
+# the kernel) against the per-level route (gathers + scaled coordinate copies + four launches + slice copies)
+from dbaf_amd.corr import AltCorrBlock  # noqa: E402
+blk = AltCorrBlock(t(syn.make_fmaps(W.B, 128, W.h, W.w, 1000)).float()[None], num_levels=4, radius=3)
+
+
+def timed(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+with torch.no_grad():
+    fused = timed(lambda: blk(coords, ii, jj))
+cg = coords.clone().requires_grad_(True)
+per_level = timed(lambda: blk(cg, ii, jj))
+print("AltCorrBlock.__call__, 96 edges, float: one launch %.1f us; per-level route (autograd) %.1f us" % (fused, per_level), flush=True)

@@ -272,6 +272,15 @@ def test_altcorrblock_mirror_matches_per_level_oracle():
     blk = AltCorrBlock(t, num_levels=4, radius=3)
     out = blk(torch.from_numpy(coords).cuda(), torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda())
     assert out.shape == (1, 4, 196, H, W)
+    # that was ONE launch for the four levels (no autograd involved); with a gradient wanted the levels go through
+    # CorrLayer one by one -- the same arithmetic: identical bits, and the gradient reaches the coordinates' producer
+    cg = torch.from_numpy(coords).cuda().requires_grad_(True)
+    out_g = blk(cg, torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda())
+    assert out_g.requires_grad and torch.equal(out_g.detach(), out)
+    # two coordinate sets per pixel ([B, N, H, W, S, 2]): the fused launch answers both
+    c2 = torch.stack([torch.from_numpy(coords).cuda(), torch.from_numpy(coords).cuda() + 0.37], 4)
+    out2 = blk(c2, torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda())
+    assert out2.shape == (1, 4, 196, H, W, 2) and torch.equal(out2[..., 0], out)
     got = out.cpu().numpy()[0]
     pyr = [p.cpu().numpy()[0] for p in blk.pyramid]                                   # [N, H>>l, W>>l, C] pre-divided by 4
     for lvl in range(4):
