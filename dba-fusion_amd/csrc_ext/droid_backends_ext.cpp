@@ -1,0 +1,333 @@
+// Compiled `droid_backends` for MI355X: the pybind11 module a maintainer would build in place of the reference's
+// src/droid.cpp (/root/reference/src/droid.cpp:1-316) -- same function names, argument order, in-place semantics and error
+// behaviour (CHECK_CONTIGUOUS -> c10::Error -> RuntimeError), every function a thin adapter over the C ABI of
+// include/dba_hip.h (libdba_hip.so: the hand-written gfx950 kernels).  No kernels here, no torch types below this file.
+//
+//   module name      _droid_backends_C   (dba-fusion_amd/droid_backends/__init__.py re-exports it next to the caching /
+//                                          shadowing policies that live in Python; `import _droid_backends_C as
+//                                          droid_backends` is a complete drop-in by itself)
+//   built by         make ext            (g++ against the torch headers; links libdba_hip.so by $ORIGIN-relative rpath)
+//
+// Work is enqueued on the caller's CURRENT HIP stream (c10::hip::getCurrentHIPStream), like every torch op around it.
+#include <torch/extension.h>
+
+#include <c10/hip/HIPStream.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "dba_hip.h"
+
+namespace {
+
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")   // src/droid.cpp:105
+#define CHECK_DEVICE(x) TORCH_CHECK((x).is_cuda(), "droid_backends (MI355X): " #x " must be a HIP device tensor; there is no CPU path")
+#define CHECK_INPUT(x) \
+  do {                 \
+    CHECK_CONTIGUOUS(x); \
+    CHECK_DEVICE(x);     \
+  } while (0)
+
+void check(int rc, const char *what) {
+  if (rc == DBA_OK) return;
+  const char *name = rc == DBA_ERR_ARG ? "DBA_ERR_ARG" : rc == DBA_ERR_WORKSPACE ? "DBA_ERR_WORKSPACE"
+                     : rc == DBA_ERR_HIP ? "DBA_ERR_HIP" : rc == DBA_ERR_UNSUPPORTED ? "DBA_ERR_UNSUPPORTED" : "error";
+  TORCH_CHECK(false, "dba_hip: ", what, " failed with ", name, " ", rc == DBA_ERR_HIP ? dba_last_error() : "");
+}
+
+dba_stream_t stream_of(const torch::Tensor &t) { return (dba_stream_t)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+struct BaDims {
+  int N, B, ht, wd, t0, t1, eta_rows;
+};
+
+BaDims ba_dims(const torch::Tensor &disps, const torch::Tensor &eta, const torch::Tensor &ii, int t0, int t1) {
+  TORCH_CHECK(disps.dim() == 3, "disps must be [B, ht, wd]");
+  BaDims d;
+  d.N = (int)ii.size(0);
+  d.B = (int)disps.size(0);
+  d.ht = (int)disps.size(1);
+  d.wd = (int)disps.size(2);
+  d.t0 = t0;
+  d.t1 = t1;
+  const int64_t hw = (int64_t)d.ht * d.wd;
+  TORCH_CHECK(eta.numel() % hw == 0, "eta must view as [-1, ht*wd] (droid_kernels.cu:1476)");
+  d.eta_rows = (int)(eta.numel() / hw);
+  return d;
+}
+
+torch::Tensor workspace(const BaDims &d, const torch::Tensor &like, size_t *nbytes) {
+  *nbytes = dba_ba_workspace_bytes(d.N, d.B, d.ht, d.wd, d.t0, d.t1);
+  TORCH_CHECK(*nbytes > 0, "dba_ba_workspace_bytes: invalid sizes");
+  return torch::empty({(int64_t)*nbytes}, like.options().dtype(torch::kUInt8));
+}
+
+// ba (src/droid.cpp:109-138): in place on poses[t0:t1], disps[kx]; returns {dx, dz}
+std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens,
+                              torch::Tensor targets, torch::Tensor weights, torch::Tensor eta, torch::Tensor ii,
+                              torch::Tensor jj, const int t0, const int t1, const int iterations, const float lm,
+                              const float ep, const bool motion_only) {
+  CHECK_INPUT(targets);
+  CHECK_INPUT(weights);
+  CHECK_INPUT(poses);
+  CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics);
+  CHECK_INPUT(disps_sens);
+  CHECK_INPUT(ii);
+  CHECK_INPUT(jj);
+  eta = eta.contiguous();   // the reference takes eta.view(-1, ht*wd) of whatever it is given
+  CHECK_DEVICE(eta);
+  if (iterations <= 0) return {torch::Tensor(), torch::Tensor()};   // (two undefined tensors, nothing touched: :1437)
+  const BaDims d = ba_dims(disps, eta, ii, t0, t1);
+  size_t nbytes;
+  torch::Tensor ws = workspace(d, poses, &nbytes);
+  const int P = t1 - t0;
+  const int Mmax = std::min(d.B, P + d.N);
+  torch::Tensor dx = torch::empty({P, 6}, poses.options());
+  torch::Tensor dz = torch::empty({Mmax, (int64_t)d.ht * d.wd}, poses.options());
+  check(dba_ba(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), disps_sens.data_ptr<float>(),
+               targets.data_ptr<float>(), weights.data_ptr<float>(), eta.data_ptr<float>(), d.eta_rows, ii.data_ptr<int64_t>(),
+               jj.data_ptr<int64_t>(), d.N, d.B, d.ht, d.wd, t0, t1, iterations, lm, ep, motion_only ? 1 : 0,
+               dx.data_ptr<float>(), dz.data_ptr<float>(), ws.data_ptr(), nbytes, stream_of(poses)),
+        "dba_ba");
+  if (motion_only) return {dx, torch::Tensor()};
+  return {dx, dz};   // rows [0, |kx|) of dz are written (|kx| is known on the device only)
+}
+
+// frame_distance (src/droid.cpp:181-197)
+torch::Tensor frame_distance(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor ii,
+                             torch::Tensor jj, const float beta) {
+  CHECK_INPUT(poses);
+  CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics);
+  CHECK_INPUT(ii);
+  CHECK_INPUT(jj);
+  const int N = (int)ii.size(0);
+  torch::Tensor dist = torch::zeros({N}, poses.options());
+  check(dba_frame_distance(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), ii.data_ptr<int64_t>(),
+                           jj.data_ptr<int64_t>(), N, (int)disps.size(1), (int)disps.size(2), beta, dist.data_ptr<float>(),
+                           stream_of(poses)),
+        "dba_frame_distance");
+  return dist;
+}
+
+// projmap (src/droid.cpp:200-215)
+std::vector<torch::Tensor> projmap(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor ii,
+                                   torch::Tensor jj) {
+  CHECK_INPUT(poses);
+  CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics);
+  CHECK_INPUT(ii);
+  CHECK_INPUT(jj);
+  const int N = (int)ii.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor coords = torch::zeros({N, ht, wd, 3}, poses.options());
+  torch::Tensor valid = torch::zeros({N, ht, wd, 1}, poses.options());
+  check(dba_projmap(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), ii.data_ptr<int64_t>(),
+                    jj.data_ptr<int64_t>(), N, ht, wd, coords.data_ptr<float>(), valid.data_ptr<float>(), stream_of(poses)),
+        "dba_projmap");
+  return {coords, valid};
+}
+
+// iproj (src/droid.cpp:218-227)
+torch::Tensor iproj(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics) {
+  CHECK_INPUT(poses);
+  CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics);
+  const int nm = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor points = torch::zeros({nm, ht, wd, 3}, disps.options());
+  check(dba_iproj(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), nm, ht, wd,
+                  points.data_ptr<float>(), stream_of(disps)),
+        "dba_iproj");
+  return points;
+}
+
+// depth_filter (src/droid.cpp:281-295)
+torch::Tensor depth_filter(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor ix,
+                           torch::Tensor thresh) {
+  CHECK_INPUT(poses);
+  CHECK_INPUT(disps);
+  CHECK_INPUT(intrinsics);
+  CHECK_INPUT(ix);
+  CHECK_INPUT(thresh);
+  const int num = (int)ix.size(0), nbuf = (int)disps.size(0), ht = (int)disps.size(1), wd = (int)disps.size(2);
+  torch::Tensor counter = torch::zeros({num, ht, wd}, disps.options());
+  check(dba_depth_filter(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), ix.data_ptr<int64_t>(),
+                         thresh.data_ptr<float>(), num, nbuf, ht, wd, counter.data_ptr<float>(), stream_of(disps)),
+        "dba_depth_filter");
+  return counter;
+}
+
+int vol_dtype(const torch::Tensor &t) {
+  if (t.scalar_type() == torch::kHalf) return DBA_F16;
+  if (t.scalar_type() == torch::kFloat) return DBA_F32;
+  TORCH_CHECK(false, "volume / feature-map dtype not supported on the MI355X path (half / float)");
+}
+
+// corr_index_forward (src/droid.cpp:231-239): the kernel on the reference layout (no shadows here: a policy of the Python
+// adapter)
+std::vector<torch::Tensor> corr_index_forward(torch::Tensor volume, torch::Tensor coords, int radius) {
+  CHECK_INPUT(volume);
+  CHECK_INPUT(coords);
+  TORCH_CHECK(coords.scalar_type() == torch::kFloat, "coords must be float32");
+  const int n = (int)volume.size(0), h1 = (int)volume.size(1), w1 = (int)volume.size(2), h2 = (int)volume.size(3),
+            w2 = (int)volume.size(4);
+  const int rd = 2 * radius + 1;
+  torch::Tensor corr = torch::empty({n, rd, rd, h1, w1}, volume.options());
+  check(dba_corr_index_forward(volume.data_ptr(), coords.data_ptr<float>(), corr.data_ptr(), n, h1, w1, h2, w2, radius,
+                               vol_dtype(volume), stream_of(volume)),
+        "dba_corr_index_forward");
+  return {corr};
+}
+
+// corr_index_backward (src/droid.cpp:241-252; training only)
+std::vector<torch::Tensor> corr_index_backward(torch::Tensor volume, torch::Tensor coords, torch::Tensor corr_grad, int radius) {
+  CHECK_INPUT(volume);
+  CHECK_INPUT(coords);
+  CHECK_INPUT(corr_grad);
+  const int n = (int)volume.size(0), h1 = (int)volume.size(1), w1 = (int)volume.size(2), h2 = (int)volume.size(3),
+            w2 = (int)volume.size(4);
+  torch::Tensor vg = torch::zeros(volume.sizes(), volume.options().dtype(torch::kFloat));
+  torch::Tensor cg = corr_grad.to(torch::kFloat).contiguous();
+  check(dba_corr_index_backward(coords.data_ptr<float>(), cg.data_ptr<float>(), vg.data_ptr<float>(), n, h1, w1, h2, w2, radius,
+                                stream_of(volume)),
+        "dba_corr_index_backward");
+  return {vg.to(volume.scalar_type())};
+}
+
+// altcorr_forward (src/droid.cpp:254-264)
+std::vector<torch::Tensor> altcorr_forward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords, int radius) {
+  CHECK_INPUT(fmap1);
+  CHECK_INPUT(fmap2);
+  CHECK_INPUT(coords);
+  TORCH_CHECK(fmap1.scalar_type() == fmap2.scalar_type(), "altcorr_forward: fmap1 / fmap2 must have one dtype");
+  const int B = (int)coords.size(0), S = (int)coords.size(1), H1 = (int)coords.size(2), W1 = (int)coords.size(3);
+  const int H2 = (int)fmap2.size(1), W2 = (int)fmap2.size(2), C = (int)fmap2.size(3);
+  const int rd = 2 * radius + 1;
+  torch::Tensor corr = torch::empty({B, S, rd * rd, H1, W1}, fmap1.options());
+  check(dba_altcorr_forward_t(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr<float>(), corr.data_ptr(), B, S, H1, W1, H2, W2,
+                              C, radius, vol_dtype(fmap1), stream_of(fmap1)),
+        "dba_altcorr_forward");
+  return {corr};
+}
+
+// altcorr_backward (src/droid.cpp:266-278; training only): {fmap1_grad, fmap2_grad, coords_grad (zeros, like the reference's)}
+std::vector<torch::Tensor> altcorr_backward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords,
+                                            torch::Tensor corr_grad, int radius) {
+  CHECK_INPUT(fmap1);
+  CHECK_INPUT(fmap2);
+  CHECK_INPUT(coords);
+  CHECK_INPUT(corr_grad);
+  const auto dt = fmap1.scalar_type();
+  torch::Tensor f1 = fmap1.to(torch::kFloat), f2 = fmap2.to(torch::kFloat), g = corr_grad.to(torch::kFloat).contiguous();
+  const int B = (int)coords.size(0), S = (int)coords.size(1), H1 = (int)coords.size(2), W1 = (int)coords.size(3);
+  const int H2 = (int)fmap2.size(1), W2 = (int)fmap2.size(2), C = (int)fmap2.size(3);
+  torch::Tensor g1 = torch::zeros({B, H1, W1, C}, f1.options());
+  torch::Tensor g2 = torch::zeros({B, H2, W2, C}, f1.options());
+  torch::Tensor gc = torch::zeros({B, S, H1, W1, 2}, f1.options());
+  check(dba_altcorr_backward(f1.data_ptr<float>(), f2.data_ptr<float>(), coords.data_ptr<float>(), g.data_ptr<float>(),
+                             g1.data_ptr<float>(), g2.data_ptr<float>(), B, S, H1, W1, H2, W2, C, radius, stream_of(fmap1)),
+        "dba_altcorr_backward");
+  return {g1.to(dt), g2.to(dt), gc};
+}
+
+// BACore (src/bacore.h:4-70, src/droid.cpp:311-315): split-phase BA for the GTSAM fusion path
+class BACore {
+ public:
+  void init(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens, torch::Tensor targets,
+            torch::Tensor weights, torch::Tensor eta, torch::Tensor ii, torch::Tensor jj, const int t0, const int t1,
+            const int iterations, const float lm, const float ep, const bool motion_only) {
+    (void)iterations;   // accepted and ignored, like the reference's init
+    (void)motion_only;
+    CHECK_INPUT(targets);
+    CHECK_INPUT(weights);
+    CHECK_INPUT(poses);
+    CHECK_INPUT(disps);
+    CHECK_INPUT(intrinsics);
+    CHECK_INPUT(disps_sens);
+    CHECK_INPUT(ii);
+    CHECK_INPUT(jj);
+    poses_ = poses, disps_ = disps, intrinsics_ = intrinsics, disps_sens_ = disps_sens, targets_ = targets, weights_ = weights;
+    eta_ = eta.contiguous(), ii_ = ii, jj_ = jj;
+    d_ = ba_dims(disps, eta_, ii, t0, t1);
+    lm_ = lm, ep_ = ep;
+    ws_ = workspace(d_, poses, &nbytes_);
+    ready_ = true;
+  }
+
+  // H [6P,6P], v [6P]: caller-owned CPU float64 (depth_video.py:395-396), complete on return
+  void hessian(torch::Tensor H, torch::Tensor v) {
+    TORCH_CHECK(ready_, "BACore.init must be called first");
+    TORCH_CHECK(!H.is_cuda() && !v.is_cuda() && H.scalar_type() == torch::kDouble && v.scalar_type() == torch::kDouble,
+                "BACore.hessian: H, v must be CPU float64 tensors (droid_kernels.cu:1889-1890)");
+    const int n = 6 * (d_.t1 - d_.t0);
+    const bool direct = H.is_contiguous() && v.is_contiguous() && H.dim() == 2 && H.size(0) == n && H.size(1) == n && v.numel() == n;
+    torch::Tensor Hh = direct ? H : torch::zeros({n, n}, H.options());
+    torch::Tensor vh = direct ? v : torch::zeros({n}, v.options());
+    check(dba_bacore_hessian(poses_.data_ptr<float>(), disps_.data_ptr<float>(), intrinsics_.data_ptr<float>(),
+                             disps_sens_.data_ptr<float>(), targets_.data_ptr<float>(), weights_.data_ptr<float>(),
+                             eta_.data_ptr<float>(), d_.eta_rows, ii_.data_ptr<int64_t>(), jj_.data_ptr<int64_t>(), d_.N, d_.B,
+                             d_.ht, d_.wd, d_.t0, d_.t1, Hh.data_ptr<double>(), vh.data_ptr<double>(), ws_.data_ptr(), nbytes_,
+                             stream_of(poses_)),
+          "dba_bacore_hessian");
+    if (!direct) {   // the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
+      H.copy_(Hh.slice(0, 0, H.size(0)).slice(1, 0, H.size(1)));
+      v.copy_(vh.slice(0, 0, v.size(0)));
+    }
+  }
+
+  void optimize(torch::Tensor H, torch::Tensor v) {
+    TORCH_CHECK(ready_, "BACore.init must be called first");
+    torch::Tensor Hh = H.to(torch::kCPU, torch::kDouble).contiguous(), vh = v.to(torch::kCPU, torch::kDouble).contiguous();
+    dx_ = torch::zeros({d_.t1 - d_.t0, 6}, poses_.options());
+    check(dba_bacore_optimize(Hh.data_ptr<double>(), vh.data_ptr<double>(), d_.N, d_.B, d_.ht, d_.wd, d_.t0, d_.t1, lm_, ep_,
+                              dx_.data_ptr<float>(), ws_.data_ptr(), nbytes_, stream_of(poses_)),
+          "dba_bacore_optimize");
+  }
+
+  std::vector<torch::Tensor> retract(torch::Tensor _dx) {
+    TORCH_CHECK(ready_, "BACore.init must be called first");
+    torch::Tensor dxh = _dx.to(torch::kCPU, torch::kDouble).contiguous().view({-1});
+    const int P = d_.t1 - d_.t0;
+    TORCH_CHECK(dxh.numel() >= 6 * P, "BACore.retract: dx must have ", 6 * P, " entries");
+    torch::Tensor dx = torch::zeros({P, 6}, poses_.options());
+    torch::Tensor dz = torch::zeros({std::min(d_.B, P + d_.N), (int64_t)d_.ht * d_.wd}, poses_.options());
+    check(dba_bacore_retract(poses_.data_ptr<float>(), disps_.data_ptr<float>(), ii_.data_ptr<int64_t>(), jj_.data_ptr<int64_t>(),
+                             d_.N, d_.B, d_.ht, d_.wd, d_.t0, d_.t1, dxh.data_ptr<double>(), dx.data_ptr<float>(),
+                             dz.data_ptr<float>(), ws_.data_ptr(), nbytes_, stream_of(poses_)),
+          "dba_bacore_retract");
+    dx_ = dx;
+    return {dx, dz};
+  }
+
+ private:
+  torch::Tensor poses_, disps_, intrinsics_, disps_sens_, targets_, weights_, eta_, ii_, jj_, ws_, dx_;
+  BaDims d_{};
+  size_t nbytes_ = 0;
+  float lm_ = 0.f, ep_ = 0.f;
+  bool ready_ = false;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_droid_backends_C, m) {
+  m.doc() = "droid_backends for MI355X (compiled adapter over include/dba_hip.h)";
+  m.def("version", [] { return std::string(dba_version()); });
+  // bundle adjustment kernels (src/droid.cpp:299-302)
+  m.def("ba", &ba, "bundle adjustment");
+  m.def("frame_distance", &frame_distance, "frame_distance");
+  m.def("projmap", &projmap, "projmap");
+  m.def("depth_filter", &depth_filter, "depth_filter");
+  m.def("iproj", &iproj, "back projection");
+  // correlation volume kernels (:305-309)
+  m.def("altcorr_forward", &altcorr_forward, "ALTCORR forward");
+  m.def("altcorr_backward", &altcorr_backward, "ALTCORR backward");
+  m.def("corr_index_forward", &corr_index_forward, "INDEX forward");
+  m.def("corr_index_backward", &corr_index_backward, "INDEX backward");
+  py::class_<BACore>(m, "BACore")
+      .def(py::init<>())
+      .def("init", &BACore::init)
+      .def("hessian", &BACore::hessian)
+      .def("optimize", &BACore::optimize)
+      .def("retract", &BACore::retract);
+}

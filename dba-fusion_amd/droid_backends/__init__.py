@@ -22,6 +22,23 @@ from dbaf_amd._lib import DBA_F16, DBA_F32
 __all__ = ["ba", "ba_extend", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
            "altcorr_backward", "corr_index_forward", "corr_index_backward", "BACore"]
 
+# The compiled adapter (csrc_ext/droid_backends_ext.cpp -> _droid_backends_C.so, `make ext`): the pybind11 module a
+# maintainer would build in place of the reference's src/droid.cpp -- every binding of droid.cpp:297-316 over the same C ABI.
+# `import droid_backends._droid_backends_C as droid_backends` is a complete drop-in by itself.  This package serves the
+# stateless operators straight from it and keeps, in Python, the policies the reference's call pattern rewards: the BA
+# workspace / prepared-graph cache (`ba`), pinned staging (`BACore`), the flow-aligned shadows (`corr_index_forward`).
+# DBA_ADAPTER=ctypes keeps every call on the ctypes path (the two are the same C ABI calls; tests run both).
+import os as _os
+
+compiled = None
+if _os.environ.get("DBA_ADAPTER", "") != "ctypes":
+    try:
+        from . import _droid_backends_C as compiled   # noqa: F401
+    except ImportError:
+        if _os.environ.get("DBA_ADAPTER", "") == "compiled":
+            raise
+ADAPTER = "compiled (pybind11) + ctypes policies" if compiled is not None else "ctypes"
+
 
 def _check(x, name, dtype=None):
     if not isinstance(x, torch.Tensor):
@@ -700,3 +717,16 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
                                                 _ptr(g2), int(B), int(S), int(H1), int(W1), int(H2), int(W2),
                                                 int(C), int(radius), _stream()), "dba_altcorr_backward")
     return [g1.to(dt), g2.to(dt), gc]
+
+
+# ---- the stateless operators come from the compiled adapter when it is built (same C ABI calls as the functions above) ----
+_ctypes_impl = dict(frame_distance=frame_distance, projmap=projmap, depth_filter=depth_filter, iproj=iproj,
+                    corr_index_backward=corr_index_backward, altcorr_forward=altcorr_forward, altcorr_backward=altcorr_backward)
+if compiled is not None:
+    frame_distance = compiled.frame_distance
+    projmap = compiled.projmap
+    depth_filter = compiled.depth_filter
+    iproj = compiled.iproj
+    corr_index_backward = compiled.corr_index_backward
+    altcorr_forward = compiled.altcorr_forward
+    altcorr_backward = compiled.altcorr_backward

@@ -84,8 +84,20 @@ def test_corr_mirrors_have_the_reference_signatures():
             assert all(e.default is not inspect.Parameter.empty for e in extra), (cls, name, mp)
 
 
+def _nparams(fn):
+    """number of parameters of a Python function or of a pybind11 builtin (whose signature is the first docstring line)"""
+    import inspect
+    try:
+        return len(inspect.signature(fn).parameters)
+    except ValueError:
+        head = fn.__doc__.splitlines()[0]
+        inner = head[head.index("(") + 1:head.rindex(")")]
+        return len([a for a in inner.split(",") if a.strip()]) if inner.strip() else 0
+
+
 def test_droid_backends_signatures_match_the_bindings():
-    """src/droid.cpp: every m.def / class method bound there exists here with the same number of parameters"""
+    """src/droid.cpp: every m.def / class method bound there exists here with the same number of parameters -- in the
+    package AND in the compiled adapter (csrc_ext/droid_backends_ext.cpp), which must be a drop-in by itself"""
     import inspect
     import droid_backends
     text = open(os.path.join(REF, "src", "droid.cpp")).read()
@@ -96,7 +108,9 @@ def test_droid_backends_signatures_match_the_bindings():
         assert m, cname
         nargs = len([a for a in m.group(1).split(",") if a.strip()])
         fn = getattr(droid_backends, pyname)
-        assert len(inspect.signature(fn).parameters) == nargs, (pyname, nargs, inspect.signature(fn))
+        assert _nparams(fn) == nargs, (pyname, nargs)
+        if droid_backends.compiled is not None and pyname != "ba_extend":   # (ba_extend: debug variant, Python only)
+            assert _nparams(getattr(droid_backends.compiled, pyname)) == nargs, ("compiled", pyname, nargs)
     methods = re.findall(r'\.def\("(\w+)",\s*&BACore::(\w+)\)', text)
     assert {m for m, _ in methods} >= {"init", "hessian", "optimize", "retract"}
     hdr = open(os.path.join(REF, "src", "bacore.h")).read()
@@ -106,3 +120,5 @@ def test_droid_backends_signatures_match_the_bindings():
         nargs = len([a for a in m.group(1).split(",") if a.strip()])
         fn = getattr(droid_backends.BACore, pyname)
         assert len(inspect.signature(fn).parameters) == nargs + 1, (pyname, nargs)  # + self
+        if droid_backends.compiled is not None:
+            assert _nparams(getattr(droid_backends.compiled.BACore, pyname)) == nargs + 1, ("compiled", pyname, nargs)

@@ -1,0 +1,110 @@
+"""GPU: the compiled `droid_backends` (csrc_ext/droid_backends_ext.cpp -> _droid_backends_C, the pybind11 module that takes
+the place of the reference's src/droid.cpp:297-316) against the ctypes adapter: same C ABI underneath, so the same results --
+`ba` in the deterministic accumulation mode to the bit -- and the same error behaviour (RuntimeError on non-contiguous or
+host tensors, CHECK_CONTIGUOUS at droid.cpp:105-106)."""
+import numpy as np
+import pytest
+import torch
+
+from dbaf_amd import synthetic as syn
+from util import to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _both():
+    import droid_backends
+    assert droid_backends.compiled is not None, "the compiled adapter is not built (make ext)"
+    return droid_backends, droid_backends.compiled
+
+
+def test_package_serves_stateless_operators_from_the_compiled_module():
+    db, C = _both()
+    for name in ("frame_distance", "projmap", "depth_filter", "iproj", "corr_index_backward", "altcorr_forward", "altcorr_backward"):
+        assert getattr(db, name) is getattr(C, name), name
+    assert "gfx950" in C.version() and db.ADAPTER.startswith("compiled")
+
+
+def test_compiled_ba_equals_the_ctypes_adapter_bit_for_bit_in_deterministic_mode():
+    db, C = _both()
+    from dbaf_amd import _lib
+    lib = _lib.load()
+    W = syn.window_tiny_b(4)
+    lib.dba_ba_set_deterministic(1)
+    try:
+        outs = []
+        for fn in (db.ba, C.ba):
+            d = to_dev(W)
+            r = fn(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+                   W.t0, W.t1, 2, W.lm, W.ep, False)
+            outs.append((d["poses"].clone(), d["disps"].clone(), r[0].clone(), r[1][:W.M].clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        # motion-only: no depth update; iterations <= 0: nothing touched
+        d = to_dev(W)
+        r = C.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+                 W.t0, W.t1, 2, W.lm, W.ep, True)
+        assert r[1] is None and torch.equal(d["disps"], to_dev(W)["disps"])
+        r = C.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+                 W.t0, W.t1, 0, W.lm, W.ep, False)
+        assert r == [None, None]
+    finally:
+        lib.dba_ba_set_deterministic(0)
+
+
+def test_compiled_bacore_and_operators_equal_the_ctypes_adapter():
+    db, C = _both()
+    W = syn.window_tiny_b(6)
+    d = to_dev(W)
+    P = W.t1 - W.t0
+    res = []
+    for cls in (db.BACore, C.BACore):
+        s = to_dev(W)
+        core = cls()
+        core.init(s["poses"], s["disps"], s["intrinsics"], s["disps_sens"], s["target"], s["weight"], s["eta"], s["ii"], s["jj"],
+                  W.t0, W.t1, 2, W.lm, W.ep, False)
+        H = torch.zeros(6 * P, 6 * P, dtype=torch.float64)
+        v = torch.zeros(6 * P, dtype=torch.float64)
+        core.hessian(H, v)
+        dx = torch.linalg.solve(H + 1e-3 * torch.eye(6 * P, dtype=torch.float64), v)
+        core.retract(dx)
+        res.append((H, v, s["poses"].cpu(), s["disps"].cpu()))
+    np.testing.assert_allclose(res[0][0].numpy(), res[1][0].numpy(), rtol=1e-12, atol=1e-12 * float(res[0][0].abs().max()))
+    np.testing.assert_allclose(res[0][1].numpy(), res[1][1].numpy(), rtol=1e-12, atol=1e-12 * float(res[0][1].abs().max()))
+    np.testing.assert_allclose(res[0][2].numpy(), res[1][2].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res[0][3].numpy(), res[1][3].numpy(), rtol=1e-5, atol=1e-6)
+    # stateless operators: compiled module vs the ctypes implementations kept in the package
+    ci = db._ctypes_impl
+    ii, jj = d["ii"], d["jj"]
+    assert torch.equal(C.frame_distance(d["poses"], d["disps"], d["intrinsics"], ii, jj, 0.3),
+                       ci["frame_distance"](d["poses"], d["disps"], d["intrinsics"], ii, jj, 0.3))
+    for a, b in zip(C.projmap(d["poses"], d["disps"], d["intrinsics"], ii, jj), ci["projmap"](d["poses"], d["disps"], d["intrinsics"], ii, jj)):
+        assert torch.equal(a, b)
+    assert torch.equal(C.iproj(d["poses"], d["disps"], d["intrinsics"]), ci["iproj"](d["poses"], d["disps"], d["intrinsics"]))
+    ix = torch.tensor([0, 2, 4], device="cuda")
+    th = torch.tensor([0.05, 0.1, 0.2], device="cuda")
+    assert torch.equal(C.depth_filter(d["poses"], d["disps"], d["intrinsics"], ix, th),
+                       ci["depth_filter"](d["poses"], d["disps"], d["intrinsics"], ix, th))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    vol = torch.randn(3, 12, 16, 12, 16, device="cuda", generator=g).half()
+    c = (torch.rand(3, 2, 12, 16, device="cuda", generator=g) * 14).float()
+    assert torch.equal(C.corr_index_forward(vol, c, 3)[0], db.corr_index_forward(vol, c, 3)[0])
+    f1 = torch.randn(2, 12, 16, 32, device="cuda", generator=g)
+    f2 = torch.randn(2, 12, 16, 32, device="cuda", generator=g)
+    cc = (torch.rand(2, 1, 12, 16, 2, device="cuda", generator=g) * 12).float()
+    assert torch.equal(C.altcorr_forward(f1, f2, cc, 3)[0], ci["altcorr_forward"](f1, f2, cc, 3)[0])
+
+
+def test_compiled_error_behaviour():
+    _, C = _both()
+    W = syn.window_tiny_a(1)
+    d = to_dev(W)
+    with pytest.raises(RuntimeError):   # CHECK_CONTIGUOUS
+        C.frame_distance(d["poses"].t().contiguous().t(), d["disps"], d["intrinsics"], d["ii"], d["jj"], 0.3)
+    with pytest.raises(RuntimeError):   # host tensor: no CPU path
+        C.iproj(d["poses"].cpu(), d["disps"], d["intrinsics"])
+    with pytest.raises(RuntimeError):   # BACore.hessian wants CPU float64
+        core = C.BACore()
+        core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+                  W.t0, W.t1, 2, W.lm, W.ep, False)
+        core.hessian(torch.zeros(6, 6, device="cuda", dtype=torch.float64), torch.zeros(6, dtype=torch.float64))
