@@ -377,6 +377,20 @@ def main():
         extras["build_GBps"] = round(bbytes / (b_us * 1e-6) / 1e9, 1)
         extras["build_frac_of_hbm_peak"] = round(bbytes / (b_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         extras["build_TFLOPs"] = round(bflops / (b_us * 1e-6) / 1e12, 1)
+        # what add_factors pays since round 4: the same 32 edges built straight into free slots of a standing block (no
+        # allocation of level tensors, nothing concatenated): drop 32 edges, cat 32 new ones
+        host = CorrBlock(fmaps[ii[:64]][None], fmaps[jj[:64]][None], num_levels=4, radius=3, capacity=64).build() \
+            if n_loc >= 64 else None
+        if host is not None:
+            keep32 = torch.arange(64, device=dev) >= 32
+            state_h = {"blk": host}
+
+            def into_slots():
+                state_h["blk"] = state_h["blk"][keep32].cat(CorrBlock(f1, f2, num_levels=4, radius=3))
+            s_us = timed(into_slots, 5) / nb
+            extras["build_into_slots_us_per_edge"] = round(s_us, 2)
+            extras["build_into_slots_frac_of_hbm_peak"] = round(bbytes / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            del host, state_h
         del f1, f2
         # zero-edit route: reference-layout volumes + droid_backends.corr_index_forward per level + cat, i.e. what the
         # reference's own modules/corr.py executes against this repo's droid_backends
