@@ -375,14 +375,27 @@ class CorrBlock:
 
     def __getitem__(self, index):
         """keep / re-order edges (corr.py:57-60; rm_factors passes a boolean mask): the slot table is indexed, nothing
-        else moves; dropped edges' slots are found free at the next `cat`"""
+        else moves; dropped edges' slots are found free at the next `cat`.  The table is edited on the host (one small
+        device-to-host copy of the index -- the synchronisation torch's own boolean indexing performs anyway) so that the
+        next `cat` knows the free slots without asking the device."""
         self._materialise()
-        self._slots = self._slots[index.to(self._slots.device) if isinstance(index, torch.Tensor) else index]
-        if self._slots.dim() == 0:
-            self._slots = self._slots.reshape(1)
-        self._slots = self._slots.contiguous()
-        self.n = int(self._slots.shape[0])
-        self._slots_host = None
+        host = self._host_slots()
+        if isinstance(index, torch.Tensor):
+            if index.dtype == torch.bool:
+                keep = index.reshape(-1).cpu().tolist()
+                assert len(keep) == len(host), "CorrBlock[mask]: mask length != number of edges"
+                new = [s for s, k in zip(host, keep) if k]
+            else:
+                new = [host[i] for i in index.reshape(-1).cpu().tolist()]
+        elif isinstance(index, slice):
+            new = host[index]
+        elif isinstance(index, int):
+            new = [host[index]]
+        else:
+            new = [host[i] for i in index]
+        self._slots_host = list(new)
+        self._slots = torch.tensor(self._slots_host, dtype=torch.int32, device=self._slots.device)
+        self.n = len(self._slots_host)
         self._identity = False
         return self
 
