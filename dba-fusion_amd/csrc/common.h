@@ -104,6 +104,36 @@ __device__ __forceinline__ int group8_minmax(int x) {  // result in all 8 lanes 
 }
 
 
+// ---- pixel order of the flow-aligned volumes' pixel axis ----------------------------------------------------------------
+// A 128-byte line of a flow-aligned plane holds 64 source pixels at ONE tap offset, and a lookup reads the union of those
+// pixels' windows: the fewer distinct window origins among the 64 pixels, the fewer lines.  The flow varies with DISTANCE,
+// so 64 pixels should be close together: a 4 x 16 tile of the map instead of a 64 x 1 strip of a row (bench scene: 79
+// instead of 92 lines per wave and level; the lookup's time is proportional to that number, profiles/r04_lookup_lines.txt).
+//   tiled  (h1 % 4 == 0 and w1 % 16 == 0):  p = ((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) * 64 + (y1 & 3) * 16 + (x1 & 15)
+//   linear (any other map):                 p = y1 * w1 + x1, planes padded to a multiple of 64 pixels
+// Which one a map shape gets is decided here and nowhere else (build, re-layout and lookup kernels all ask shear_tiled);
+// DBA_SHEAR_TILES=0 (read once per process) keeps every shape linear.
+bool shear_tiled(int h1, int w1);
+
+__host__ __device__ __forceinline__ int sh_pixel_index(int y1, int x1, int w1, bool tiled) {
+  return tiled ? (((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) << 6) + ((y1 & 3) << 4) + (x1 & 15) : y1 * w1 + x1;
+}
+// plane index p -> (y1, x1); inv_w1 = 1.0f / w1 (linear order: float quotient + one correction either way)
+__device__ __forceinline__ void sh_pixel_yx(int p, int w1, float inv_w1, bool tiled, int &y1, int &x1) {
+  if (tiled) {
+    const int t = p >> 6, tiles_x = w1 >> 4;
+    const int tyi = (int)(((float)t + 0.5f) / (float)tiles_x);   // (tiles_x <= a few hundred: exact)
+    const int txi = t - tyi * tiles_x;
+    y1 = (tyi << 2) + ((p >> 4) & 3);
+    x1 = (txi << 4) + (p & 15);
+  } else {
+    y1 = (int)(((float)p + 0.5f) * inv_w1);
+    x1 = p - y1 * w1;
+    if (x1 < 0) { y1--; x1 += w1; }
+    if (x1 >= w1) { y1++; x1 -= w1; }
+  }
+}
+
 // ---- SE3 helpers on (t, q_xyzw) -----------------------------------------------------------
 struct Rot3 {
   float r[9];  // row-major

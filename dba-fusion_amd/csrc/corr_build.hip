@@ -30,8 +30,11 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // fragment loads are 512 contiguous bytes, were measured and change nothing), value / 4 rounded to half
 // (corr.py:67-68); C is a multiple of 16.  Reads as 16-byte pieces along the pixels, writes as 16-byte pieces along the
 // channels (round 3; 2-byte accesses before: 23.4 us per 32-edge map, two launches).
+// w_tiled > 0: the output pixel axis is in the 4 x 16 tile order of common.h (the source operand of the flow-aligned build,
+// whose 64-pixel strips are then tiles of the map); 0: linear.
 __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
-                                                               _Float16 *__restrict__ out, int C, int HW, int kb) {
+                                                               _Float16 *__restrict__ out, int C, int HW, int kb,
+                                                               int w_tiled) {
   __shared__ _Float16 tile[64][72];   // [channel][pixel]; pitch 144 B: the 8 lanes of a channel row write 16 B each
   const int e = blockIdx.z;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -59,8 +62,9 @@ __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *_
   for (int pass = 0; pass < 2; pass++) {
     const int idx = pass * 256 + t;        // 64 pixels x 8 channel octets
     const int pl = idx >> 3, oct = idx & 7;
-    const int p = p0 + pl, c = c0 + 8 * oct;
-    if (p < HW && c < C) {
+    const int pin = p0 + pl, c = c0 + 8 * oct;
+    if (pin < HW && c < C) {
+      const int p = w_tiled ? sh_pixel_index(pin / w_tiled, pin % w_tiled, w_tiled, true) : pin;
       half8 v;
 #pragma unroll
       for (int k = 0; k < 8; k++) v[k] = tile[8 * oct + k][pl];
@@ -172,9 +176,9 @@ int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *lev
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16);
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, 0);
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16);
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
   hipLaunchKernelGGL(corr_gemm_kernel, dim3((HW2 + 127) / 128, (HW1 + 127) / 128, n), dim3(256), 0, s, A, Bm,
                      static_cast<_Float16 *>(levels[0]), C, HW1, HW2);
   DBA_LAUNCH_CHECK();

@@ -83,7 +83,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NT, bool LOOP>
 __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_build_fused_kernel(
     const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm, FusedLevels L, int C, int h1, int w1, int h2, int w2,
-    int HW1p, float inv_w1, int strips_per_wg, const int *__restrict__ oslots
+    int HW1p, float inv_w1, int strips_per_wg, const int *__restrict__ oslots, int tiled
 #ifdef FB_PROF
     , unsigned long long *prof
 #endif
@@ -289,12 +289,8 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   const int p = p0 + lane;
   const bool active = p < HW1;
   int x1, y1;
-  auto pixel_xy = [&](int pix, int &x, int &y) {
-    const int pc = min(pix, HW1 - 1);
-    y = (int)(((float)pc + 0.5f) * inv_w1);
-    x = pc - y * w1;
-    if (x < 0) { y--; x += w1; }
-    if (x >= w1) { y++; x -= w1; }
+  auto pixel_xy = [&](int pix, int &x, int &y) {   // plane index -> source pixel (common.h: linear or 4 x 16 tiles)
+    sh_pixel_yx(min(pix, HW1 - 1), w1, inv_w1, tiled != 0, y, x);
   };
   pixel_xy(p, x1, y1);
   constexpr unsigned OOR = 0x80000000u;
@@ -538,7 +534,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 }
 
 // defined in corr_build.hip
-__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb);
+__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
 
 }  // namespace dba
 
@@ -574,10 +570,11 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
   hipStream_t s = (hipStream_t)stream;
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
+  const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the source pixels in 4 x 16 tiles: the plane's pixel order (common.h)
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16);
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16);
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
   const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
@@ -617,15 +614,15 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
     hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
-                       inv_w1, spw, out_slots FB_PROF_ARG);
+                       inv_w1, spw, out_slots, tiled FB_PROF_ARG);
   } else if (w2 <= 64) {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
     hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
-                       1, out_slots FB_PROF_ARG);
+                       1, out_slots, tiled FB_PROF_ARG);
   } else {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
     hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
-                       1, out_slots FB_PROF_ARG);
+                       1, out_slots, tiled FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
 #ifdef FB_PROF

@@ -28,6 +28,11 @@
 
 namespace dba {
 
+bool shear_tiled(int h1, int w1) {
+  static const bool enabled = [] { const char *e = getenv("DBA_SHEAR_TILES"); return !(e && e[0] == '0'); }();
+  return enabled && h1 > 0 && w1 > 0 && (h1 & 3) == 0 && (w1 & 15) == 0;
+}
+
 constexpr int SH_MAX_LEVELS = 8;
 
 struct ShLevels {
@@ -51,7 +56,7 @@ struct ShReproj {
 __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restrict__ V,
                                                          _Float16 *__restrict__ Vs, int h1, int w1, int h2l,
                                                          int w2l, int lvl, int HW1p, const int *__restrict__ src_idx,
-                                                         const int *__restrict__ dst_slots) {
+                                                         const int *__restrict__ dst_slots, int tiled) {
   extern __shared__ _Float16 tile[];  // [64][w2l + 2]
   const int pitch = w2l + 2;
   const int x0 = blockIdx.x * 64;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restr
   for (int idx = threadIdx.x; idx < nx * w2l; idx += blockDim.x) {
     const int dx = idx / nx, xi = idx - dx * nx;
     const int tx = (((x0 + xi) >> lvl) + dx) % w2l;
-    Vs[(((size_t)ed * h2l + dy) * w2l + dx) * HW1 + (size_t)y1 * w1 + x0 + xi] = tile[xi * pitch + tx];
+    Vs[(((size_t)ed * h2l + dy) * w2l + dx) * HW1 + (size_t)sh_pixel_index(y1, x0 + xi, w1, tiled != 0)] = tile[xi * pitch + tx];
   }
 }
 
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
                                                                           _Float16 *__restrict__ out, int n,
                                                                           int h1, int w1, int h2, int w2,
                                                                           int num_levels, int lvl0, int cflags,
-                                                                          const int *__restrict__ slots, ShReproj RP) {
+                                                                          const int *__restrict__ slots, ShReproj RP, int tiled) {
+  // tiled: the plane's pixel axis is in 4 x 16 tiles (common.h) and a wave owns one TILE instead of 64 pixels of a row
   // slots: edge e's volumes live in slot slots[e] of every level's store (null: slot e) -- the slot-addressed CorrBlock,
   // whose cat / index operations edit this table instead of moving volumes (dbaf/modules/corr.py:52-60)
   // lvl0 / cflags: a launch may serve a sub-range of levels [lvl0, lvl0 + gridDim.y) of the pyramid (num_levels = levels
@@ -256,7 +262,24 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
 #endif
   const int slvl = (cflags & 2) ? 0 : lvl;
   const int h2l = h2 >> lvl, w2l = w2 >> lvl;
-  const bool rowvalid = rowid < n * h1 * xtiles;
+  // a wave's unit of work: 64 consecutive pixels of the plane's pixel axis = one 4 x 16 tile of the map, or (linear order)
+  // 64 consecutive x1 of one row
+  const int tiles_x = w1 >> 4;
+  const int units = tiled ? (HW1 >> 6) : h1 * xtiles;   // per edge
+  const bool rowvalid = rowid < n * units;
+  auto unit_geometry = [&](int u, int &y1_, int &x1_, int &pbase_) {   // this lane's pixel, the unit's first plane index
+    if (tiled) {
+      const int tyi = u / tiles_x, txi = u - tyi * tiles_x;
+      y1_ = (tyi << 2) + (lane >> 4);
+      x1_ = (txi << 4) + (lane & 15);
+      pbase_ = u << 6;
+    } else {
+      y1_ = u / xtiles;
+      const int xt_ = u - y1_ * xtiles;
+      x1_ = xt_ * 64 + lane;
+      pbase_ = y1_ * w1 + xt_ * 64;
+    }
+  };
   _Float16 *olvl = out + (size_t)blockIdx.y * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
   const size_t estride = (size_t)num_levels * RD * RD * HW1;
   if (threadIdx.x == 0) ocount = 0;
@@ -267,16 +290,18 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   float dsrc = 0.f;
   int gsrc = 0;
   if (reproj && rowvalid) {
-    const int ey = rowid / xtiles, e = ey / h1, y1 = ey - e * h1;
+    const int e = rowid / units;
+    int y1, x1, pb;
+    unit_geometry(rowid - e * units, y1, x1, pb);
     const int ix = (int)RP.ii[e];
-    const int x1c = min((rowid - ey * xtiles) * 64 + lane, w1 - 1);
+    const int x1c = min(x1, w1 - 1);
     dsrc = RP.disps[(size_t)ix * HW1 + y1 * w1 + x1c];
 #ifndef SH_NO_XCD_SWIZZLE
     const int row0 = lb * SH_WAVES;
 #else
     const int row0 = blockIdx.x * SH_WAVES;
 #endif
-    gsrc = max(0, e * h1 * xtiles - row0);  // the wave of this workgroup that owns the edge's first row here
+    gsrc = max(0, e * units - row0);  // the wave of this workgroup that owns the edge's first unit here
     if (wave == gsrc) {
       const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);
       if (lane == 0) {
@@ -292,10 +317,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   __syncthreads();
 
   if (rowvalid) {
-    const int xt = rowid % xtiles;
-    const int ey = rowid / xtiles;  // e * h1 + y1
-    const int y1 = ey % h1, e = ey / h1;
-    const int x1 = xt * 64 + lane;
+    const int e = rowid / units;
+    int y1, x1, pbase;
+    unit_geometry(rowid - e * units, y1, x1, pbase);
     const bool active = x1 < w1;
     const int x1c = min(x1, w1 - 1);
     float2 cxy;
@@ -317,12 +341,13 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     }
     const ShPixel P = sh_pixel<R>(cxy, lvl, x1c, y1, h2l, w2l, active, slvl);
     const bool touches = P.touches;
-    const int ox = P.ox, oy = P.oy, sy = y1 >> lvl;
+    const int ox = P.ox, oy = P.oy;
     _Float16 *obase = olvl + (size_t)e * estride;     // uniform
-    const unsigned pix = (unsigned)(y1 * w1 + x1);   // this lane's pixel inside a channel plane
+    const unsigned pix = (unsigned)(y1 * w1 + x1);   // this lane's pixel inside a channel plane (row-major, whatever the planes' order)
 
     // (the streaming path addresses one edge's level through a buffer resource: 31-bit byte range)
-    const bool can_stream = ((w1 & 7) == 0) && (xt * 64 + 64 <= w1) &&
+    const int xlast = __builtin_amdgcn_readlane(x1, 63);
+    const bool can_stream = ((w1 & 7) == 0) && (xlast < w1) &&
                             ((size_t)h2l * w2l * HW1 * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
     const unsigned long long tmask = __ballot(touches);
     int refx = 0, refy = 0;
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     }
     const bool inlier = can_stream && touches && (abs(ox - refx) <= SH_BAND) && (abs(oy - refy) <= SH_BAND);
     const bool outlier = touches && !inlier;
-    if (outlier) olist[atomicAdd(&ocount, 1)] = ey * w1 + x1;  // <= 64 per wave: the list cannot overflow
+    if (outlier) olist[atomicAdd(&ocount, 1)] = (int)((unsigned)e * (unsigned)HW1 + pix);  // <= 64 per wave: the list cannot overflow
 
     const int big = 1 << 28;
     const bool any = __ballot(inlier) != 0ull;
@@ -369,7 +394,11 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
 
       // staging slots: lane + 64 t -> plane-row jx = (lane >> 3) + 8 t of the union, piece sub
-      const int xs = xt * 64 + sub * 8;  // first x1 of this piece
+      // (the piece's 8 pixels are the lanes 8 sub .. 8 sub + 7: one row of the map in either pixel order)
+      const int xs = __builtin_amdgcn_ds_bpermute(sub * 32, x1);            // first x1 of this piece
+      const int ysl = __builtin_amdgcn_ds_bpermute(sub * 32, y1 >> lvl);    // its source row at this level
+      // union rows whose target row (ysl + by0 + row) lies inside the map, for this piece
+      const int vr0 = max(0, -(ysl + by0)), vr1 = min(min(by1 - by0 + WN, SH_NY), h2l - (ysl + by0));
       unsigned goff[2], jlo[2], jlen[2];
       int ldsoff[2];
       u4v *keep = &keep_all[wave][0][lane];  // [t * 64]: parked in LDS, 8 VGPRs less in the streaming loop
@@ -380,8 +409,10 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
         const int dxv = bx0 + jx;
         // (fetching the whole union box instead of the per-piece ranges, ~30 % more bytes, changes nothing: DESIGN 4.1)
         const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN);
-        jlo[t] = (unsigned)py0;                 // plane-rows [py0, py1 + WN) are read by this piece's lanes
-        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
+        // plane-rows [py0, py1 + WN) are read by this piece's lanes; of those, the ones inside the map are requested
+        const int r0 = max(py0, vr0), r1 = min(py1 + WN, vr1);
+        jlo[t] = (unsigned)r0;
+        jlen[t] = (act && r1 > r0) ? (unsigned)(r1 - r0) : 0u;
         int m;
         if (pow2) m = dxv & (w2l - 1);
         else { m = dxv % w2l; m += (m < 0) ? w2l : 0; }
@@ -399,7 +430,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
         }
         keep[t * 64] = k;
         edge_any |= act && (qa > 0 || qb < 8);
-        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + (unsigned)xs);  // bytes inside one plane-row dy
+        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + (unsigned)pbase + (unsigned)sub * 8u);  // bytes inside one plane-row dy
         ldsoff[t] = jx * 64 + sub * 8;
       }
       const bool masked = __ballot(edge_any) != 0ull;  // some piece of this wave straddles the image border
@@ -417,8 +448,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       constexpr unsigned OOR = 0x80000000u;
       const int es = slots ? slots[e] : e;                                // uniform: the edge's slot in the stores
       const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;  // uniform: this edge, this level
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(vedge + (size_t)y1 * w1), 0, (int)((unsigned)h2l * rowbytes - 2u * (unsigned)(y1 * w1)), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)((unsigned)h2l * rowbytes), 0x00020000);
       const __amdgpu_buffer_rsrc_t rout =
           __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
 
@@ -433,11 +463,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
       const _Float16 *tp = touches ? stage + rx * 64 + lane : zero_taps + lane;
 
       auto request = [&](int row, int dy, u4v (&dst)[2]) {  // pieces of plane-row `row` of the union (dy = its plane)
-        const int ty = sy + by0 + row;  // uniform
-        const bool rowok = (row < ny) && (ty >= 0) && (ty < h2l);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-          const bool need = rowok && (((unsigned)row - jlo[t]) < jlen[t]);  // row in [jlo, jlo + jlen)
+          const bool need = (((unsigned)row - jlo[t]) < jlen[t]);  // row in [jlo, jlo + jlen): inside the union, the map and ny
           dst[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, need ? goff[t] : OOR, (unsigned)dy * rowbytes, SH_LOAD_AUX);
         }
       };
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
     }
     const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, true, slvl);
     const int es = slots ? slots[e] : e;
-    const _Float16 *vol = L.vol[lvl] + (size_t)es * h2l * w2l * HW1 + (size_t)y1 * w1 + x1;
+    const _Float16 *vol = L.vol[lvl] + (size_t)es * h2l * w2l * HW1 + (size_t)sh_pixel_index(y1, x1, w1, tiled != 0);
     _Float16 *o = olvl + (size_t)e * estride + (size_t)y1 * w1 + x1;
     int dxm[WN];
     bool cok[WN];
@@ -624,7 +652,7 @@ __device__ __forceinline__ int sh2_mod(int v, int n, float inv_n, bool pow2) {
 template <int R>
 __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_resident_kernel(
     ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP) {
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP, int tiled) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -656,26 +684,25 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
     *reinterpret_cast<u4v *>(zeros + lane * 16) = z;
   }
 
-  const int p = p0 + lane;
+  const int p = p0 + lane;            // index on the planes' pixel axis (linear or 4 x 16 tiles: common.h)
   const bool active = p < HW1;
   const int pc = min(p, HW1 - 1);
-  int y1 = (int)(((float)pc + 0.5f) * inv_w1);
-  int x1 = pc - y1 * w1;
-  if (x1 < 0) { y1--; x1 += w1; }
-  if (x1 >= w1) { y1++; x1 -= w1; }
+  int y1, x1;
+  sh_pixel_yx(pc, w1, inv_w1, tiled != 0, y1, x1);
+  const int plin = y1 * w1 + x1;      // the pixel in row-major order: coordinates, inverse depths, outputs
   float2 cxy;
   if (cflags & 4) {  // the reprojection taken along (see ShReproj): this wave's edge geometry, then one pixel per lane
     const int ix = (int)RP.ii[e];
-    const float dsrc = RP.disps[(size_t)ix * HW1 + pc];
+    const float dsrc = RP.disps[(size_t)ix * HW1 + plin];
     const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);  // uniform
     float ok;
     cxy = reproject_pixel(G, (float)x1, (float)y1, dsrc, ok);
     if (lvl == 0 && active) {
-      if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + p] = cxy;
-      if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + p] = ok;
+      if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + plin] = cxy;
+      if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + plin] = ok;
     }
   } else {
-    cxy = sh_coord(coords, cplanar, (size_t)e, HW1, pc);
+    cxy = sh_coord(coords, cplanar, (size_t)e, HW1, plin);
   }
   const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, active, slvl);
   const bool touches = P.touches;
@@ -787,7 +814,7 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
     const bool writes = in || zero_lane;
     const unsigned long long wm = __ballot(writes);
     const bool masked = __ballot(in && clipped) != 0ull;
-    const unsigned pix2 = 2u * (unsigned)p;
+    const unsigned pix2 = 2u * (unsigned)plin;
     const unsigned tb = in ? (unsigned)(stage - smem) + (unsigned)((ry * nxa + rx) * 128) + 2u * (unsigned)lane
                            : (unsigned)(zeros - smem) + 2u * (unsigned)lane;
     const unsigned radv = in ? (unsigned)nxa * 128u : 0u;
@@ -858,7 +885,7 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
   const bool left = can_stream ? (((todo >> lane) & 1ull) != 0ull) : active;
   if (left) {
     const _Float16 *vol = vedge + p;
-    _Float16 *o = obase + p;
+    _Float16 *o = obase + plin;
     if (!touches) {
 #pragma unroll
       for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
@@ -928,7 +955,7 @@ __device__ __forceinline__ int group4_minmax(int x) {  // result in all 4 lanes 
 template <int R>
 __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
     ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP) {
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP, int tiled) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -955,13 +982,12 @@ __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
   }
 
   // ---- this lane's two pixels (same row: w1 is even and pA is even)
-  const int pA = p0 + 2 * lane;
-  const bool active = pA < HW1;  // (HW1 is even: both pixels or none)
-  const int pc = min(pA, HW1 - 2);
-  int y1 = (int)(((float)pc + 0.5f) * inv_w1);
-  int x1 = pc - y1 * w1;
-  if (x1 < 0) { y1--; x1 += w1; }
-  if (x1 >= w1) { y1++; x1 -= w1; }
+  const int pA = p0 + 2 * lane;    // index on the planes' pixel axis (even: its neighbour 2 l + 1 is the next pixel of the
+  const bool active = pA < HW1;    // same row in the linear AND in the tiled order); HW1 is even: both pixels or none
+  const int pcp = min(pA, HW1 - 2);
+  int y1, x1;
+  sh_pixel_yx(pcp, w1, inv_w1, tiled != 0, y1, x1);
+  const int pc = y1 * w1 + x1;     // row-major index of pixel A: coordinates, inverse depths, outputs
   float2 cA, cB;
   if (cflags & 4) {  // the reprojection taken along (ShReproj)
     const int ix = (int)RP.ii[e];
@@ -971,8 +997,8 @@ __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
     cA = reproject_pixel(G, (float)x1, (float)y1, d2.x, okA);
     cB = reproject_pixel(G, (float)(x1 + 1), (float)y1, d2.y, okB);
     if (lvl == 0 && active) {
-      if (RP.coords_out) *reinterpret_cast<float4 *>(RP.coords_out + (size_t)e * HW1 + pA) = make_float4(cA.x, cA.y, cB.x, cB.y);
-      if (RP.valid_out) *reinterpret_cast<float2 *>(RP.valid_out + (size_t)e * HW1 + pA) = make_float2(okA, okB);
+      if (RP.coords_out) *reinterpret_cast<float4 *>(RP.coords_out + (size_t)e * HW1 + pc) = make_float4(cA.x, cA.y, cB.x, cB.y);
+      if (RP.valid_out) *reinterpret_cast<float2 *>(RP.valid_out + (size_t)e * HW1 + pc) = make_float2(okA, okB);
     }
   } else if (!cplanar) {
     const float4 c4 = *reinterpret_cast<const float4 *>(coords + (size_t)e * HW1 + pc);
@@ -1105,7 +1131,7 @@ __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
     const unsigned tbA = useA ? (unsigned)(((PA.oy - by0) * nxa + (PA.ox - bx0)) * 256) + 4u * (unsigned)lane : zb;
     const unsigned tbB = useB ? (unsigned)(((PB.oy - by0) * nxa + (PB.ox - bx0)) * 256) + 4u * (unsigned)lane + 2u : zb + 2u;
     const unsigned radvA = useA ? (unsigned)nxa * 256u : 0u, radvB = useB ? (unsigned)nxa * 256u : 0u;
-    const unsigned voff = writes ? 2u * (unsigned)pA : OOR;
+    const unsigned voff = writes ? 2u * (unsigned)pc : OOR;
     const unsigned chb = 2u * (unsigned)HW1;
 
     unsigned cmask[WN];  // per tap column: keep mask of (pixel A | pixel B)
@@ -1168,9 +1194,8 @@ __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
 #pragma unroll 1
     for (int q = 0; q < 2; q++) {
       const ShPixel &P = q ? PB : PA;
-      const int p = pA + q;
-      const _Float16 *vol = vedge + p;
-      _Float16 *o = obase + p;
+      const _Float16 *vol = vedge + pA + q;
+      _Float16 *o = obase + pc + q;
       if (!P.touches) {
 #pragma unroll
         for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
@@ -1235,6 +1260,8 @@ int dba_corr_lookup_select(int kernel) {
   return DBA_OK;
 }
 
+int dba_corr_sheared_tiled(int h1, int w1) { return shear_tiled(h1, w1) ? 1 : 0; }
+
 int dba_corr_sheared_plane_elems(int h1, int w1) {
   if (h1 <= 0 || w1 <= 0) return 0;
   return (h1 * w1 + 63) / 64 * 64;
@@ -1255,7 +1282,7 @@ int dba_corr_shear_level_slots(const void *ref_level, void *sheared_store, const
   dim3 grid((w1 + 63) / 64, h2l, n * h1);
   hipLaunchKernelGGL(corr_shear_kernel, grid, dim3(256), lds, (hipStream_t)stream,
                      static_cast<const _Float16 *>(ref_level), static_cast<_Float16 *>(sheared_store), h1, w1, h2l,
-                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1), src_idx, dst_slots);
+                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1), src_idx, dst_slots, shear_tiled(h1, w1) ? 1 : 0);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -1272,7 +1299,8 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   // streaming 95.8 / 523 us, resident 102 / 535 us; 28x107, 122 edges: streaming 128, resident 104 us; 55x55 streams
   // only in the resident form.  Automatic choice: streaming for 64-pixel-wide rows, resident otherwise;
   // dba_corr_lookup_select() / DBA_LOOKUP_KERNEL=stream|resident override it.
-  const bool stream_ok = (w1 % 64 == 0);
+  const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the planes' pixel order (common.h): a wave owns a 4 x 16 tile of the map
+  const bool stream_ok = (w1 % 64 == 0) || tiled;
   const int sel = g_lookup_select.load(std::memory_order_relaxed);
   const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
   hipEvent_t e0 = g_time_start, e1 = g_time_stop;
@@ -1284,17 +1312,17 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
     dim3 grid((unsigned)pst, nlv);
     hipExtLaunchKernelGGL((corr_lookup_pair_kernel<3>), grid, dim3(64), (size_t)SH3_WAVE_BYTES, (hipStream_t)stream, e0, e1, 0, L,
                           reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP);
+                          nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP, tiled);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
   if (want_stream && stream_ok) {
     const int xtiles = (w1 + 63) / 64;
-    const long rows = (long)n * h1 * xtiles;
+    const long rows = tiled ? (long)n * (h1 * w1 / 64) : (long)n * h1 * xtiles;
     dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), nlv);
     hipExtLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, e0, e1, 0, L,
                           reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          nlv, lvl0, cflags, slots, RP);
+                          nlv, lvl0, cflags, slots, RP, tiled);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
@@ -1311,7 +1339,7 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   }
   hipExtLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, e0, e1, 0, L,
                         reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP);
+                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP, tiled);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -243,10 +243,14 @@ class CorrBlock:
         return [s.index_select(0, idx) for s in self._stores]
 
     def sheared_level(self, lvl):
-        """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1] (a view without the plane padding)"""
+        """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1]: without the plane padding, and with the pixel
+        axis back in row-major order where the planes keep it in 4 x 16 tiles (dba_corr_sheared_tiled)"""
         assert self.layout == "sheared"
-        v = self.corr_pyramid[lvl]
-        return v[..., :self.h1 * self.w1].unflatten(-1, (self.h1, self.w1))
+        v = self.corr_pyramid[lvl][..., :self.h1 * self.w1]
+        if _lib.load().dba_corr_sheared_tiled(self.h1, self.w1):
+            v = v.unflatten(-1, (self.h1 // 4, self.w1 // 16, 4, 16)).permute(0, 1, 2, 3, 5, 4, 6)
+            return v.reshape(v.shape[:3] + (self.h1, self.w1))
+        return v.unflatten(-1, (self.h1, self.w1))
 
     @property
     def capacity(self):

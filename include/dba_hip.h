@@ -228,6 +228,12 @@ int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device
  * size (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup result is bit-identical to
  * corr_index_forward on the reference layout.  f16 only, radius 3. */
 int dba_corr_sheared_plane_elems(int h1, int w1);
+/* Order of the pixel axis.  Maps with h1 % 4 == 0 and w1 % 16 == 0 keep their source pixels in 4 x 16 TILES,
+ * pixel = ((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) * 64 + (y1 & 3) * 16 + (x1 & 15), so that the 64 pixels of a 128-byte line are
+ * neighbours in BOTH directions: the union of their windows -- what a lookup wave reads -- is 79 instead of 92 lines per wave
+ * and level on the bench scene, and the lookup's time is proportional to that number (profiles/r04_lookup_lines.txt).  Other
+ * maps: pixel = y1 * w1 + x1.  Returns 1 for the tiled order (DBA_SHEAR_TILES=0 keeps every shape linear). */
+int dba_corr_sheared_tiled(int h1, int w1);
 /* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 1 = streaming
  * (64-pixel-wide rows only, falls back to resident otherwise), 2 = resident.  Process-wide; results are bit-identical. */
 int dba_corr_lookup_select(int kernel);

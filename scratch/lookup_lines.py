@@ -31,7 +31,18 @@ def lines(c):
     return tot / 4
 
 
-for name, c in (("identity + (2.3, 1.7)", ident + np.array([2.3, 1.7], np.float32)),
+def tiled(c, th, tw):
+    """the scene's FLOW re-arranged so that a 64 x 1 strip carries the flow of a th x tw pixel tile: the lines the kernel then
+    reads are the lines a layout with th x tw tiles per 128-byte line would read on the real scene"""
+    flow = c - ident
+    N = c.shape[0]
+    f = flow.reshape(N, 64 // th, th, 64 // tw, tw, 2).transpose(0, 1, 3, 2, 4, 5).reshape(N, 64, 64, 2)   # tile-major pixels
+    return (ident + f).astype(np.float32)
+
+
+for name, c in (("bench scene as 4 x 16 tiles", tiled(scene, 4, 16)), ("bench scene as 8 x 8 tiles", tiled(scene, 8, 8)),
+                ("bench scene as 2 x 32 tiles", tiled(scene, 2, 32)),
+                ("identity + (2.3, 1.7)", ident + np.array([2.3, 1.7], np.float32)),
                 ("bench scene", scene.astype(np.float32)),
                 ("bench scene + U(-1, 1) px", (scene + rng.uniform(-1, 1, scene.shape)).astype(np.float32)),
                 ("bench scene + U(-2, 2) px", (scene + rng.uniform(-2, 2, scene.shape)).astype(np.float32))):
