@@ -114,18 +114,23 @@ __device__ __forceinline__ int group8_minmax(int x) {  // result in all 8 lanes 
 // Which one a map shape gets is decided here and nowhere else (build, re-layout and lookup kernels all ask shear_tiled);
 // DBA_SHEAR_TILES=0 (read once per process) keeps every shape linear.
 bool shear_tiled(int h1, int w1);
+#ifndef SH_TILE_WLOG
+#define SH_TILE_WLOG 4   // tile width 16 (x 4 rows); 5: 2 x 32, 3: 8 x 8 (experiments)
+#endif
+constexpr int SH_TW_LOG = SH_TILE_WLOG, SH_TW = 1 << SH_TW_LOG, SH_TH_LOG = 6 - SH_TW_LOG, SH_TH = 1 << SH_TH_LOG;
 
 __host__ __device__ __forceinline__ int sh_pixel_index(int y1, int x1, int w1, bool tiled) {
-  return tiled ? (((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) << 6) + ((y1 & 3) << 4) + (x1 & 15) : y1 * w1 + x1;
+  return tiled ? (((y1 >> SH_TH_LOG) * (w1 >> SH_TW_LOG) + (x1 >> SH_TW_LOG)) << 6) + ((y1 & (SH_TH - 1)) << SH_TW_LOG) + (x1 & (SH_TW - 1))
+               : y1 * w1 + x1;
 }
 // plane index p -> (y1, x1); inv_w1 = 1.0f / w1 (linear order: float quotient + one correction either way)
 __device__ __forceinline__ void sh_pixel_yx(int p, int w1, float inv_w1, bool tiled, int &y1, int &x1) {
   if (tiled) {
-    const int t = p >> 6, tiles_x = w1 >> 4;
+    const int t = p >> 6, tiles_x = w1 >> SH_TW_LOG;
     const int tyi = (int)(((float)t + 0.5f) / (float)tiles_x);   // (tiles_x <= a few hundred: exact)
     const int txi = t - tyi * tiles_x;
-    y1 = (tyi << 2) + ((p >> 4) & 3);
-    x1 = (txi << 4) + (p & 15);
+    y1 = (tyi << SH_TH_LOG) + ((p >> SH_TW_LOG) & (SH_TH - 1));
+    x1 = (txi << SH_TW_LOG) + (p & (SH_TW - 1));
   } else {
     y1 = (int)(((float)p + 0.5f) * inv_w1);
     x1 = p - y1 * w1;

@@ -30,7 +30,9 @@ namespace dba {
 
 bool shear_tiled(int h1, int w1) {
   static const bool enabled = [] { const char *e = getenv("DBA_SHEAR_TILES"); return !(e && e[0] == '0'); }();
-  return enabled && h1 > 0 && w1 > 0 && (h1 & 3) == 0 && (w1 & 15) == 0;
+  // (maps whose rows are whole 64-pixel segments: the shapes the rows-over-tiles lookup serves; the other forms read tiled
+  // planes slower than linear ones because their stores then come in 32-byte pieces)
+  return enabled && h1 > 0 && w1 > 0 && (h1 & (SH_TH - 1)) == 0 && (w1 & (SH_TW - 1)) == 0 && (w1 & 63) == 0;
 }
 
 constexpr int SH_MAX_LEVELS = 8;
@@ -143,6 +145,9 @@ constexpr int SH_WAVES = SH_WAVES_CFG;   // waves (source rows) per workgroup
 constexpr int SH_BLOCK = SH_WAVES * 64;
 constexpr int SH_DEPTH = SH_DEPTH_CFG;   // plane-rows in flight per wave (registers: 8 VGPRs per row)
 constexpr int SH_OCC = SH_OCC_CFG;       // waves per SIMD the register budget is set for
+
+// workgroup barrier that orders LDS traffic only: global loads and stores of the wave stay in flight across it
+__device__ __forceinline__ void lds_handoff() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct ShPixel {  // per-pixel lookup state, identical arithmetic in the streaming and the gather phase
   int ix0, iy0, ox, oy;
@@ -264,14 +269,14 @@ __global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(S
   const int h2l = h2 >> lvl, w2l = w2 >> lvl;
   // a wave's unit of work: 64 consecutive pixels of the plane's pixel axis = one 4 x 16 tile of the map, or (linear order)
   // 64 consecutive x1 of one row
-  const int tiles_x = w1 >> 4;
+  const int tiles_x = w1 >> SH_TW_LOG;
   const int units = tiled ? (HW1 >> 6) : h1 * xtiles;   // per edge
   const bool rowvalid = rowid < n * units;
   auto unit_geometry = [&](int u, int &y1_, int &x1_, int &pbase_) {   // this lane's pixel, the unit's first plane index
     if (tiled) {
       const int tyi = u / tiles_x, txi = u - tyi * tiles_x;
-      y1_ = (tyi << 2) + (lane >> 4);
-      x1_ = (txi << 4) + (lane & 15);
+      y1_ = (tyi << SH_TH_LOG) + (lane >> SH_TW_LOG);
+      x1_ = (txi << SH_TW_LOG) + (lane & (SH_TW - 1));
       pbase_ = u << 6;
     } else {
       y1_ = u / xtiles;
@@ -1233,6 +1238,603 @@ __global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
   }
 }
 
+
+// =====================================================================================================================
+// Lookup, fourth form ("band"): tiles for the READS, rows for the WRITES.
+//
+// With the planes' pixel axis in 4 x 16 tiles (common.h) a 128-byte line serves a compact patch of the map, and the union
+// of a tile's windows is 79 lines where a 64 x 1 strip needs 92 (bench scene) -- but a wave that OWNS a tile stores every
+// output channel as four 32-byte pieces of four different lines, and the vector memory pipe pays per line: the tile-owning
+// forms lose more on their stores than they gain on their reads (round 4: 111 against 95 us).  Here a workgroup of four
+// waves takes a BAND of the map (4 rows x 64 columns = the four tiles of one tile row; maps 64 pixels wide):
+//   phase 1  wave w is the LOADER of tile w: window origins of the tile's pixels, their union, exec-masked LDS-DMA of the
+//            pieces some 8-pixel group needs into the tile's LDS region (the resident form's staging);
+//   barrier
+//   phase 2  wave w is the WORKER of map row w of the band: lane = x1; a pixel's taps sit in the region of ITS tile
+//            (x1 >> 4) at the slot of its position in that tile; lock-step over the tap rows, and every store instruction
+//            writes one channel of one whole map row: a full 128-byte line, as in the row-owning forms;
+//   phase 3  pixels a loader could not take into its tile's union (far from the others) are gathered by that loader's lane.
+// Arithmetic identical to the other forms (channel-pair packed f16), bit for bit.
+constexpr int SH4_LCAP = 144;                        // lines per tile region
+constexpr int SH4_REGION = SH4_LCAP * 128;
+constexpr int SH4_ZEROS = 4 * SH4_REGION;            // 8 zero lines
+constexpr int SH4_META = SH4_ZEROS + 1024;           // per tile: refx, refy, band, bx0, by0, nxa, any, -
+constexpr int SH4_BYTES = SH4_META + 4 * 32;
+
+template <int R>
+__global__ __launch_bounds__(256) void corr_lookup_band_kernel(ShLevels L, const float2 *__restrict__ coords,
+                                                               _Float16 *__restrict__ out, int n, int h1, int w1, int h2,
+                                                               int w2, int num_levels, int lvl0, int cflags,
+                                                               const int *__restrict__ slots, ShReproj RP) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  static_assert(WN == 8, "written for radius 3");
+  static_assert(SH_TW == 16 && SH_TH == 4, "a band is one row of 4 x 16 tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..3: tile (phase 1) / map row (phase 2) of the band
+  const int HW1 = h1 * w1;                                             // (w1 == 64)
+  const int bands = h1 >> 2;
+  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
+  const int bid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);      // XCD-contiguous order
+  const int lvl = blockIdx.y + lvl0;
+  const int slvl = (cflags & 2) ? 0 : lvl;
+  const bool cplanar = (cflags & 1) != 0;
+  const int e = bid / bands, band = bid - e * bands;                   // (grid.x == n * bands exactly)
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+  const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
+  const float inv_w2l = 1.0f / (float)w2l, inv_h2l = 1.0f / (float)h2l;
+  int *const meta = reinterpret_cast<int *>(smem + SH4_META);
+  if (threadIdx.x < 64) {
+    u4v z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u4v *>(smem + SH4_ZEROS + threadIdx.x * 16) = z;
+  }
+
+  EdgeGeom G;
+  int ix = 0;
+  if (cflags & 4) {
+    ix = (int)RP.ii[e];
+    G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);   // uniform
+  }
+  auto pixel = [&](int y1, int x1, bool hand_out) {             // coordinates -> lookup state of pixel (y1, x1)
+    const int plin = y1 * w1 + x1;
+    float2 c;
+    if (cflags & 4) {
+      float ok;
+      c = reproject_pixel(G, (float)x1, (float)y1, RP.disps[(size_t)ix * HW1 + plin], ok);
+      if (hand_out && lvl == 0) {
+        if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + plin] = c;
+        if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + plin] = ok;
+      }
+    } else {
+      c = sh_coord(coords, cplanar, (size_t)e, HW1, plin);
+    }
+    return sh_pixel<R>(c, lvl, x1, y1, h2l, w2l, true, slvl);
+  };
+
+  const size_t rowstride = (size_t)w2l * HW1;   // (tiled maps have no plane padding)
+  const unsigned rowbytes = (unsigned)(2 * rowstride);
+  const int es = slots ? slots[e] : e;
+  const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
+  _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;
+  constexpr unsigned OOR = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)((unsigned)h2l * rowbytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
+  const int big = 1 << 28;
+
+  // ---- phase 1: loader of tile (band, wave) ------------------------------------------------------------------------------
+  const int ly = (band << 2) + (lane >> 4), lx = (wave << 4) + (lane & 15);
+  bool leftover;   // a touching pixel of this tile that its union does not cover: gathered in phase 3
+  {
+    const ShPixel P = pixel(ly, lx, false);
+    const unsigned long long tmask = __ballot(P.touches);
+    bool in = false;
+    int refx = 0, refy = 0, bw = -1, bx0 = 0, by0 = 0, nxa = 8, ny = 8;
+    if (tmask != 0ull) {
+      const int fl = __ffsll((long long)tmask) - 1;
+      refx = __builtin_amdgcn_readlane(P.ox, fl);
+      refy = __builtin_amdgcn_readlane(P.oy, fl);
+      bw = 64;
+      for (;;) {
+        in = P.touches && (abs(P.ox - refx) <= bw) && (abs(P.oy - refy) <= bw);
+        bx0 = wave_minmax<true>(in ? P.ox : big);
+        by0 = wave_minmax<true>(in ? P.oy : big);
+        const int bx1 = wave_minmax<false>(in ? P.ox : -big), by1 = wave_minmax<false>(in ? P.oy : -big);
+        nxa = bx1 - bx0 + WN;
+        ny = by1 - by0 + WN;
+        if (nxa <= 16 && ny <= 16 && nxa * ny <= SH4_LCAP) break;
+        bw = (bw > 4) ? 4 : (bw >> 1);   // 64 -> 4 -> 2 -> 1 -> 0 (one window: 8 x 8 lines)
+      }
+    }
+    leftover = P.touches && !in;
+    if (lane == 0) {
+      int *m = meta + 8 * wave;
+      m[0] = refx, m[1] = refy, m[2] = bw, m[3] = bx0, m[4] = by0, m[5] = nxa;
+    }
+    if (tmask != 0ull) {
+      const int rx = in ? P.ox - bx0 : 0, ry = in ? P.oy - by0 : 0;
+      const int gx0 = group8_minmax<true>(in ? rx : 31), gx1 = group8_minmax<false>(in ? rx : -1);
+      const int gy0 = group8_minmax<true>(in ? ry : 31), gy1 = group8_minmax<false>(in ? ry : -1);
+      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
+      const int sub = lane & 7;
+      const int pg = __builtin_amdgcn_ds_bpermute(sub * 32, packed);
+      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
+      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
+      const unsigned p0 = (unsigned)((((band << 2) + wave)) << 6);   // plane index of the tile's first pixel (tiles_x == 4)
+      unsigned goff[2], jlen[2];
+      const unsigned jlo = (unsigned)py0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int jx = (lane >> 3) + 8 * t;
+        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN) && (jx < nxa);
+        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
+        const int m = sh2_mod(bx0 + jx, w2l, inv_w2l, pow2);
+        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + p0 + (unsigned)sub * 8u);
+      }
+      int dym = __builtin_amdgcn_readfirstlane(sh2_mod(by0, h2l, inv_h2l, pow2));
+      const bool wide = nxa > 8;
+      unsigned ldsrow = (unsigned)(wave * SH4_REGION);
+      const unsigned ldspitch = (unsigned)nxa * 128u;
+      for (int row = 0; row < ny; row++) {
+        const unsigned soff = (unsigned)dym * rowbytes;
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+        if (((unsigned)row - jlo) < jlen[0])
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow), 16, goff[0],
+                                                   soff, 0, SH_LOAD_AUX);
+        if (wide) {
+          if (((unsigned)row - jlo) < jlen[1])
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow + 1024u), 16,
+                                                     goff[1], soff, 0, SH_LOAD_AUX);
+        }
+        ldsrow += ldspitch;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase 2: worker of map row (band, wave) ----------------------------------------------------------------------------
+  {
+    const int y1 = (band << 2) + wave, x1 = lane;
+    const ShPixel P = pixel(y1, x1, true);
+    const int tx = lane >> 4;                                    // the pixel's tile, whose loader staged its window
+    const int slot = (wave << 4) | (lane & 15);                  // ... and its position in that tile
+    const int4 m0 = *reinterpret_cast<const int4 *>(meta + 8 * tx);
+    const int2 m1 = *reinterpret_cast<const int2 *>(meta + 8 * tx + 4);
+    const int refx = m0.x, refy = m0.y, bw = m0.z, bx0 = m0.w, by0 = m1.x, nxa = m1.y;
+    const bool in = P.touches && (abs(P.ox - refx) <= bw) && (abs(P.oy - refy) <= bw);   // the loader's decision, re-made
+    const bool writes = in || !P.touches;                        // (untouched pixels: exact zeros through zero weights)
+    h2v W00, W01, W10, W11;
+    W00.x = W00.y = P.h00;
+    W01.x = W01.y = P.h01;
+    W10.x = W10.y = P.h10;
+    W11.x = W11.y = P.h11;
+    const int ia = max(0, -P.ix0), ib = min(WN, w2l - P.ix0);
+    const int ja = max(0, -P.iy0), jb = min(WN, h2l - P.iy0);
+    const bool clipped = in && (ia > 0 || ib < WN || ja > 0 || jb < WN);
+    unsigned cm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      cm[k] = ((2 * k >= ia && 2 * k < ib) ? 0x0000ffffu : 0u) | ((2 * k + 1 >= ia && 2 * k + 1 < ib) ? 0xffff0000u : 0u);
+    const bool masked = __ballot(clipped) != 0ull;
+    const unsigned tb = in ? (unsigned)(tx * SH4_REGION) + (unsigned)(((P.oy - by0) * nxa + (P.ox - bx0)) * 128) + 2u * (unsigned)slot
+                           : (unsigned)SH4_ZEROS + 2u * (unsigned)lane;
+    const unsigned radv = in ? (unsigned)nxa * 128u : 0u;
+    const unsigned voff = writes ? 2u * (unsigned)(y1 * w1 + x1) : OOR;
+    const unsigned chb = 2u * (unsigned)HW1;
+    ShTaps A, B;
+    auto load_row = [&](int j, ShTaps &T) {
+      sh_read_taps(reinterpret_cast<const _Float16 *>(smem + tb + (unsigned)j * radv), T);
+      if (masked) {
+        const bool rowok = (j >= ja) && (j < jb);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned keep = clipped ? (rowok ? cm[k] : 0u) : 0xffffffffu;
+          T.e[k] = __builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, T.e[k]) & keep);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned lo = __builtin_bit_cast(unsigned, T.e[k]);
+          const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, T.e[k < 3 ? k + 1 : 3]) : 0u;
+          T.o[k] = __builtin_bit_cast(h2v, __builtin_amdgcn_alignbit(hi, lo, 16));
+        }
+      }
+    };
+    auto emit = [&](int b, const ShTaps &prev, const ShTaps &cur) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        h2v acc = prev.e[k] * W00;
+        acc = acc + cur.e[k] * W01;
+        acc = acc + prev.o[k] * W10;
+        acc = acc + cur.o[k] * W11;
+        const unsigned bits = __builtin_bit_cast(unsigned, acc);
+        const unsigned soff = (unsigned)((2 * k) * RD + b) * chb;
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, soff, SH_STORE_AUX);
+        if (k < 3)
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, soff + (unsigned)RD * chb, SH_STORE_AUX);
+      }
+    };
+    load_row(0, A);
+    load_row(1, B); emit(0, A, B);
+    load_row(2, A); emit(1, B, A);
+    load_row(3, B); emit(2, A, B);
+    load_row(4, A); emit(3, B, A);
+    load_row(5, B); emit(4, A, B);
+    load_row(6, A); emit(5, B, A);
+    load_row(7, B); emit(6, A, B);
+  }
+
+  // ---- phase 3: what a loader left out of its tile's union, pixel by pixel ---------------------------------------------
+  if (__ballot(leftover) != 0ull) {
+    if (leftover) {
+      const ShPixel P = pixel(ly, lx, false);
+      const _Float16 *vol = vedge + ((((band << 2) + wave)) << 6) + lane;
+      _Float16 *o = obase + ly * w1 + lx;
+      int dxm[WN];
+      bool cok[WN];
+#pragma unroll
+      for (int i = 0; i < WN; i++) {
+        dxm[i] = sh2_mod(P.ox + i, w2l, inv_w2l, pow2);
+        const int txx = P.ix0 + i;
+        cok[i] = (txx >= 0) && (txx < w2l);
+      }
+      int dym = sh2_mod(P.oy, h2l, inv_h2l, pow2);
+      _Float16 prev[WN];
+#pragma unroll
+      for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
+      for (int j = 0; j < WN; j++) {
+        const int ty = P.iy0 + j;
+        const bool rok = (ty >= 0) && (ty < h2l);
+        _Float16 cur[WN];
+#pragma unroll
+        for (int i = 0; i < WN; i++) cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1] : (_Float16)0.f;
+        if (j >= 1) {
+#pragma unroll
+          for (int a = 0; a < RD; a++) o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
+        }
+#pragma unroll
+        for (int i = 0; i < WN; i++) prev[i] = cur[i];
+        dym = (dym + 1 == h2l) ? 0 : dym + 1;
+      }
+    }
+  }
+}
+
+
+// =====================================================================================================================
+// Lookup, fifth form ("rows over tiles"): the streaming form with the READS in tiles and the WRITES in rows.
+//
+// A workgroup of four waves owns a band of the map -- 4 rows x 64 columns = the four 4 x 16 tiles of one tile row of the
+// planes (common.h; maps whose width is a multiple of 64, a band cut into 64-column segments).  Wave w plays two parts in every step of the plane-row walk:
+//   LOADER of tile w   its lanes 8 s .. 8 s + 7 are the piece s of every 128-byte line of the tile, it requests the pieces of
+//                      the plane-row two steps ahead and stages the arrived one into the tile's 2 KB LDS row;
+//   WORKER of row w    lane = x1 of map row 4 band + w; a pixel's taps sit in the LDS row of ITS tile (x1 >> 4) at the slot
+//                      of its position in that tile (16 w + (x1 & 15)); the blend and the stores are the streaming form's:
+//                      a store instruction writes the lanes' channel (a, b) of ONE map row -- runs of whole lines.
+// The tiles' staging rows are double-buffered and one workgroup barrier per step hands them from the loaders to the workers.
+// What the loaders need of their tile's pixels (window origins) the workers publish through LDS in the prologue; the walk's
+// first row and length are common to the band (the union over the four tiles), each loader only requests the rows and pieces
+// its own tile needs.  Same arithmetic, bit for bit.
+constexpr int SB_TILES = 4;
+#ifndef SB_MIN_WAVES
+#define SB_MIN_WAVES 1   // (measured: 6 waves per SIMD with 77 registers beat 7 and 8 with fewer)
+#endif
+#ifndef SB_DEPTH
+#define SB_DEPTH 2
+#endif
+
+template <int R>
+__global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(ShLevels L, const float2 *__restrict__ coords,
+                                                                  _Float16 *__restrict__ out, int n, int h1, int w1, int h2,
+                                                                  int w2, int num_levels, int lvl0, int cflags,
+                                                                  const int *__restrict__ slots, ShReproj RP) {
+  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
+  static_assert(WN == 8, "written for radius 3");
+  static_assert(SH_TW == 16 && SH_TH == 4, "a band is one row of 4 x 16 tiles");
+  __shared__ __attribute__((aligned(16))) _Float16 stage_all[2][SB_TILES][SH_NX * 64];   // [buffer][tile][line][slot]
+  __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];
+  // window origins of the band's pixels, [row][x1]: only the prologue needs them, in the first staging buffer's space
+  int(*const org_x)[64] = reinterpret_cast<int(*)[64]>(&stage_all[0][0][0]);
+  int(*const org_y)[64] = reinterpret_cast<int(*)[64]>(&stage_all[0][2][0]);
+  static_assert(sizeof(stage_all[0][0]) * 2 >= SB_TILES * 64 * sizeof(int), "origins fit in two tile rows");
+  __shared__ unsigned long long touch_row[SB_TILES], inl_tile[SB_TILES];
+  __shared__ int tinfo[SB_TILES][4];                            // per tile: bx0, by0, by1, any
+  __shared__ int olist[256];
+  __shared__ int ocount;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HW1 = h1 * w1;
+  const int segs = w1 >> 6, units = (h1 >> 2) * segs;   // (w1 % 64 == 0: a band is cut into segments of four tiles)
+  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
+  const int bid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
+  const int lvl = blockIdx.y + lvl0;
+  const int slvl = (cflags & 2) ? 0 : lvl;
+  const bool cplanar = (cflags & 1) != 0;
+  const int e = bid / units, unit = bid - e * units;
+  const int band = unit / segs, seg = unit - band * segs;
+  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+  _Float16 *olvl = out + (size_t)blockIdx.y * RD * RD * HW1;
+  const size_t estride = (size_t)num_levels * RD * RD * HW1;
+  if (threadIdx.x == 0) ocount = 0;
+  for (int i = threadIdx.x; i < WN * 64; i += 256) zero_taps[i] = (_Float16)0.f;
+  const int xseg = seg << 6;
+
+  // ---- worker pixel: (row 4 band + wave, x1 = lane) ------------------------------------------------------------------------
+  const int y1 = (band << 2) + wave, x1 = xseg + lane;
+  const unsigned pix = (unsigned)(y1 * w1 + x1);
+  float2 cxy;
+  if (cflags & 4) {
+    const int ix = (int)RP.ii[e];
+    const float dsrc = RP.disps[(size_t)ix * HW1 + pix];
+    const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);   // uniform
+    float ok;
+    cxy = reproject_pixel(G, (float)x1, (float)y1, dsrc, ok);
+    if (lvl == 0) {
+      if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + pix] = cxy;
+      if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + pix] = ok;
+    }
+  } else {
+    cxy = sh_coord(coords, cplanar, (size_t)e, HW1, (int)pix);
+  }
+  const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, true, slvl);
+  const bool touches = P.touches;
+  org_x[wave][lane] = P.ox;
+  org_y[wave][lane] = P.oy;
+  {
+    const unsigned long long tm = __ballot(touches);
+    if (lane == 0) touch_row[wave] = tm;
+  }
+  __syncthreads();
+
+  // ---- loader of tile `wave`: its pixels are (row lane >> 4, x1 = 16 wave + (lane & 15)) of the band --------------------------
+  const int trow = lane >> 4, tcol = (wave << 4) + (lane & 15);
+  const int tox = org_x[trow][tcol], toy = org_y[trow][tcol];
+  const bool ttouch = ((touch_row[trow] >> tcol) & 1ull) != 0ull;
+  const bool can_stream = ((size_t)h2l * w2l * HW1 * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
+  bool tinl;
+  {
+    const unsigned long long tmask = __ballot(ttouch);
+    int refx = 0, refy = 0;
+    if (tmask) {
+      const int first = __ffsll((long long)tmask) - 1, last = 63 - __clzll((long long)tmask);
+      const int fxo = __builtin_amdgcn_readlane(tox, first), fyo = __builtin_amdgcn_readlane(toy, first);
+      const int lxo = __builtin_amdgcn_readlane(tox, last), lyo = __builtin_amdgcn_readlane(toy, last);
+      const bool nearf = ttouch && (abs(tox - fxo) <= SH_BAND) && (abs(toy - fyo) <= SH_BAND);
+      const bool nearl = ttouch && (abs(tox - lxo) <= SH_BAND) && (abs(toy - lyo) <= SH_BAND);
+      const bool usef = __popcll(__ballot(nearf)) >= __popcll(__ballot(nearl));
+      refx = usef ? fxo : lxo;
+      refy = usef ? fyo : lyo;
+    }
+    tinl = can_stream && ttouch && (abs(tox - refx) <= SH_BAND) && (abs(toy - refy) <= SH_BAND);
+  }
+  const int big = 1 << 28;
+  const unsigned long long tinl_mask = __ballot(tinl);
+  const int tbx0 = wave_minmax<true>(tinl ? tox : big);
+  const int tby0 = wave_minmax<true>(tinl ? toy : big), tby1 = wave_minmax<false>(tinl ? toy : -big);
+  if (lane == 0) {
+    tinfo[wave][0] = tbx0, tinfo[wave][1] = tby0, tinfo[wave][2] = tby1, tinfo[wave][3] = (tinl_mask != 0ull) ? 1 : 0;
+    inl_tile[wave] = tinl_mask;
+  }
+  __syncthreads();
+
+  // ---- the band's common walk: plane-rows BY0 .. BY0 + ny - 1 ----------------------------------------------------------------
+  int BY0 = big, BY1 = -big;
+#pragma unroll
+  for (int t = 0; t < SB_TILES; t++) {
+    if (tinfo[t][3]) {
+      BY0 = min(BY0, tinfo[t][1]);
+      BY1 = max(BY1, tinfo[t][2]);
+    }
+  }
+  const bool any = BY1 >= BY0;
+  const int ny = any ? BY1 - BY0 + WN : 0;   // (no LDS row depends on it: a band of far-apart tiles just walks longer)
+
+  // worker side
+  const int mytile = lane >> 4, slot = (wave << 4) | (lane & 15);
+  const bool inlier = ((inl_tile[mytile] >> slot) & 1ull) != 0ull;
+  const bool outlier = touches && !inlier;
+  if (outlier) olist[atomicAdd(&ocount, 1)] = (int)((unsigned)e * (unsigned)HW1 + pix);
+  const int rx = inlier ? P.ox - tinfo[mytile][0] : 0, ry = inlier ? P.oy - BY0 : 0;
+  _Float16 *obase = olvl + (size_t)e * estride;
+
+  if (!any) {
+    if (!outlier) {   // nothing streams in this band: untouched pixels are exact zeros
+      _Float16 *o = obase + pix;
+#pragma unroll
+      for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
+    }
+  } else {
+    // ---- loader geometry (the streaming form's, per tile; rows relative to the band's BY0) ---------------------------------
+    const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
+    const int lrx = tinl ? tox - tbx0 : 0, lry = tinl ? toy - BY0 : 0;
+    const int gx0 = group8_minmax<true>(tinl ? lrx : 15), gx1 = group8_minmax<false>(tinl ? lrx : -1);
+    const int gy0 = group8_minmax<true>(tinl ? lry : big), gy1 = group8_minmax<false>(tinl ? lry : -1);
+    const int sub = lane & 7;
+    const int px0 = __builtin_amdgcn_ds_bpermute(sub * 32, gx0), px1 = __builtin_amdgcn_ds_bpermute(sub * 32, gx1);
+    const int py0 = __builtin_amdgcn_ds_bpermute(sub * 32, gy0), py1 = __builtin_amdgcn_ds_bpermute(sub * 32, gy1);
+    // the piece's 8 pixels: row (sub >> 1) of the tile, x1 from (segment) + 16 wave + 8 (sub & 1)
+    const int xs = xseg + (wave << 4) + ((sub & 1) << 3);
+    const int ysl = ((band << 2) + (sub >> 1)) >> lvl;
+    const int vr0 = max(0, -(ysl + BY0)), vr1 = min(ny, h2l - (ysl + BY0));
+    unsigned goff[2], jlo[2], jlen[2], kbits[2];
+    int ldsoff[2];
+    bool edge_any = false;
+    const unsigned p0 = (unsigned)((band * (w1 >> 4) + (seg << 2) + wave) << 6);   // plane index of the tile's first pixel
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int jx = (lane >> 3) + 8 * t;
+      const int dxv = tbx0 + jx;
+      const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN);
+      const int r0 = max(py0, vr0), r1 = min(py1 + WN, vr1);
+      jlo[t] = (unsigned)r0;
+      jlen[t] = (act && r1 > r0) ? (unsigned)(r1 - r0) : 0u;
+      int m;
+      if (pow2) m = dxv & (w2l - 1);
+      else { m = dxv % w2l; m += (m < 0) ? w2l : 0; }
+      const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
+      const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
+      const int qa = max(0, lo - xs), qb = min(8, hi - xs);
+      // which of the piece's 8 pixels have this tap column inside the level's map: one bit each (expanded to a 16-byte mask
+      // only in the waves that have such a border at all)
+      kbits[t] = (qb > qa) ? ((0xffu >> (8 - (qb - qa))) << qa) : 0u;
+      edge_any |= act && (qa > 0 || qb < 8);
+      goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + p0 + (unsigned)sub * 8u);
+      ldsoff[t] = jx * 64 + sub * 8;
+    }
+    const bool masked = __ballot(edge_any) != 0ull;
+    int dym;
+    if (pow2) dym = BY0 & (h2l - 1);
+    else { dym = BY0 % h2l; dym += (dym < 0) ? h2l : 0; }
+    dym = __builtin_amdgcn_readfirstlane(dym);
+    const size_t rowstride = (size_t)w2l * HW1;
+    const unsigned rowbytes = (unsigned)(2 * rowstride);
+    constexpr unsigned OOR = 0x80000000u;
+    const int es = slots ? slots[e] : e;
+    const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)((unsigned)h2l * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
+
+    h2v W00, W01, W10, W11;
+    W00.x = W00.y = P.h00;
+    W01.x = W01.y = P.h01;
+    W10.x = W10.y = P.h10;
+    W11.x = W11.y = P.h11;
+    const bool writes = !outlier;
+    // worker's taps: the LDS row of its tile (buffer 0 / 1 alternate), line rx, slot
+    const _Float16 *tp0 = inlier ? &stage_all[0][mytile][rx * 64 + slot] : zero_taps + lane;
+    const _Float16 *tp1 = inlier ? &stage_all[1][mytile][rx * 64 + slot] : zero_taps + lane;
+    _Float16 *const st0 = stage_all[0][wave], *const st1 = stage_all[1][wave];
+
+    auto request = [&](int row, int dy, u4v (&dst)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const bool need = (((unsigned)row - jlo[t]) < jlen[t]);
+        dst[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, need ? goff[t] : OOR, (unsigned)dy * rowbytes, SH_LOAD_AUX);
+      }
+    };
+    u4v regs[SB_DEPTH][2];   // ring of SB_DEPTH plane-rows in flight
+    int dnext = dym;
+#pragma unroll
+    for (int r = 0; r < SB_DEPTH; r++) {
+      request(r, dnext, regs[r]);
+      dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
+    }
+    // step jy: loaders stage row jy into buffer jy & 1 and request row jy + SB_DEPTH; barrier; workers read row jy's taps and blend
+    // them with row jy - 1's (kept in registers).  Buffer jy & 1 is written again at step jy + 2, after the barrier of step
+    // jy + 1, which every worker passes only when it has read row jy.
+    auto step = [&](int jy, const ShTaps &prev, ShTaps &cur, auto ring, auto buffer, auto emits) {
+      constexpr int r = decltype(ring)::value, bf = decltype(buffer)::value;
+      constexpr bool EMITS = decltype(emits)::value;
+      _Float16 *const st = bf ? st1 : st0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        u4v v = regs[r][t];
+        if (masked) {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const unsigned l_ = (unsigned)__builtin_amdgcn_sbfe((int)kbits[t], 2 * d, 1) & 0x0000ffffu;
+            const unsigned h_ = (unsigned)__builtin_amdgcn_sbfe((int)kbits[t], 2 * d + 1, 1) & 0xffff0000u;
+            v[d] &= (l_ | h_);
+          }
+        }
+        *reinterpret_cast<u4v *>(&st[ldsoff[t]]) = v;
+      }
+      request(jy + SB_DEPTH, dnext, regs[r]);
+      dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
+      lds_handoff();
+      sh_read_taps(bf ? tp1 : tp0, cur);
+      if constexpr (EMITS) {
+        const int j = jy - ry;
+        const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
+        const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          h2v acc = prev.e[k] * W00;
+          acc = acc + cur.e[k] * W01;
+          acc = acc + prev.o[k] * W10;
+          acc = acc + cur.o[k] * W11;
+          const unsigned bits = __builtin_bit_cast(unsigned, acc);
+          const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, SH_STORE_AUX);
+          if (k < 3)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, SH_STORE_AUX);
+        }
+      }
+    };
+    ShTaps A, B;
+#pragma unroll
+    for (int k = 0; k < 4; k++) A.e[k] = A.o[k] = B.e[k] = B.o[k] = (h2v)((_Float16)0.f);
+    // unrolled over lcm(2, SB_DEPTH) rows: ring slot, staging buffer and the roles of the two tap-row sets are compile-time
+    constexpr int UNR = (SB_DEPTH % 2 == 0) ? SB_DEPTH : 2 * SB_DEPTH;
+    auto body = [&](int jy, auto uc, auto emits) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (u % 2 == 0) step(jy + u, B, A, std::integral_constant<int, u % SB_DEPTH>{}, std::integral_constant<int, 0>{}, emits);
+      else step(jy + u, A, B, std::integral_constant<int, u % SB_DEPTH>{}, std::integral_constant<int, 1>{}, emits);
+    };
+    auto group = [&](int jy, auto first_emits) {
+      body(jy, std::integral_constant<int, 0>{}, first_emits);
+      body(jy, std::integral_constant<int, 1>{}, std::true_type{});
+      if constexpr (UNR > 2) body(jy, std::integral_constant<int, 2>{}, std::true_type{});
+      if constexpr (UNR > 3) body(jy, std::integral_constant<int, 3>{}, std::true_type{});
+      if constexpr (UNR > 4) body(jy, std::integral_constant<int, 4>{}, std::true_type{});
+      if constexpr (UNR > 5) body(jy, std::integral_constant<int, 5>{}, std::true_type{});
+      static_assert(UNR <= 6, "SB_DEPTH 2, 3 or 4");
+    };
+    group(0, std::false_type{});   // row 0 only loads taps; ny >= 8 > UNR.  (ny is uniform over the workgroup: every wave
+    for (int jy = UNR; jy < ny; jy += UNR) group(jy, std::true_type{});   // meets every barrier)
+  }
+
+  // ---- gather phase: the band's outliers straight from the planes ---------------------------------------------------------
+  __syncthreads();
+  const int cnt = ocount;
+  for (int t = threadIdx.x; t < cnt; t += 256) {
+    const int gp = olist[t];
+    const int gx = gp % w1, gey = gp / w1;
+    const int gy = gey % h1, ge = gey / h1;
+    float2 c;
+    if (cflags & 4) {
+      const int ix = (int)RP.ii[ge];
+      float ok;
+      c = reproject_pixel(edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[ge]), (float)gx, (float)gy,
+                          RP.disps[(size_t)ix * HW1 + gy * w1 + gx], ok);
+    } else {
+      c = sh_coord(coords, cplanar, (size_t)ge, HW1, gy * w1 + gx);
+    }
+    const ShPixel Q = sh_pixel<R>(c, lvl, gx, gy, h2l, w2l, true, slvl);
+    const int ges = slots ? slots[ge] : ge;
+    const _Float16 *vol = L.vol[lvl] + (size_t)ges * h2l * w2l * HW1 + (size_t)sh_pixel_index(gy, gx, w1, true);
+    _Float16 *o = olvl + (size_t)ge * estride + (size_t)gy * w1 + gx;
+    int dxm[WN];
+    bool cok[WN];
+#pragma unroll
+    for (int i = 0; i < WN; i++) {
+      int m = (Q.ox + i) % w2l;
+      m += (m < 0) ? w2l : 0;
+      dxm[i] = m;
+      const int tx = Q.ix0 + i;
+      cok[i] = (tx >= 0) && (tx < w2l);
+    }
+    int dym = Q.oy % h2l;
+    dym += (dym < 0) ? h2l : 0;
+    _Float16 prev[WN];
+#pragma unroll
+    for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
+    for (int j = 0; j < WN; j++) {
+      const int ty = Q.iy0 + j;
+      const bool rok = (ty >= 0) && (ty < h2l);
+      _Float16 cur[WN];
+#pragma unroll
+      for (int i = 0; i < WN; i++) cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1] : (_Float16)0.f;
+      if (j >= 1) {
+#pragma unroll
+        for (int a = 0; a < RD; a++) o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], Q);
+      }
+#pragma unroll
+      for (int i = 0; i < WN; i++) prev[i] = cur[i];
+      dym = (dym + 1 == h2l) ? 0 : dym + 1;
+    }
+  }
+}
+
 }  // namespace dba
 
 using namespace dba;
@@ -1240,7 +1842,8 @@ using namespace dba;
 // 0 = automatic, 1 = streaming form, 2 = resident form, 3 = pair form (initialised from DBA_LOOKUP_KERNEL)
 static std::atomic<int> g_lookup_select{[] {
   const char *e = getenv("DBA_LOOKUP_KERNEL");
-  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : (e && e[0] == 'p') ? 3 : 0;
+  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r' && e[1] == 'e') ? 2 : (e && e[0] == 'p') ? 3 : (e && e[0] == 'b') ? 4
+         : (e && e[0] == 'r' && e[1] == 'o') ? 5 : 0;   // stream | resident | pair | band | rowtile
 }()};
 
 // events armed for the next lookup launch of this thread (dba_corr_lookup_arm_timing)
@@ -1255,12 +1858,12 @@ int dba_corr_lookup_arm_timing(void *start_event, void *stop_event) {
 }
 
 int dba_corr_lookup_select(int kernel) {
-  if (kernel < 0 || kernel > 3) return DBA_ERR_ARG;
+  if (kernel < 0 || kernel > 5) return DBA_ERR_ARG;
   g_lookup_select.store(kernel, std::memory_order_relaxed);
   return DBA_OK;
 }
 
-int dba_corr_sheared_tiled(int h1, int w1) { return shear_tiled(h1, w1) ? 1 : 0; }
+int dba_corr_sheared_tiled(int h1, int w1) { return shear_tiled(h1, w1) ? SH_TW : 0; }
 
 int dba_corr_sheared_plane_elems(int h1, int w1) {
   if (h1 <= 0 || w1 <= 0) return 0;
@@ -1305,6 +1908,31 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
   hipEvent_t e0 = g_time_start, e1 = g_time_stop;
   g_time_start = g_time_stop = nullptr;
+  // "band" form (tiles for the reads, rows for the writes): tiled planes of 64-pixel-wide maps
+  const bool rowtile_ok = tiled && SH_TW == 16 && (w1 & 63) == 0 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * h1 * w1 * 2 < ((size_t)1 << 31);
+  const bool band_ok = tiled && SH_TW == 16 && w1 == 64 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * h1 * w1 * 2 < ((size_t)1 << 31);
+  if (sel == 4 && band_ok) {
+    static DeviceOnce band_once;
+    if (band_once.needed()) {
+      DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_lookup_band_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      band_once.done();
+    }
+    dim3 grid((unsigned)((long)n * (h1 / 4)), nlv);
+    hipExtLaunchKernelGGL((corr_lookup_band_kernel<3>), grid, dim3(256), (size_t)SH4_BYTES, (hipStream_t)stream, e0, e1, 0, L,
+                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2, nlv, lvl0,
+                          cflags, slots, RP);
+    DBA_LAUNCH_CHECK();
+    return DBA_OK;
+  }
+  if ((sel == 5 || sel == 0) && rowtile_ok) {   // "rows over tiles": the streaming walk, loaders per tile, workers per map row
+    dim3 grid((unsigned)((long)n * (h1 / 4) * (w1 / 64)), nlv);
+    hipExtLaunchKernelGGL((corr_lookup_rowtile_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, L,
+                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2, nlv, lvl0,
+                          cflags, slots, RP);
+    DBA_LAUNCH_CHECK();
+    return DBA_OK;
+  }
   // "pair" form (two adjacent pixels per lane, 4-byte stores): even map width, whole 128-pixel strips
   const bool pair_ok = ((w1 & 1) == 0) && ((HW1p & 127) == 0) && (((h1 * w1) & 1) == 0);
   if (sel == 3 && pair_ok) {

@@ -247,8 +247,10 @@ class CorrBlock:
         axis back in row-major order where the planes keep it in 4 x 16 tiles (dba_corr_sheared_tiled)"""
         assert self.layout == "sheared"
         v = self.corr_pyramid[lvl][..., :self.h1 * self.w1]
-        if _lib.load().dba_corr_sheared_tiled(self.h1, self.w1):
-            v = v.unflatten(-1, (self.h1 // 4, self.w1 // 16, 4, 16)).permute(0, 1, 2, 3, 5, 4, 6)
+        tw = _lib.load().dba_corr_sheared_tiled(self.h1, self.w1)     # tile width (0: row-major)
+        if tw:
+            th = 64 // tw
+            v = v.unflatten(-1, (self.h1 // th, self.w1 // tw, th, tw)).permute(0, 1, 2, 3, 5, 4, 6)
             return v.reshape(v.shape[:3] + (self.h1, self.w1))
         return v.unflatten(-1, (self.h1, self.w1))
 

@@ -232,7 +232,8 @@ int dba_corr_sheared_plane_elems(int h1, int w1);
  * pixel = ((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) * 64 + (y1 & 3) * 16 + (x1 & 15), so that the 64 pixels of a 128-byte line are
  * neighbours in BOTH directions: the union of their windows -- what a lookup wave reads -- is 79 instead of 92 lines per wave
  * and level on the bench scene, and the lookup's time is proportional to that number (profiles/r04_lookup_lines.txt).  Other
- * maps: pixel = y1 * w1 + x1.  Returns 1 for the tiled order (DBA_SHEAR_TILES=0 keeps every shape linear). */
+ * maps: pixel = y1 * w1 + x1.  Returns the tile width (16) for the tiled order, 0 for the row-major one (DBA_SHEAR_TILES=0
+ * keeps every shape row-major). */
 int dba_corr_sheared_tiled(int h1, int w1);
 /* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 1 = streaming
  * (64-pixel-wide rows only, falls back to resident otherwise), 2 = resident.  Process-wide; results are bit-identical. */

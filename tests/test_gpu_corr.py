@@ -69,7 +69,7 @@ def _smooth_coords(rng, n, h, w):
 
 @pytest.mark.parametrize("layout", ["reference", "sheared"])
 @pytest.mark.parametrize("shape", [(3, 32, 16, 24), (2, 16, 24, 64), (1, 16, 16, 136), (2, 16, 20, 44), (2, 16, 17, 23),
-                                   (1, 16, 18, 71)])
+                                   (1, 16, 18, 71), (2, 16, 12, 128), (1, 16, 8, 192)])
 def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape, lookup_kernel):
     if layout == "reference" and lookup_kernel != "auto":
         pytest.skip("the kernel selection only concerns the sheared layout")
@@ -119,7 +119,7 @@ def test_lookup_non_finite_coords_do_not_fault(layout, lookup_kernel):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64), (3, 32, 24, 64), (1, 16, 8, 64), (2, 128, 28, 107), (1, 32, 55, 55),
-                                   (1, 16, 48, 64), (1, 16, 18, 71), (2, 16, 20, 44), (1, 16, 9, 128), (1, 16, 16, 16),
+                                   (1, 16, 48, 64), (1, 16, 18, 71), (2, 16, 20, 44), (1, 16, 9, 128), (1, 16, 16, 16), (1, 16, 12, 128),
                                    (2, 16, 8, 8), (1, 16, 9, 10), (1, 32, 11, 13), (1, 16, 8, 65), (1, 16, 33, 36),
                                    (1, 128, 55, 55), (2, 128, 18, 44), (3, 128, 9, 10), (1, 128, 11, 13), (5, 128, 8, 8)])
 def test_fused_sheared_build_equals_unfused_pipeline(shape):

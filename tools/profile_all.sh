@@ -13,11 +13,11 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
-bash tools/profile_round.sh $TAG 25_96 corr_lookup_sheared > $OUT/${TAG}_round_25_96.log 2>&1
-bash tools/profile_round.sh $TAG 64_512 corr_lookup_sheared > $OUT/${TAG}_round_64_512.log 2>&1
+bash tools/profile_round.sh $TAG 25_96 corr_lookup_rowtile > $OUT/${TAG}_round_25_96.log 2>&1
+bash tools/profile_round.sh $TAG 64_512 corr_lookup_rowtile > $OUT/${TAG}_round_64_512.log 2>&1
 bash tools/profile_round.sh $TAG 32_122 corr_lookup_resident > $OUT/${TAG}_round_32_122.log 2>&1
 bash tools/profile_round.sh $TAG 9_36_55x55 corr_lookup_resident > $OUT/${TAG}_round_9_36_55x55.log 2>&1
-bash tools/profile_round.sh $TAG 10_54_48x64 corr_lookup_sheared > $OUT/${TAG}_round_10_54_48x64.log 2>&1
+bash tools/profile_round.sh $TAG 10_54_48x64 corr_lookup_rowtile > $OUT/${TAG}_round_10_54_48x64.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 SQ=$OUT/${TAG}_sq
 rm -rf $SQ; mkdir -p $SQ
@@ -40,7 +40,7 @@ timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SQ
 python - > $OUT/${TAG}_sq_counters.txt <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
-names = ("corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur_gram", "ba_schur_kernel", "ba_solve_tile", "ba_solve_band", "ba_update")
+names = ("corr_lookup_rowtile", "corr_lookup_sheared", "corr_lookup_resident", "corr_build_fused", "ba_linearize", "ba_schur_gram", "ba_schur_kernel", "ba_solve_tile", "ba_solve_band", "ba_update")
 for f in glob.glob("$SQ/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
