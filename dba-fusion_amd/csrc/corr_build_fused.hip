@@ -103,12 +103,29 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   _Float16 *T = smem;                              // [64][PITCH]  level 0, rounded; before that: the strip's A operand
   _Float16 *Ab0 = LOOP ? smem + 64 * PITCH : smem;  // the strip's source operand (LOOP: two 16 KB buffers behind the tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int ty0 = blockIdx.y * FT_ROWS;            // first target row of the tile
-  const int e = blockIdx.z;
+  // Workgroup -> (strip group, target-row tile, edge).  Tiled planes: the row tiles ty0 and ty0 + 8 of one source tile write
+  // complementary pieces of the same lines (see the level-0 stores), so all row tiles of a (strip group, edge) go to ONE
+  // XCD -- consecutive dispatch ids round-robin over the 8 XCDs, each XCD takes a contiguous eighth of the logical ids,
+  // row tile fastest -- and run side by side: the pieces then meet in that XCD's L2 and leave it as whole lines.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifndef FB_NO_XCD_MAP
+  if (tiled) {
+    const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+    const int lin = bx + (int)gridDim.x * (by + (int)gridDim.y * bz);
+    const int q8 = total >> 3, r8 = total & 7, xk = lin & 7;
+    const int logical = xk * q8 + min(xk, r8) + (lin >> 3);
+    by = logical % (int)gridDim.y;
+    const int rest = logical / (int)gridDim.y;
+    bx = rest % (int)gridDim.x;
+    bz = rest / (int)gridDim.x;
+  }
+#endif
+  const int ty0 = by * FT_ROWS;                    // first target row of the tile
+  const int e = bz;
   const int HW1 = h1 * w1, HW2 = h2 * w2;
   const int l31 = lane & 31, kh = (lane >> 5) * 8;
   const int nstrips = HW1p >> 6;
-  const int s_begin = LOOP ? (int)blockIdx.x * strips_per_wg : (int)blockIdx.x;
+  const int s_begin = LOOP ? bx * strips_per_wg : bx;
   const int s_end = LOOP ? min(nstrips, s_begin + strips_per_wg) : s_begin + 1;
   constexpr int KSL = 8;                           // k-steps of the LOOP form (C = 128)
   half8 bres[LOOP ? KSL : 1][NT];                  // LOOP: the wave's target fragments, resident
@@ -325,21 +342,28 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   // quad of pixels reads the tile along a diagonal (pixel + 1, column + 1); with columns 0..3 replicated behind the row
   // only the first column wraps, once per line, and the store offset just advances by four planes: ~10 VALU
   // instructions per 8-byte store where the general form needs ~70 ----
+  // Tiled pixel order (common.h): the strip is a 4 x 16 tile of the map, its quads sit on four source rows, and a line of
+  // the planes holds all four at ONE dy = ty - y1.  So that a store instruction still writes whole lines, the quads of tile
+  // row rr take the target row (wave + rr) mod 8 of the workgroup's tile instead of the wave's own: dy is then the same for
+  // every lane of waves 0..4 (four full lines per instruction), and two values, 8 apart, in waves 5..7.  (With the wave's
+  // own row for every quad each instruction wrote sixteen 32-byte pieces: 16.7 against 14.7 us per edge.)
+  const int rr = tiled ? ((lane & 15) >> 2) : 0;
   {
-    const int ty = ty0 + wave;
+    const int wrow = (wave + rr) & (FT_ROWS - 1);
+    const int ty = ty0 + wave, tyq = ty0 + wrow;
 #ifdef FB_ABLATE_L0STORE
     if (ty < 0) {
 #else
-    if (ty < h2) {  // (wave-uniform)
+    if (tiled || ty < h2) {  // (wave-uniform)
 #endif
       const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
-      if (quad_regular) {
+      if (quad_regular && tyq < h2) {
         int t = qx[0] + g;
         t -= (t >= w2) ? w2 : 0;
-        int dy = ty - qy[0];
+        int dy = tyq - qy[0];
         dy += (dy < 0) ? h2 : 0;
         unsigned voff = ((unsigned)dy * (unsigned)w2 + (unsigned)g) * plane_bytes + 2u * (unsigned)(p0 + q4);
-        const _Float16 *lb = T + q4 * PITCH + wave * RP;
+        const _Float16 *lb = T + q4 * PITCH + wrow * RP;
         for (int dx0 = 0; dx0 < w2; dx0 += 16) {  // four lines per batch: their 16 LDS reads are in flight together
           unsigned short a[4][4];
 #pragma unroll
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           }
         }
       }
-      for (unsigned long long m = irregular; m; m &= m - 1) {
+      for (unsigned long long m = (ty < h2) ? irregular : 0ull; m; m &= m - 1) {
         const int pl = 4 * (int)__builtin_ctzll(m) + ipx;  // this lane's pixel of the quad, within the strip
         int xi, yi;
         pixel_xy(p0 + pl, xi, yi);
@@ -454,17 +478,19 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
     const int w2l = w2 >> 1, h2l = h2 >> 1;
     const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
     const int tyl = wave & 3, tyg = (ty0 >> 1) + tyl;
-    if (tyg < h2l) {  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
-      if (quad_regular) {
+    // (tiled: the quads of tile rows 2, 3 -- level-1 source row + 1 -- take the next pooled row, see level 0)
+    const int tylq = (tyl + (rr >> 1)) & 3, tygq = (ty0 >> 1) + tylq;
+    if (tiled || tyg < h2l) {  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
+      if (quad_regular && tygq < h2l) {
         const int xh = qx[0] >> 1;
         const int o1 = (qx[1] >> 1) - xh, o2 = (qx[2] >> 1) - xh, o3 = (qx[3] >> 1) - xh;
         int t = xh + 4 * (wave >> 2) + g;
         t -= (t >= w2l) ? w2l : 0;
         t -= (t >= w2l) ? w2l : 0;  // (maps down to 8 columns: twice)
-        int dy = tyg - (qy[0] >> 1);
+        int dy = tygq - (qy[0] >> 1);
         dy += (dy < 0) ? h2l : 0;
         unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * (wave >> 2) + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
-        const _Float16 *lb = P1 + (q4 * 4 + tyl) * RP1;
+        const _Float16 *lb = P1 + (q4 * 4 + tylq) * RP1;
         for (int dx0 = 4 * (wave >> 2); dx0 < w2l; dx0 += 8) {
           const _Float16 *pp = lb + t;
           const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
@@ -480,7 +506,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           t -= (t >= w2l) ? w2l : 0;
         }
       }
-      for (unsigned long long m = irregular; m; m &= m - 1) {  // (the two waves of a row take alternate groups of 16 offsets)
+      for (unsigned long long m = (tyg < h2l) ? irregular : 0ull; m; m &= m - 1) {  // (the two waves of a row take alternate groups of 16 offsets)
         const int pl = 4 * (int)__builtin_ctzll(m) + ipx;
         int xi, yi;
         pixel_xy(p0 + pl, xi, yi);
