@@ -273,6 +273,208 @@ __global__ __launch_bounds__(256) void altcorr_backward_kernel(const float *__re
     if (k < cn) o[k] += f1g[k];
 }
 
+
+// =====================================================================================================================
+// The same op as a contraction on the matrix cores, for HALF feature pyramids and float output: what AltCorrBlock computes
+// in the reference (dbaf/modules/corr.py:107-125: the half pyramid of fmaps / 4 is cast with .float() at every lookup and
+// correlated in float).  Products of two halves are exact in float, so feeding the halves to v_mfma_f32_32x32x16_f16
+// differs from the reference's float chain only in the ORDER of the float additions (tests: <= 2e-5 of the reference).
+//
+// A workgroup (8 waves) owns a 4 x 16 tile of source pixels of one (edge, coordinate set, level).  The windows of the 64
+// pixels overlap (coherent flow): their union box, clipped to the level's map, is a few hundred target pixels (bench scene:
+// 252 / 128 / 72 / 42 on the four levels, never above 378).  The tile's correlation with that box -- 64 sources x NB targets
+// x C channels -- is ONE small GEMM instead of 64 x 64 separate dot products that each re-read their operands:
+//   * wave w takes the target blocks w, w + 8 (32 targets each); their fragments (a target pixel's C halves are
+//     contiguous in the channels-last pyramid: 16-byte loads, no staging) stay in registers for both source halves;
+//   * per half of the tile (32 sources: two tile rows) the products targets x sources leave the accumulators as float quads
+//     of four consecutive targets of one source into an LDS tile T[32][NB] (50 KB: three workgroups per CU);
+//   * window phase: thread (pixel p of the half, output row g, half of the output columns) reads its 2 x 5 taps from T[p] -- taps outside
+//     the box are outside the map: zeros --, blends them with the pixel's four bilinear weights in the reference's
+//     se, sw, ne, nw order and stores its 4 (3) outputs of row g.
+// A tile whose clipped box exceeds ALTM_NB targets (incoherent coordinates) computes its taps as per-thread dot products.
+typedef _Float16 altm_half8 __attribute__((ext_vector_type(8)));
+typedef float altm_f16v __attribute__((ext_vector_type(16)));
+typedef float altm_f4v __attribute__((ext_vector_type(4)));
+constexpr int ALTM_NB = 384;                // targets of a box the LDS tile holds (12 blocks of 32)
+constexpr int ALTM_PITCH = ALTM_NB + 4;     // floats per source row: 16-byte aligned quads, rows 4 banks apart
+constexpr int ALTM_KS = 8;                  // k-steps of 16 channels: C <= 128
+#ifndef ALTM_WAVES_DEF
+#define ALTM_WAVES_DEF 4
+#endif
+#ifndef ALTM_MIN_WAVES
+#define ALTM_MIN_WAVES 2
+#endif
+// waves per workgroup (4 or 8), target blocks per wave (waves x blocks x 32 >= ALTM_NB), output columns per window thread
+// (4 waves: a thread takes an output row; 8 waves: half a row)
+constexpr int ALTM_WAVES = ALTM_WAVES_DEF, ALTM_BPW = 12 / ALTM_WAVES + (ALTM_WAVES == 8 ? 1 : 0), ALTM_NOX = (ALTM_WAVES == 8) ? 4 : 7;
+static_assert(ALTM_WAVES * ALTM_BPW * 32 >= ALTM_NB, "every block of the box has a wave");
+
+__global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_kernel(const _Float16 *__restrict__ fmap1, AltLevels Lv,
+                                                           const float *__restrict__ coords, float *__restrict__ corr, int S,
+                                                           int H1, int W1, int C, int num_levels,
+                                                           const int64_t *__restrict__ ii, const int64_t *__restrict__ jj) {
+  constexpr int R = 3, RD = 7, WN = 8;
+  extern __shared__ __attribute__((aligned(16))) float altm_tile[];   // [32][ALTM_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bs = blockIdx.z;
+  const int lvl = bs % num_levels;
+  bs /= num_levels;
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const _Float16 *fmap2 = static_cast<const _Float16 *>(Lv.f2[lvl]);
+  const int b = bs / S;
+  const int b1 = ii ? (int)ii[b] : b, b2 = jj ? (int)jj[b] : b;
+  const int HW1 = H1 * W1;
+  const int ksteps = C >> 4;
+
+  // ---- every wave: lane = pixel of the tile (row lane >> 4, column lane & 15) ------------------------------------------------
+  const int h1 = blockIdx.y * ALT_TH + (lane >> 4), w1 = blockIdx.x * ALT_TW + (lane & 15);
+  const bool inb = (h1 < H1) && (w1 < W1);
+  const int pix = min(h1, H1 - 1) * W1 + min(w1, W1 - 1);
+  const float *cp = coords + ((size_t)bs * HW1 + pix) * 2;
+  const float cscale = 1.0f / (float)(1 << lvl);   // coords / 2**i (corr.py:116): exact
+  const float x2 = cp[0] * cscale, y2 = cp[1] * cscale;
+  const float fxf = floorf(x2), fyf = floorf(y2);
+  const float dx = x2 - fxf, dy = y2 - fyf;
+  const bool sane = (fabsf(x2) < 1.0e6f) && (fabsf(y2) < 1.0e6f);
+  const int wx0 = sane ? (int)fxf - R : -(1 << 20), wy0 = sane ? (int)fyf - R : -(1 << 20);
+  const bool hits = inb && sane && (wx0 + WN > 0) && (wx0 < W2) && (wy0 + WN > 0) && (wy0 < H2);
+  const float wnw = dy * dx, wne = dy * (1 - dx), wsw = (1 - dy) * dx, wse = (1 - dy) * (1 - dx);   // (altcorr_kernel.cu:112-115)
+  const int big = 1 << 28;
+  const bool any = __ballot(hits) != 0ull;
+  // the union box of the windows, clipped to the map: columns cx0 .. cx1 - 1, rows cy0 .. cy1 - 1
+  const int cx0 = max(wave_minmax<true>(hits ? wx0 : big), 0), cx1 = min(wave_minmax<false>(hits ? wx0 : -big) + WN, W2);
+  const int cy0 = max(wave_minmax<true>(hits ? wy0 : big), 0), cy1 = min(wave_minmax<false>(hits ? wy0 : -big) + WN, H2);
+  const int CW = any ? cx1 - cx0 : 0, CH = any ? cy1 - cy0 : 0;
+  const int NBX = CW * CH;
+  const bool boxed = any && NBX <= ALTM_NB;
+  const int nblk = boxed ? (NBX + 31) >> 5 : 0;
+  const _Float16 *f2b = fmap2 + (size_t)b2 * H2 * W2 * C;
+  const int l31 = lane & 31, kh = (lane >> 5) * 8;
+
+  // ---- this wave's target fragments: block `blk`, target t = 32 blk + (lane & 31), channels 16 ks + 8 (lane >> 5) .. + 7 ------
+  altm_half8 tf[ALTM_BPW][ALTM_KS];
+#pragma unroll
+  for (int u = 0; u < ALTM_BPW; u++) {
+    const int blk = wave + ALTM_WAVES * u;
+    const int t = blk * 32 + l31;
+    const bool tok = (blk < nblk) && (t < NBX);
+    const int tyy = tok ? t / CW : 0, txx = tok ? t - tyy * CW : 0;
+    const _Float16 *tp = f2b + ((size_t)(cy0 + tyy) * W2 + (cx0 + txx)) * C + kh;
+#pragma unroll
+    for (int ks = 0; ks < ALTM_KS; ks++) {
+      altm_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (tok && ks < ksteps) v = *reinterpret_cast<const altm_half8 *>(tp + ks * 16);
+      tf[u][ks] = v;
+    }
+  }
+
+  // window-phase role of this thread: pixel p of the current half, output row g (tap rows g, g + 1), output columns
+  // ox0 .. ox0 + 3 (tap columns ox0 .. ox0 + 4): the 7 x 7 outputs of a pixel are dealt to 14 threads
+  const int p = tid & 31, g = (tid >> 5) & 7, ox0 = (tid >> 8) * ALTM_NOX;
+  float *const orow_base = corr + ((size_t)(bs * num_levels + lvl) * RD * RD) * HW1;
+
+  for (int half = 0; half < 2; half++) {
+    const int src_lane = half * 32 + p;   // the pixel's lane in the prologue's numbering
+    const int pwx0 = __builtin_amdgcn_ds_bpermute(src_lane * 4, wx0), pwy0 = __builtin_amdgcn_ds_bpermute(src_lane * 4, wy0);
+    const float pnw = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(wnw)));
+    const float pne = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(wne)));
+    const float psw = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(wsw)));
+    const float pse = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(wse)));
+    const int pflags = __builtin_amdgcn_ds_bpermute(src_lane * 4, (hits ? 1 : 0) | (inb ? 2 : 0));
+    const int ppix = __builtin_amdgcn_ds_bpermute(src_lane * 4, pix);
+    const bool phits = (pflags & 1) != 0, pinb = (pflags & 2) != 0;
+    float taps[2][ALTM_NOX + 1];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int i = 0; i < ALTM_NOX + 1; i++) taps[r][i] = 0.f;
+
+    if (boxed) {
+      // ---- products: acc[u][r] = target block u x the half's 32 sources ---------------------------------------------------------
+      altm_f16v acc[ALTM_BPW];
+#pragma unroll
+      for (int u = 0; u < ALTM_BPW; u++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[u][r] = 0.f;
+      const int spix = __builtin_amdgcn_ds_bpermute((half * 32 + l31) * 4, pix);   // source pixel of this lane's fragment
+      const _Float16 *sp = fmap1 + ((size_t)b1 * HW1 + spix) * C + kh;
+      // (blocks past the box and k-steps past C hold zero target fragments: their products are computed and never read)
+#pragma unroll
+      for (int ks = 0; ks < ALTM_KS; ks++) {
+        altm_half8 sf = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ks < ksteps) sf = *reinterpret_cast<const altm_half8 *>(sp + ks * 16);
+#pragma unroll
+        for (int u = 0; u < ALTM_BPW; u++)
+          if (u == 0 || wave + ALTM_WAVES * u < nblk)   // (wave-uniform; block u = 0 past the box: zero fragments)
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf[u][ks], sf, acc[u], 0, 0, 0);  // targets x sources
+      }
+      if (half) __syncthreads();   // the first half's window phase has read the tile
+      // D layout: column = lane & 31 (source), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (target within the block)
+#pragma unroll
+      for (int u = 0; u < ALTM_BPW; u++) {
+        if (wave + ALTM_WAVES * u < nblk) {
+#pragma unroll
+          for (int rq = 0; rq < 4; rq++) {
+            altm_f4v v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = acc[u][4 * rq + q];
+            *reinterpret_cast<altm_f4v *>(altm_tile + l31 * ALTM_PITCH + (wave + ALTM_WAVES * u) * 32 + 8 * rq + 4 * (lane >> 5)) = v;
+          }
+        }
+      }
+      __syncthreads();
+      if (phits && g < RD) {
+        const float *trow = altm_tile + p * ALTM_PITCH;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int ty = pwy0 + g + r;
+          const bool rok = (ty >= cy0) && (ty < cy1);
+#pragma unroll
+          for (int i = 0; i < ALTM_NOX + 1; i++) {
+            const int tx = pwx0 + ox0 + i;
+            const bool ok = rok && (tx >= cx0) && (tx < cx1);
+            taps[r][i] = ok ? trow[(ty - cy0) * CW + (tx - cx0)] : 0.f;
+          }
+        }
+      }
+    } else if (phits && g < RD) {
+      // ---- incoherent tile: this thread's 16 taps as dot products (float accumulation of exact products) -----------------------
+      const _Float16 *sp = fmap1 + ((size_t)b1 * HW1 + ppix) * C;
+      for (int c = 0; c < C; c += 8) {
+        const altm_half8 a = *reinterpret_cast<const altm_half8 *>(sp + c);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int ty = pwy0 + g + r;
+#pragma unroll
+          for (int i = 0; i < ALTM_NOX + 1; i++) {
+            const int tx = pwx0 + ox0 + i;
+            if (ty >= 0 && ty < H2 && tx >= 0 && tx < W2) {
+              const altm_half8 v = *reinterpret_cast<const altm_half8 *>(f2b + ((size_t)ty * W2 + tx) * C + c);
+              float sd = taps[r][i];
+#pragma unroll
+              for (int k = 0; k < 8; k++) sd = __builtin_fmaf((float)a[k], (float)v[k], sd);
+              taps[r][i] = sd;
+            }
+          }
+        }
+      }
+    }
+    // ---- blend (the reference's order of a tap's four updates: se, then sw, ne, nw of the later taps) and store row g ----------
+    if (pinb && g < RD) {
+      float *o = orow_base + ppix + (size_t)(g + RD * ox0) * HW1;   // channel = iy + RD * ix
+#pragma unroll
+      for (int ox = 0; ox < ALTM_NOX; ox++) {
+        float v = taps[0][ox] * pse;
+        v = v + taps[0][ox + 1] * psw;
+        v = v + taps[1][ox] * pne;
+        v = v + taps[1][ox + 1] * pnw;
+        // (no hit: zero taps; NaN coordinates give NaN weights and NaN here, like the reference)
+        if (ox0 + ox < RD) o[(size_t)(RD * ox) * HW1] = v;
+      }
+    }
+  }
+}
+
 }  // namespace dba
 
 using namespace dba;
@@ -330,6 +532,24 @@ extern "C" int dba_altcorr_pyramid_forward(const void *fmap1, const void *const 
     return altcorr_forward_launch<_Float16>(fmap1, nullptr, coords, corr, B, S, H1, W1, H1, W1, C, radius, (hipStream_t)stream,
                                             Lv, num_levels, ii, jj);
   return DBA_ERR_UNSUPPORTED;
+}
+
+extern "C" int dba_altcorr_pyramid_forward_f16maps(const void *fmap1, const void *const *fmap2_levels, const int64_t *ii,
+                                                   const int64_t *jj, const float *coords, float *corr, int B, int S, int H1,
+                                                   int W1, int C, int num_levels, int radius, dba_stream_t stream) {
+  if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || C <= 0 || num_levels < 1 || num_levels > 8) return DBA_ERR_ARG;
+  if (radius != 3 || (C % 16) != 0 || C > 16 * ALTM_KS) return DBA_ERR_UNSUPPORTED;
+  if ((long)B * S == 0) return DBA_OK;
+  if ((long)B * S * num_levels > 65535) return DBA_ERR_UNSUPPORTED;
+  if (!fmap1 || !fmap2_levels || !coords || !corr) return DBA_ERR_ARG;
+  if ((H1 >> (num_levels - 1)) < 1 || (W1 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
+  AltLevels Lv;
+  for (int l = 0; l < 8; l++) Lv.f2[l] = (l < num_levels) ? fmap2_levels[l] : nullptr;
+  dim3 grid((W1 + ALT_TW - 1) / ALT_TW, (H1 + ALT_TH - 1) / ALT_TH, B * S * num_levels);
+  hipLaunchKernelGGL(altcorr_mfma_kernel, grid, dim3(64 * ALTM_WAVES), (size_t)32 * ALTM_PITCH * sizeof(float), (hipStream_t)stream,
+                     static_cast<const _Float16 *>(fmap1), Lv, coords, corr, S, H1, W1, C, num_levels, ii, jj);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
 }
 
 extern "C" int dba_altcorr_forward(const float *fmap1, const float *fmap2, const float *coords, float *corr,

@@ -71,6 +71,7 @@ SYMBOLS = {
     "dba_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P]),
     "dba_altcorr_forward_t": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),
     "dba_altcorr_pyramid_forward": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
+    "dba_altcorr_pyramid_forward_f16maps": (c_int, [_P] * 6 + [c_int] * 7 + [_P]),
     "dba_altcorr_backward": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
     "dba_reproject": (c_int, [_P] * 5 + [c_int] * 3 + [_P, _P, _P]),
     "dba_frame_distance": (c_int, [_P] * 5 + [c_int] * 3 + [c_float, _P, _P]),

@@ -468,6 +468,7 @@ class AltCorrBlock:
                 level = F.avg_pool2d(level, 2, stride=2)
             self.pyramid.append(level.permute(0, 2, 3, 1).reshape(B, N, H >> lvl, W >> lvl, C).contiguous())
         self._f32 = None
+        self.mfma = os.environ.get("DBA_ALTCORR_MFMA", "1") != "0"   # half pyramids: the matrix-core form (csrc/altcorr.hip)
 
     def _float_pyramid(self):
         if self._f32 is None:
@@ -478,10 +479,9 @@ class AltCorrBlock:
         """coords [B, N, H, W, S, 2] -> [B, N, L * 49, H, W, S]"""
         B, N, H, W, S, _ = coords.shape
         rd2 = (2 * self.radius + 1) ** 2
-        pyr = self._float_pyramid()
         cs = coords.movedim(4, 2).reshape(B * N, S, H, W, 2)               # the S coordinate sets in front of the pixels
-        wants_grad = torch.is_grad_enabled() and (coords.requires_grad or any(p.requires_grad for p in pyr))
-        F_ = pyr[0].shape[1]                                               # frames per batch entry
+        wants_grad = torch.is_grad_enabled() and (coords.requires_grad or any(p.requires_grad for p in self.pyramid))
+        F_ = self.pyramid[0].shape[1]                                      # frames per batch entry
         if not wants_grad and cs.is_cuda and (H >> (self.num_levels - 1)) >= 1 and (W >> (self.num_levels - 1)) >= 1 \
                 and B * N * S * self.num_levels <= 65535:
             ii_ = torch.as_tensor(ii, device=cs.device).to(torch.int64).reshape(-1)
@@ -492,11 +492,24 @@ class AltCorrBlock:
             c = cs if (cs.dtype == torch.float32 and cs.is_contiguous()) else cs.float().contiguous()
             out = torch.empty(B * N, S, self.num_levels * rd2, H, W, dtype=torch.float32, device=cs.device)
             lib = _lib.load()
+            half = self.pyramid
+            Cn = int(half[0].shape[-1])
+            if self.mfma and half[0].dtype == torch.float16 and self.radius == 3 and Cn % 16 == 0 and Cn <= 128:
+                # the reference's case (half maps under autocast, `.float()` at the lookup): the halves go to the matrix cores
+                # as they are -- exact products, float sums; no float twins of the pyramid are made at all
+                ptrs = (ctypes.c_void_p * self.num_levels)(*[p.data_ptr() for p in half])
+                _lib.check(lib.dba_altcorr_pyramid_forward_f16maps(_ptr(half[0]), ptrs, _ptr(ii_.contiguous()),
+                                                                   _ptr(jj_.contiguous()), _ptr(c), _ptr(out), B * N, S, H, W, Cn,
+                                                                   self.num_levels, self.radius, _stream()),
+                           "dba_altcorr_pyramid_forward_f16maps")
+                return out.reshape(B, N, S, self.num_levels * rd2, H, W).movedim(2, -1)
+            pyr = self._float_pyramid()
             ptrs = (ctypes.c_void_p * self.num_levels)(*[p.data_ptr() for p in pyr])
             _lib.check(lib.dba_altcorr_pyramid_forward(_ptr(pyr[0]), ptrs, _ptr(ii_.contiguous()), _ptr(jj_.contiguous()), _ptr(c),
                                                        _ptr(out), B * N, S, H, W, int(pyr[0].shape[-1]), self.num_levels,
                                                        self.radius, _lib.DBA_F32, _stream()), "dba_altcorr_pyramid_forward")
             return out.reshape(B, N, S, self.num_levels * rd2, H, W).movedim(2, -1)
+        pyr = self._float_pyramid()
         src = pyr[0][:, ii].reshape(B * N, H, W, -1)                       # level-0 maps of the source frames
         out = coords.new_empty(B, N, self.num_levels * rd2, H, W, S, dtype=src.dtype)
         for lvl, tgt_all in enumerate(pyr):

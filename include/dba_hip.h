@@ -337,6 +337,15 @@ int dba_altcorr_pyramid_forward(const void *fmap1, const void *const *fmap2_leve
                                 const int64_t *ii, const int64_t *jj, const float *coords, void *corr, int B, int S, int H1,
                                 int W1, int C, int num_levels, int radius, int dtype, dba_stream_t stream);
 
+/* The same lookup for HALF feature pyramids with float output, on the matrix cores: what AltCorrBlock computes in the
+ * reference, whose half pyramid (fmaps / 4 under autocast) is cast with .float() at every lookup (dbaf/modules/corr.py:120)
+ * and correlated in float.  Products of halves are exact in float; the result differs from the float chain of
+ * altcorr_kernel.cu:58-147 only in the order of the float additions.  fmap1 / fmap2_levels: half, channels-last
+ * [F, H1 >> l, W1 >> l, C]; C % 16 == 0, C <= 128; radius 3; corr: float [B, S, L * 49, H1, W1]. */
+int dba_altcorr_pyramid_forward_f16maps(const void *fmap1, const void *const *fmap2_levels /* host array of L device ptrs */,
+                                        const int64_t *ii, const int64_t *jj, const float *coords, float *corr, int B, int S,
+                                        int H1, int W1, int C, int num_levels, int radius, dba_stream_t stream);
+
 /* altcorr_backward (src/droid.cpp:266-278, src/altcorr_kernel.cu:152-286,321-356; training only):
  * gradients wrt the feature maps; fmap1_grad [B,H1,W1,C], fmap2_grad [B,H2,W2,C] must be zero-initialised
  * by the caller (fmap2_grad is accumulated with float atomics like the reference); the reference's

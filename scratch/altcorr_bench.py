@@ -70,3 +70,15 @@ with torch.no_grad():
 cg = coords.clone().requires_grad_(True)
 per_level = timed(lambda: blk(cg, ii, jj))
 print("AltCorrBlock.__call__, 96 edges, float: one launch %.1f us; per-level route (autograd) %.1f us" % (fused, per_level), flush=True)
+
+# the reference's case: HALF maps (autocast) -> the matrix-core form (one small GEMM per 4 x 16 tile and level)
+blk_h = AltCorrBlock(t(syn.make_fmaps(W.B, 128, W.h, W.w, 1000))[None], num_levels=4, radius=3)
+assert blk_h.pyramid[0].dtype == torch.float16
+with torch.no_grad():
+    mf = timed(lambda: blk_h(coords, ii, jj))
+    a = blk_h(coords, ii, jj)
+    blk_h.mfma = False
+    fl = timed(lambda: blk_h(coords, ii, jj))
+    b = blk_h(coords, ii, jj)
+print("AltCorrBlock.__call__ on HALF maps, 96 edges: matrix cores %.1f us, float chain on the .float() twins %.1f us; max |diff| %.2e "
+      "(|corr| max %.2f)" % (mf, fl, float((a - b).abs().max()), float(b.abs().max())), flush=True)

@@ -292,6 +292,56 @@ def test_altcorrblock_mirror_matches_per_level_oracle():
     np.testing.assert_allclose(got, vol, rtol=0, atol=0.02 * np.abs(vol).max())
 
 
+@pytest.mark.parametrize("case", ["smooth", "random", "edges", "wide"])
+def test_altcorrblock_on_half_maps_runs_on_the_matrix_cores_and_matches_the_float_chain(case):
+    """The reference's case: the feature maps are HALF (autocast), AltCorrBlock keeps fmaps / 4 and its 2x2 averages in half
+    and casts them with .float() at every lookup (modules/corr.py:98-120).  dbaf_amd.corr.AltCorrBlock then feeds the halves
+    to the matrix cores (dba_altcorr_pyramid_forward_f16maps: exact products, float sums): equal to the float chain on the
+    .float() maps up to the order of the float additions, on coherent flow (one small GEMM per 4 x 16 tile), on incoherent
+    coordinates (per-thread dot products), at the map borders, for NaN / huge coordinates and on maps that are not whole tiles."""
+    from dbaf_amd.corr import AltCorrBlock
+    orc = _oracle()
+    rng = np.random.default_rng(23)
+    B, N, C, H, W = (1, 3, 128, 24, 32) if case != "wide" else (1, 2, 64, 18, 71)
+    fmaps = (0.5 * rng.standard_normal((B, N, C, H, W))).astype(np.float16)
+    ii, jj = np.array([0, 1, 2 % N, 0]), np.array([1, 0, 0, 1])
+    E = len(ii)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    if case == "random":
+        coords = np.stack([rng.uniform(-6, W + 6, (E, H, W)), rng.uniform(-6, H + 6, (E, H, W))], -1).astype(np.float32)
+    else:
+        amp = 2.0 if case != "edges" else 14.0
+        coords = np.stack([xx[None] + rng.uniform(-amp, amp, (E, 1, 1)) + 0.3 * np.sin(yy / 3)[None],
+                           yy[None] + rng.uniform(-amp, amp, (E, 1, 1)) + 0.3 * np.cos(xx / 4)[None]], -1).astype(np.float32)
+    coords[0, 0, 0] = (np.nan, 1.0)
+    coords[0, 0, 1] = (3.0e9, 2.0)
+    coords[0, 0, 2] = (5.0, 7.0)                     # integer coordinates
+    coords[1, 3, 4] = (-300.0, 9.0)                  # a window that misses the map must not stretch the tile's box
+    t = torch.from_numpy(fmaps).cuda()
+    blk = AltCorrBlock(t, num_levels=4, radius=3)
+    assert blk.pyramid[0].dtype == torch.float16 and blk.mfma
+    cdev = torch.from_numpy(coords)[None].cuda()
+    iid, jjd = torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()
+    out = blk(cdev, iid, jjd)
+    assert out.shape == (1, E, 196, H, W) and out.dtype == torch.float32 and blk._f32 is None   # no float twins were made
+    got = out.cpu().numpy()[0]
+    pyr = [p.float().cpu().numpy()[0] for p in blk.pyramid]
+    for lvl in range(4):
+        ref = orc.altcorr_forward(pyr[0][ii], pyr[lvl][jj], (coords / 2 ** lvl)[:, None], 3)[:, 0]
+        np.testing.assert_allclose(got[:, 49 * lvl:49 * lvl + 49], ref, rtol=2e-5, atol=2e-5)
+    assert np.isnan(got[0, :, 0, 0]).all() and (got[0, :, 0, 1] == 0).all()   # NaN weights / a window far off the map
+    # the float route of the same block (DBA_ALTCORR_MFMA=0 / float maps) agrees to the same bound
+    blk.mfma = False
+    out_f = blk(cdev, iid, jjd).cpu().numpy()[0]
+    np.testing.assert_allclose(got, out_f, rtol=2e-5, atol=2e-5)
+    # two coordinate sets per pixel
+    blk.mfma = True
+    c2 = torch.stack([cdev, cdev + 0.37], 4)
+    out2 = blk(c2, iid, jjd)
+    assert out2.shape == (1, E, 196, H, W, 2)
+    assert torch.equal(torch.nan_to_num(out2[..., 0], nan=7.0), torch.nan_to_num(out, nan=7.0))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_corr_index_backward_matches_oracle(dtype):
     import droid_backends
