@@ -298,6 +298,7 @@ typedef float altm_f4v __attribute__((ext_vector_type(4)));
 constexpr int ALTM_NB = 384;                // targets of a box the LDS tile holds (12 blocks of 32)
 constexpr int ALTM_PITCH = ALTM_NB + 4;     // floats per source row: 16-byte aligned quads, rows 4 banks apart
 constexpr int ALTM_KS = 8;                  // k-steps of 16 channels: C <= 128
+constexpr int ALTM_ROW = 144;               // bytes of a staged operand row: 64 channels + 16 bytes (bank spread)
 #ifndef ALTM_WAVES_DEF
 #define ALTM_WAVES_DEF 4
 #endif
@@ -308,6 +309,8 @@ constexpr int ALTM_KS = 8;                  // k-steps of 16 channels: C <= 128
 // (4 waves: a thread takes an output row; 8 waves: half a row)
 constexpr int ALTM_WAVES = ALTM_WAVES_DEF, ALTM_BPW = 12 / ALTM_WAVES + (ALTM_WAVES == 8 ? 1 : 0), ALTM_NOX = (ALTM_WAVES == 8) ? 4 : 7;
 static_assert(ALTM_WAVES * ALTM_BPW * 32 >= ALTM_NB, "every block of the box has a wave");
+constexpr int ALTM_SRC_OFF = 32 * ALTM_PITCH * 4, ALTM_TGT_OFF = ALTM_SRC_OFF + 64 * ALTM_ROW;
+constexpr int ALTM_LDS_BYTES = ALTM_TGT_OFF + ALTM_WAVES * 32 * ALTM_ROW;
 
 __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_kernel(const _Float16 *__restrict__ fmap1, AltLevels Lv,
                                                            const float *__restrict__ coords, float *__restrict__ corr, int S,
@@ -351,20 +354,85 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
   const _Float16 *f2b = fmap2 + (size_t)b2 * H2 * W2 * C;
   const int l31 = lane & 31, kh = (lane >> 5) * 8;
 
-  // ---- this wave's target fragments: block `blk`, target t = 32 blk + (lane & 31), channels 16 ks + 8 (lane >> 5) .. + 7 ------
-  altm_half8 tf[ALTM_BPW][ALTM_KS];
+  // ---- operands through LDS.  A lane that loads ITS fragment straight from the channels-last map takes 16 bytes out of a line
+  // of its own: a wave's load instruction then touches 32 lines for 1 KB (the texture addresser walks them one by one; the
+  // kernel was bound by exactly that: 445 us).  Staged, an instruction reads whole lines -- lane = (pixel l >> 3, 16-byte
+  // piece l & 7): eight pixels x 128 contiguous bytes -- into rows of 144 bytes (36 words: the fragment reads of 32
+  // consecutive pixels, 16 bytes each, fall into different banks), one HALF of the channels at a time:
+  //   ALTM_SRC  [64 pixels][144 B]   the tile's sources, staged by the whole workgroup
+  //   ALTM_TGT  [wave][32 targets][144 B]   the block a wave is multiplying, private to the wave (LDS operations of one wave
+  //             execute in order: no barrier between its writes and its fragment reads)
+  // offsets (halves) of this lane's pieces: sources P = tid >> 3 and P + 32; targets 8 j + (lane >> 3) of block u
+  const int piece = lane & 7;
+  unsigned char *const lds_src = reinterpret_cast<unsigned char *>(altm_tile) + ALTM_SRC_OFF;
+  unsigned char *const lds_tgt = reinterpret_cast<unsigned char *>(altm_tile) + ALTM_TGT_OFF + wave * (32 * ALTM_ROW);
+  long soff[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int P = (tid >> 3) + 32 * j;
+    soff[j] = ((long)b1 * HW1 + __builtin_amdgcn_ds_bpermute(P * 4, pix)) * C + 8 * piece;
+  }
+  int toff[ALTM_BPW][4];   // -1: no such target
+  const float inv_cw = 1.0f / (float)max(CW, 1);
 #pragma unroll
   for (int u = 0; u < ALTM_BPW; u++) {
     const int blk = wave + ALTM_WAVES * u;
-    const int t = blk * 32 + l31;
-    const bool tok = (blk < nblk) && (t < NBX);
-    const int tyy = tok ? t / CW : 0, txx = tok ? t - tyy * CW : 0;
-    const _Float16 *tp = f2b + ((size_t)(cy0 + tyy) * W2 + (cx0 + txx)) * C + kh;
 #pragma unroll
-    for (int ks = 0; ks < ALTM_KS; ks++) {
-      altm_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (tok && ks < ksteps) v = *reinterpret_cast<const altm_half8 *>(tp + ks * 16);
-      tf[u][ks] = v;
+    for (int j = 0; j < 4; j++) {
+      const int t = blk * 32 + 8 * j + (lane >> 3);
+      const bool tok = (blk < nblk) && (t < NBX);
+      const int tyy = tok ? (int)(((float)t + 0.5f) * inv_cw) : 0, txx = tok ? t - tyy * CW : 0;   // (t < 384: exact)
+      toff[u][j] = tok ? ((cy0 + tyy) * W2 + (cx0 + txx)) * C + 8 * piece : -1;
+    }
+  }
+  const altm_half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  altm_f16v acc[2][ALTM_BPW];   // [source half][target block]: targets x sources, both halves of the tile at once
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int u = 0; u < ALTM_BPW; u++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[h][u][r] = 0.f;
+  if (boxed) {
+    for (int kq = 0; kq * 64 < C; kq++) {   // channels 64 kq .. 64 kq + 63
+      const int kbase = 64 * kq;
+      const bool pok = kbase + 8 * piece < C;   // (C % 16 == 0: a 16-byte piece is inside or outside)
+      altm_half8 sreg[2], treg[ALTM_BPW][4];
+#pragma unroll
+      for (int j = 0; j < 2; j++) sreg[j] = pok ? *reinterpret_cast<const altm_half8 *>(fmap1 + soff[j] + kbase) : zero8;
+#pragma unroll
+      for (int u = 0; u < ALTM_BPW; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          treg[u][j] = (pok && toff[u][j] >= 0) ? *reinterpret_cast<const altm_half8 *>(f2b + toff[u][j] + kbase) : zero8;
+      if (kq) __syncthreads();   // every wave has read the previous half's source fragments
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        *reinterpret_cast<altm_half8 *>(lds_src + ((tid >> 3) + 32 * j) * ALTM_ROW + piece * 16) = sreg[j];
+      __syncthreads();
+      altm_half8 sf[2][4];   // source fragments: pixel 32 h + (lane & 31), channels 16 ks + 8 (lane >> 5) .. + 7
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+          sf[h][ks] = *reinterpret_cast<const altm_half8 *>(lds_src + (32 * h + l31) * ALTM_ROW + (2 * ks + (lane >> 5)) * 16);
+#pragma unroll
+      for (int u = 0; u < ALTM_BPW; u++) {
+        if (wave + ALTM_WAVES * u < nblk) {   // (wave-uniform)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            *reinterpret_cast<altm_half8 *>(lds_tgt + (8 * j + (lane >> 3)) * ALTM_ROW + piece * 16) = treg[u][j];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) {
+            const altm_half8 tfr = *reinterpret_cast<const altm_half8 *>(lds_tgt + l31 * ALTM_ROW + (2 * ks + (lane >> 5)) * 16);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+              acc[h][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tfr, sf[h][ks], acc[h][u], 0, 0, 0);  // targets x sources
+          }
+          __builtin_amdgcn_wave_barrier();   // the next block overwrites the staging rows
+        }
+      }
     }
   }
 
@@ -373,6 +441,7 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
   const int p = tid & 31, g = (tid >> 5) & 7, ox0 = (tid >> 8) * ALTM_NOX;
   float *const orow_base = corr + ((size_t)(bs * num_levels + lvl) * RD * RD) * HW1;
 
+#pragma unroll
   for (int half = 0; half < 2; half++) {
     const int src_lane = half * 32 + p;   // the pixel's lane in the prologue's numbering
     const int pwx0 = __builtin_amdgcn_ds_bpermute(src_lane * 4, wx0), pwy0 = __builtin_amdgcn_ds_bpermute(src_lane * 4, wy0);
@@ -390,24 +459,6 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
       for (int i = 0; i < ALTM_NOX + 1; i++) taps[r][i] = 0.f;
 
     if (boxed) {
-      // ---- products: acc[u][r] = target block u x the half's 32 sources ---------------------------------------------------------
-      altm_f16v acc[ALTM_BPW];
-#pragma unroll
-      for (int u = 0; u < ALTM_BPW; u++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[u][r] = 0.f;
-      const int spix = __builtin_amdgcn_ds_bpermute((half * 32 + l31) * 4, pix);   // source pixel of this lane's fragment
-      const _Float16 *sp = fmap1 + ((size_t)b1 * HW1 + spix) * C + kh;
-      // (blocks past the box and k-steps past C hold zero target fragments: their products are computed and never read)
-#pragma unroll
-      for (int ks = 0; ks < ALTM_KS; ks++) {
-        altm_half8 sf = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ks < ksteps) sf = *reinterpret_cast<const altm_half8 *>(sp + ks * 16);
-#pragma unroll
-        for (int u = 0; u < ALTM_BPW; u++)
-          if (u == 0 || wave + ALTM_WAVES * u < nblk)   // (wave-uniform; block u = 0 past the box: zero fragments)
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf[u][ks], sf, acc[u], 0, 0, 0);  // targets x sources
-      }
       if (half) __syncthreads();   // the first half's window phase has read the tile
       // D layout: column = lane & 31 (source), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (target within the block)
 #pragma unroll
@@ -417,24 +468,23 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
           for (int rq = 0; rq < 4; rq++) {
             altm_f4v v;
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = acc[u][4 * rq + q];
+            for (int q = 0; q < 4; q++) v[q] = acc[half][u][4 * rq + q];
             *reinterpret_cast<altm_f4v *>(altm_tile + l31 * ALTM_PITCH + (wave + ALTM_WAVES * u) * 32 + 8 * rq + 4 * (lane >> 5)) = v;
           }
         }
       }
       __syncthreads();
       if (phits && g < RD) {
-        const float *trow = altm_tile + p * ALTM_PITCH;
+        // taps outside the box are outside the map: zeros.  Columns i_lo .. i_hi - 1 of the thread's taps are inside.
+        const int i_lo = cx0 - (pwx0 + ox0), i_hi = cx1 - (pwx0 + ox0);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
           const int ty = pwy0 + g + r;
           const bool rok = (ty >= cy0) && (ty < cy1);
+          const float *trow = altm_tile + p * ALTM_PITCH + (rok ? (ty - cy0) * CW - i_lo : 0);
+          const int lo = rok ? i_lo : 1 << 20;
 #pragma unroll
-          for (int i = 0; i < ALTM_NOX + 1; i++) {
-            const int tx = pwx0 + ox0 + i;
-            const bool ok = rok && (tx >= cx0) && (tx < cx1);
-            taps[r][i] = ok ? trow[(ty - cy0) * CW + (tx - cx0)] : 0.f;
-          }
+          for (int i = 0; i < ALTM_NOX + 1; i++) taps[r][i] = (i >= lo && i < i_hi) ? trow[i] : 0.f;
         }
       }
     } else if (phits && g < RD) {
@@ -546,7 +596,7 @@ extern "C" int dba_altcorr_pyramid_forward_f16maps(const void *fmap1, const void
   AltLevels Lv;
   for (int l = 0; l < 8; l++) Lv.f2[l] = (l < num_levels) ? fmap2_levels[l] : nullptr;
   dim3 grid((W1 + ALT_TW - 1) / ALT_TW, (H1 + ALT_TH - 1) / ALT_TH, B * S * num_levels);
-  hipLaunchKernelGGL(altcorr_mfma_kernel, grid, dim3(64 * ALTM_WAVES), (size_t)32 * ALTM_PITCH * sizeof(float), (hipStream_t)stream,
+  hipLaunchKernelGGL(altcorr_mfma_kernel, grid, dim3(64 * ALTM_WAVES), (size_t)ALTM_LDS_BYTES, (hipStream_t)stream,
                      static_cast<const _Float16 *>(fmap1), Lv, coords, corr, S, H1, W1, C, num_levels, ii, jj);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
