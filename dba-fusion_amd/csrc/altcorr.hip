@@ -589,6 +589,7 @@ extern "C" int dba_altcorr_pyramid_forward_f16maps(const void *fmap1, const void
                                                    int W1, int C, int num_levels, int radius, dba_stream_t stream) {
   if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || C <= 0 || num_levels < 1 || num_levels > 8) return DBA_ERR_ARG;
   if (radius != 3 || (C % 16) != 0 || C > 16 * ALTM_KS) return DBA_ERR_UNSUPPORTED;
+  if ((long)H1 * W1 * C >= 2147483647L) return DBA_ERR_UNSUPPORTED;   // (a level's map is addressed with 32-bit offsets)
   if ((long)B * S == 0) return DBA_OK;
   if ((long)B * S * num_levels > 65535) return DBA_ERR_UNSUPPORTED;
   if (!fmap1 || !fmap2_levels || !coords || !corr) return DBA_ERR_ARG;

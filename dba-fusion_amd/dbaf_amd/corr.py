@@ -494,7 +494,8 @@ class AltCorrBlock:
             lib = _lib.load()
             half = self.pyramid
             Cn = int(half[0].shape[-1])
-            if self.mfma and half[0].dtype == torch.float16 and self.radius == 3 and Cn % 16 == 0 and Cn <= 128:
+            if self.mfma and half[0].dtype == torch.float16 and self.radius == 3 and Cn % 16 == 0 and Cn <= 128 \
+                    and H * W * Cn < 2 ** 31 - 1:
                 # the reference's case (half maps under autocast, `.float()` at the lookup): the halves go to the matrix cores
                 # as they are -- exact products, float sums; no float twins of the pyramid are made at all
                 ptrs = (ctypes.c_void_p * self.num_levels)(*[p.data_ptr() for p in half])
