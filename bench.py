@@ -188,6 +188,13 @@ def main():
         st = pool[i % pool.shape[0]]
         return st[:npose].view_as(poses0), st[npose + pad:npose + pad + disps0.numel()].view_as(disps0)
 
+    def reset_state():
+        # the per-step state reset (poses + inverse depths: one pass).  An elementwise kernel, not `state.copy_(state0)`: the
+        # runtime serves a device-to-device memcpy either with a blit kernel (~4 us) or with the SDMA engine, whose hand-over
+        # to the compute queue costs ~20 us per step on the boxes where it is picked (measured: 0.239 against 0.261 ms per
+        # step for the same kernels); a kernel on the stream behaves the same everywhere
+        torch.mul(state0, 1.0, out=state)
+
     refill_pool()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * max(total, 32))]   # (the extras' loops index up to 24)   # lookup: [4i, 4i+1]; ba (untimed loop): [4i+2, 4i+3]
     for e_ in ev:
@@ -204,7 +211,7 @@ def main():
         if pooled:
             poses, disps = pooled_state(i)
         else:
-            state.copy_(state0)                      # the per-step state reset (poses + inverse depths: one copy)
+            reset_state()                            # the per-step state reset (poses + inverse depths: one pass)
             poses, disps = state[:npose].view_as(poses0), state[npose + pad:].view_as(disps0)
         ii_, jj_, target_, weight_ = (ii, jj, target, weight) if graph is None else graph
         # the roofline kernel is timed live, in every timed step, with two HIP events ATTACHED TO ITS DISPATCH on the launch
@@ -332,15 +339,15 @@ def main():
             return (time.perf_counter() - t_) / reps * 1e6
 
         def plain():
-            state.copy_(state0)
+            reset_state()
             droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep, False)
 
         def sharded1():
-            state.copy_(state0)
+            reset_state()
             sh1.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, 2, W.lm, W.ep, None)
 
         def fresh_graph():   # new edge tensors on every call, as after add_factors / rm_factors: stage 0 runs, nothing is cached
-            state.copy_(state0)
+            reset_state()
             droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii.clone(), jj.clone(), W.t0, W.t1, 2, W.lm,
                               W.ep, False)
 
@@ -625,7 +632,7 @@ def main():
             # trajectory after one dba_update, device vs the CPU oracle, and each against the ground truth
             from dbaf_amd import ate
             from oracle import oracle as orc
-            state.copy_(state0)
+            reset_state()
             droid_backends.ba(poses, disps, intr, dsens, target, weight, eta, ii, jj, W.t0, W.t1, 2, W.lm, W.ep, False)
             torch.cuda.synchronize()
             dev_p = poses.cpu().numpy()[:W.num_kf]
