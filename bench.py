@@ -91,6 +91,9 @@ def main():
                     help="auto = the headline window on one GPU, weak scaling (64 KF, 64 edges per rank) on several")
     ap.add_argument("--unfused-reprojection", action="store_true",
                     help="reproject in its own launch (dba_reproject) and hand the lookup the coordinates, as round 3 did")
+    ap.add_argument("--separate-clamp", action="store_true",
+                    help="the caller's disps.clamp_(min=0.001) as an elementwise launch of its own after ba (rounds 1-3; "
+                         "default: droid_backends.ba_clamped, the clamp in ba's last launch)")
     ap.add_argument("--backend", default=os.environ.get("DBA_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend of the exchange step (gloo: host-staged, several ranks may share one GPU)")
     args = ap.parse_args()
@@ -204,6 +207,7 @@ def main():
 
     K_b4 = K[0]
     fused = not args.unfused_reprojection
+    fused_clamp = not args.separate_clamp
 
     def step(i, corr_of=lambda i: corrs[i % ncopies], lookup=None, time_ba=False, pooled=False, graph=None):
         if args.step_events:
@@ -232,14 +236,19 @@ def main():
         keep[i % ncopies] = c
         if time_ba:
             ev[4 * i + 2].record()
-        if shard is None:
+        if shard is None and fused_clamp:
+            # DepthVideo.ba's two statements (depth_video.py:559-560) in one call: the clamp rides in ba's last launch
+            droid_backends.ba_clamped(poses, disps, intr, dsens, target_, weight_, eta, ii_, jj_, W.t0, W.t1, 2, W.lm,
+                                      W.ep, False, 0.001)
+        elif shard is None:
             droid_backends.ba(poses, disps, intr, dsens, target_, weight_, eta, ii_, jj_, W.t0, W.t1, 2, W.lm, W.ep,
                               False)
         else:
             shard.ba(poses, disps, intr, dsens, target_, weight_, eta, ii_, jj_, 2, W.lm, W.ep, ba_dist)
         if time_ba:
             ev[4 * i + 3].record()
-        disps.clamp_(min=0.001)  # depth_video.py:560
+        if not (shard is None and fused_clamp):
+            disps.clamp_(min=0.001)  # depth_video.py:560
         return c
 
     for i in range(args.warmup):
@@ -560,12 +569,13 @@ def main():
             "dtype": "f32 (BA, f64 reduced system) / f16 (correlation)",
             "data": "synthetic",
             "config": {"workload": "synthetic %s -> %dx%d maps, %d-KF window, %d edges, "
-                                   "state reset + [reprojection + 4-level r=3 lookup: %s] + ba(itrs=2) per step; lookups "
+                                   "state reset + [reprojection + 4-level r=3 lookup: %s] + ba(itrs=2) + clamp (%s) per step; lookups "
                                    "rotate over %d disjoint pyramid copies (MALL-cold)" % (
                                        {(64, 64): "TUM-VI-shape 512x512", (28, 107): "KITTI-360-shape 224x856",
                                         (55, 55): "TUM-VI demo 440x440", (48, 64): "384x512 (WHU / TartanAir)"}.get(
                                            (h, w), "%dx%d frames" % (8 * h, 8 * w)), h, w, W.num_kf, N,
-                                       "one launch" if fused else "two launches", ncopies),
+                                       "one launch" if fused else "two launches",
+                                       "in ba's last launch" if (shard is None and fused_clamp) else "its own launch", ncopies),
                        "keyframes": W.num_kf, "edges": N, "map": [h, w], "parallelism": "edge-shard x%d" % world,
                        "scaling_mode": scaling,
                        "exchange": ("gloo (host-staged)" if args.backend == "gloo" and world > 1 else

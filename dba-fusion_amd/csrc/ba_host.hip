@@ -364,13 +364,13 @@ int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float e
 static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
                             int ht, int wd, int t0, int t1, int update_poses, int update_disps, float *dz_out,
                             float *dx_out, void *ws, size_t ws_bytes, dba_stream_t stream,
-                            const float *poses_src = nullptr) {
+                            const float *poses_src = nullptr, float disp_floor = 0.f) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1);
   hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, poses_src, disps, jj, frame_owned,
-                     plan.HW, t0, plan.P, update_poses, update_disps, dz_out, dx_out, plan.T, plan.W);
+                     plan.HW, t0, plan.P, update_poses, update_disps, dz_out, dx_out, plan.T, plan.W, disp_floor);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -409,7 +409,7 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
                   const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
                   const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
                   float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
-                  dba_stream_t stream, int prepared, int solver_hint) {
+                  dba_stream_t stream, int prepared, int solver_hint, float disp_floor = 0.f) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -443,7 +443,7 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
     }
     rc = ba_update_launch(poses, disps, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
                           last ? dz_out : nullptr, last ? dx_out : nullptr, ws, ws_bytes, stream,
-                          pose_src == poses ? nullptr : pose_src);
+                          pose_src == poses ? nullptr : pose_src, last ? disp_floor : 0.f);
     if (rc != DBA_OK) return rc;
     pose_src = poses;
     pending = false;
@@ -467,6 +467,17 @@ int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const f
                     dba_stream_t stream, int solver_hint) {
   return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
                 iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, 1, solver_hint);
+}
+
+int dba_ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens, const float *targets,
+               const float *weights, const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
+               int ht, int wd, int t0, int t1, int iterations, float lm, float ep, int motion_only, float *dx_out,
+               float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream, int prepared, int solver_hint,
+               float disp_floor) {
+  if (!(disp_floor >= 0.f)) return DBA_ERR_ARG;
+  return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, prepared ? 1 : 0,
+                prepared ? solver_hint : 0, disp_floor);
 }
 
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,

@@ -87,7 +87,7 @@ __global__ void ba_schur_gram_kernel(const int64_t *ii, const int64_t *jj, const
                                      int t0, int P, int nch, int lower, BaTables T, BaBuffers W);
 __global__ void ba_update_kernel(float *poses, const float *poses_src, float *disps, const int64_t *jj, const uint8_t *frame_owned,
                                  int HW, int t0, int P, int update_poses, int update_disps, float *dz_out,
-                                 float *dx_out, BaTables T, BaBuffers W);
+                                 float *dx_out, BaTables T, BaBuffers W, float disp_floor);
 __global__ void ba_copy_dx_kernel(const double *src, float *dst, int n);
 __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
 

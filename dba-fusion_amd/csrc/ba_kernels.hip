@@ -1539,7 +1539,8 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
                                                         const uint8_t *__restrict__ frame_owned, int HW,
                                                         int t0, int P, int update_poses, int update_disps,
                                                         float *__restrict__ dz_out,
-                                                        float *__restrict__ dx_out, BaTables T, BaBuffers W) {
+                                                        float *__restrict__ dx_out, BaTables T, BaBuffers W,
+                                                        float disp_floor) {
   const int m = blockIdx.y;
   if (m == T.Mmax) {  // pose retraction: T_k <- Exp(dx_k) T_k for k in [t0, t1)
     if (blockIdx.x != 0) return;
@@ -1565,7 +1566,11 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
   const float dz = backsub_pixel(T, W, m, frame, k, HW, t0, P);
   const size_t mk = (size_t)m * HW + k;
   const size_t fk = (size_t)frame * HW + k;
-  disps[fk] = disps[fk] + dz;                  // disp_retr_kernel :988
+  float d = disps[fk] + dz;                    // disp_retr_kernel :988
+  // dba_ba_run's disp_floor > 0: the caller's `self.disps.clamp_(min=0.001)` (dbaf/depth_video.py:560) taken into this,
+  // the call's last launch (torch.clamp's select: a NaN stays a NaN)
+  if (disp_floor > 0.f) d = (d < disp_floor) ? disp_floor : d;
+  disps[fk] = d;
   if (dz_out) dz_out[mk] = dz;
 }
 

@@ -45,6 +45,8 @@ SYMBOLS = {
                                                                      c_size_t, _P]),
     "dba_ba_prepared": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
                                                                               c_size_t, _P, c_int]),
+    "dba_ba_run": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
+                                                                         c_size_t, _P, c_int, c_int, c_float]),
     "dba_bacore_hessian": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P]),
     "dba_bacore_retract": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
     "dba_bacore_optimize": (c_int, [_P, _P] + [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),

@@ -181,6 +181,24 @@ def _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
        motion_only):
     """Dense bundle adjustment, in place on poses[t0:t1] and disps[kx] (droid.cpp:109-138)."""
+    return _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+               motion_only, 0.0)
+
+
+def ba_clamped(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+               motion_only, disp_floor=0.001):
+    """`ba(...)` followed by the caller's `disps.clamp_(min=disp_floor)` (DepthVideo.ba, dbaf/depth_video.py:559-560) in ONE
+    call: the clamp rides in the call's last launch instead of being an elementwise launch of its own over the whole
+    buffer (dba_ba_run; same state bit for bit, see include/dba_hip.h).  Not a reference binding: an integration that
+    wants it replaces the two statements of depth_video.py by this one call."""
+    if not (float(disp_floor) > 0.0):
+        raise RuntimeError("ba_clamped: disp_floor must be positive")
+    return _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+               motion_only, float(disp_floor))
+
+
+def _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+        motion_only, disp_floor):
     eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
     t0, t1 = int(t0), int(t1)
     P = t1 - t0
@@ -196,9 +214,11 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         hint = _BA_WS.solver_hint(key, dims) if prepared else 0
         fn = (lambda *a: lib.dba_ba_prepared(*a, hint)) if prepared else lib.dba_ba
     else:
-        key, prepared = None, False
+        key, prepared, hint = None, False, 0
         ws, nbytes = _ws(*dims, poses.device)
         fn = lib.dba_ba
+    if disp_floor > 0.0:
+        fn = lambda *a: lib.dba_ba_run(*a, int(bool(prepared)), int(hint), disp_floor)  # noqa: E731
     dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
     Mmax = min(B, P + N)
     dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written

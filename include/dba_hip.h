@@ -181,6 +181,18 @@ int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const f
  * the queue was a net for, a partner workgroup more than a second late at the hand-shake, then gives a failed solve, i.e. a
  * zero update, instead of a slower correct one). */
 
+/* dba_ba / dba_ba_prepared (prepared != 0) with the caller's next statement taken along: DepthVideo.ba clamps the inverse
+ * depths right after droid_backends.ba returns (`self.disps.clamp_(min=0.001)`, dbaf/depth_video.py:560), a launch of its
+ * own over the whole buffer.  disp_floor > 0: the LAST iteration's update writes max(d, disp_floor) (torch.clamp's select: a
+ * NaN stays a NaN) for the frames it updates -- the same state, bit for bit, whenever the frames this call does not update
+ * are at or above the floor already (they are: each was clamped after the call that updated it); earlier iterations and the
+ * returned dz are untouched, exactly as when the clamp follows the call.  disp_floor = 0: dba_ba / dba_ba_prepared. */
+int dba_ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+               const float *targets, const float *weights, const float *eta, int eta_rows,
+               const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
+               int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
+               void *ws, size_t ws_bytes, dba_stream_t stream, int prepared, int solver_hint, float disp_floor);
+
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
  * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,

@@ -86,6 +86,39 @@ def test_ba_matches_oracle(name):
     np.testing.assert_allclose(dx, r64["dx"], rtol=1e-3, atol=2e-6)
 
 
+@pytest.mark.parametrize("name", ["tiny_a", "25kf_96edges_64x64", "whu_10kf_48x64_sensor_depth"])
+@pytest.mark.parametrize("itrs,motion_only", [(2, False), (1, False), (3, False), (2, True)])
+def test_ba_clamped_is_ba_followed_by_the_callers_clamp(name, itrs, motion_only):
+    """droid_backends.ba_clamped (dba_ba_run with disp_floor > 0): DepthVideo.ba's two statements -- droid_backends.ba(...)
+    and self.disps.clamp_(min=0.001) (dbaf/depth_video.py:559-560) -- in one call, the clamp riding in the last launch.
+    Same poses, inverse depths, dx and dz bit for bit as the two statements; the floor is chosen so that a good part of the
+    pixels IS clamped (the default 0.001 rarely bites on a synthetic window)."""
+    import droid_backends
+    W = WINDOWS[name]()
+    a, b = to_dev(W), to_dev(W)
+    args = lambda d: (d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"],  # noqa: E731
+                      d["ii"], d["jj"], W.t0, W.t1, itrs, W.lm, W.ep, motion_only)
+    # the tracker's invariant: every frame is at or above the floor before the call (each was clamped after the call that
+    # updated it).  With the floor at the median, half of the pixels start ON it and the update pushes part of them below.
+    floor = float(np.median(W.disps))
+    for d in (a, b):
+        d["disps"].clamp_(min=floor)
+    dxa, dza = droid_backends.ba(*args(a))
+    below = float((a["disps"] < floor).float().mean())
+    a["disps"].clamp_(min=floor)
+    dxb, dzb = droid_backends.ba_clamped(*args(b), disp_floor=floor)
+    torch.cuda.synchronize()
+    assert torch.equal(a["poses"], b["poses"]) and torch.equal(dxa, dxb)
+    assert torch.equal(a["disps"], b["disps"])
+    if motion_only:
+        assert dza is None and dzb is None and below == 0.0
+    else:
+        assert torch.equal(dza, dzb)
+        assert below > 0.02, below      # the clamp did something
+    with pytest.raises(RuntimeError):
+        droid_backends.ba_clamped(*args(b), disp_floor=0.0)
+
+
 def _bacore_system(W, form):
     """the Schur-reduced camera system of W as BACore.hessian hands it to the host, with the given Schur kernel form"""
     import droid_backends
