@@ -45,9 +45,10 @@ for f in glob.glob("$SQ/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         for nm in names:
-            if nm in k: agg[(nm, r["Counter_Name"])].append(float(r["Counter_Value"]))
-print("# per launch, averaged over the launches of bench.py --steps 3 --warmup 1 (25 KF / 96 edges); rocprofv3 --pmc, kernel trace only")
-for k in sorted(agg): print("%-22s %-32s %16.1f  (n=%d)" % (k[0], k[1], sum(agg[k]) / len(agg[k]), len(agg[k])))
+            if nm in k: agg[(nm, int(r.get("Grid_Size") or 0), r["Counter_Name"])].append(float(r["Counter_Value"]))
+print("# per launch, averaged over the launches of one grid size (threads): bench.py --steps 3 --warmup 1 on the 25 KF / 96 edges window and,")
+print("# for the matrix-core Schur passes, --window 64_512 --steps 2 (the larger grids); rocprofv3 --pmc, kernel trace only")
+for k in sorted(agg): print("%-22s grid %-9d %-32s %16.1f  (n=%d)" % (k[0], k[1], k[2], sum(agg[k]) / len(agg[k]), len(agg[k])))
 PY
 cat $OUT/${TAG}_sq_counters.txt | head -80
 # on-the-fly correlation
