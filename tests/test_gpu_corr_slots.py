@@ -23,7 +23,7 @@ def _coords(n, h, w, seed, spread=3.0):
     return torch.from_numpy(c.astype(np.float32)).cuda()[None]
 
 
-@pytest.mark.parametrize("layout,h,w", [("sheared", 24, 64), ("sheared", 20, 28), ("reference", 16, 24)])
+@pytest.mark.parametrize("layout,h,w", [("sheared", 24, 64), ("sheared", 20, 28), ("sheared", 8, 128), ("reference", 16, 24)])
 def test_cat_and_index_edit_the_slot_table_and_lookups_stay_bit_identical(layout, h, w, lookup_kernel):
     from dbaf_amd.corr import CorrBlock
     C, nf = 32, 7
@@ -101,7 +101,7 @@ def test_build_after_an_in_place_write_of_the_maps_raises():
         blk(_coords(2, 16, 16, 0))
 
 
-@pytest.mark.parametrize("h,w", [(64, 64), (20, 64), (28, 107), (16, 16)])
+@pytest.mark.parametrize("h,w", [(64, 64), (20, 64), (28, 107), (16, 16), (12, 128), (8, 192)])
 def test_lookup_with_the_reprojection_in_its_launch(h, w, lookup_kernel):
     """one launch == dba_reproject + lookup, bit for bit (coordinates, validity, correlation features): maps whose rows
     fill whole waves (streaming form: the edge geometry is shared through LDS, workgroups that straddle two edges at h = 20),
