@@ -327,7 +327,6 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
   const int b = bs / S;
   const int b1 = ii ? (int)ii[b] : b, b2 = jj ? (int)jj[b] : b;
   const int HW1 = H1 * W1;
-  const int ksteps = C >> 4;
 
   // ---- every wave: lane = pixel of the tile (row lane >> 4, column lane & 15) ------------------------------------------------
   const int h1 = blockIdx.y * ALT_TH + (lane >> 4), w1 = blockIdx.x * ALT_TW + (lane & 15);
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(64 * ALTM_WAVES, ALTM_MIN_WAVES) void altcorr_mfma_
   const bool boxed = any && NBX <= ALTM_NB;
   const int nblk = boxed ? (NBX + 31) >> 5 : 0;
   const _Float16 *f2b = fmap2 + (size_t)b2 * H2 * W2 * C;
-  const int l31 = lane & 31, kh = (lane >> 5) * 8;
+  const int l31 = lane & 31;
 
   // ---- operands through LDS.  A lane that loads ITS fragment straight from the channels-last map takes 16 bytes out of a line
   // of its own: a wave's load instruction then touches 32 lines for 1 KB (the texture addresser walks them one by one; the
