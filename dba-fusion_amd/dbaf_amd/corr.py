@@ -242,17 +242,23 @@ class CorrBlock:
         idx = self._slots.long()
         return [s.index_select(0, idx) for s in self._stores]
 
-    def sheared_level(self, lvl):
-        """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1]: without the plane padding, and with the pixel
-        axis back in row-major order where the planes keep it in 4 x 16 tiles (dba_corr_sheared_tiled)"""
-        assert self.layout == "sheared"
-        v = self.corr_pyramid[lvl][..., :self.h1 * self.w1]
-        tw = _lib.load().dba_corr_sheared_tiled(self.h1, self.w1)     # tile width (0: row-major)
+    @staticmethod
+    def map_pixels(level, h1, w1):
+        """a flow-aligned level [..., HW1p] as [..., h1, w1]: the real pixels in row-major order -- without the plane padding,
+        un-tiled where the planes keep their pixels in 4 x 16 tiles (dba_corr_sheared_tiled; the last tile of a row may reach
+        past the map: those padding pixels are dropped)"""
+        lib = _lib.load()
+        tw = lib.dba_corr_sheared_tiled(int(h1), int(w1))     # tile width (0: row-major)
         if tw:
-            th = 64 // tw
-            v = v.unflatten(-1, (self.h1 // th, self.w1 // tw, th, tw)).permute(0, 1, 2, 3, 5, 4, 6)
-            return v.reshape(v.shape[:3] + (self.h1, self.w1))
-        return v.unflatten(-1, (self.h1, self.w1))
+            th, tx = 64 // tw, (w1 + tw - 1) // tw
+            v = level.unflatten(-1, (h1 // th, tx, th, tw)).movedim(-2, -3)      # [..., h1 / th, th, tiles_x, tw]
+            return v.reshape(v.shape[:-4] + (h1, tx * tw))[..., :w1]
+        return level[..., :h1 * w1].unflatten(-1, (h1, w1))
+
+    def sheared_level(self, lvl):
+        """level `lvl` of the flow-aligned pyramid as [n, h2l, w2l, h1, w1] (map_pixels)"""
+        assert self.layout == "sheared"
+        return CorrBlock.map_pixels(self.corr_pyramid[lvl], self.h1, self.w1)
 
     @property
     def capacity(self):

@@ -69,7 +69,7 @@ def _smooth_coords(rng, n, h, w):
 
 @pytest.mark.parametrize("layout", ["reference", "sheared"])
 @pytest.mark.parametrize("shape", [(3, 32, 16, 24), (2, 16, 24, 64), (1, 16, 16, 136), (2, 16, 20, 44), (2, 16, 17, 23),
-                                   (1, 16, 18, 71), (2, 16, 12, 128), (1, 16, 8, 192)])
+                                   (1, 16, 18, 71), (2, 16, 12, 128), (1, 16, 8, 192), (2, 16, 28, 107), (1, 16, 16, 136)])
 def test_corrblock_pyramid_lookup_matches_per_level_oracle(layout, shape, lookup_kernel):
     if layout == "reference" and lookup_kernel != "auto":
         pytest.skip("the kernel selection only concerns the sheared layout")
@@ -120,6 +120,7 @@ def test_lookup_non_finite_coords_do_not_fault(layout, lookup_kernel):
 
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64), (3, 32, 24, 64), (1, 16, 8, 64), (2, 128, 28, 107), (1, 32, 55, 55),
                                    (1, 16, 48, 64), (1, 16, 18, 71), (2, 16, 20, 44), (1, 16, 9, 128), (1, 16, 16, 16), (1, 16, 12, 128),
+                                   (1, 16, 24, 107), (2, 128, 28, 107), (1, 32, 8, 120),
                                    (2, 16, 8, 8), (1, 16, 9, 10), (1, 32, 11, 13), (1, 16, 8, 65), (1, 16, 33, 36),
                                    (1, 128, 55, 55), (2, 128, 18, 44), (3, 128, 9, 10), (1, 128, 11, 13), (5, 128, 8, 8)])
 def test_fused_sheared_build_equals_unfused_pipeline(shape):
@@ -137,9 +138,10 @@ def test_fused_sheared_build_equals_unfused_pipeline(shape):
     assert fused is not None
     unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
     for lvl in range(4):
-        a, b = fused[lvl].cpu().numpy(), unfused[lvl].cpu().numpy()
-        assert a.shape == b.shape and a.shape[-1] % 64 == 0   # [n, h2l, w2l, HW1p]; the padding is never written
-        a, b = a[..., :h * w], b[..., :h * w]
+        assert fused[lvl].shape == unfused[lvl].shape and fused[lvl].shape[-1] % 64 == 0   # [n, h2l, w2l, HW1p]
+        # (the plane padding is never written; tiled planes -- also with tiles that reach past the map -- come back row-major)
+        a = CorrBlock.map_pixels(fused[lvl], h, w).cpu().numpy()
+        b = CorrBlock.map_pixels(unfused[lvl], h, w).cpu().numpy()
         assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (lvl, (a != b).mean())
 
 
@@ -417,7 +419,8 @@ def test_strip_walking_build_for_every_chunking(n):
     fused = CorrBlock.build_sheared_fused(t1, t2, 4)
     unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
     for lvl in range(4):
-        assert torch.equal(fused[lvl][..., :h * w].view(torch.int16), unfused[lvl][..., :h * w].view(torch.int16)), lvl
+        assert torch.equal(CorrBlock.map_pixels(fused[lvl], h, w).contiguous().view(torch.int16),
+                           CorrBlock.map_pixels(unfused[lvl], h, w).contiguous().view(torch.int16)), lvl
 
 
 def test_strip_walking_build_on_a_48x64_map_with_few_edges():
@@ -430,4 +433,5 @@ def test_strip_walking_build_on_a_48x64_map_with_few_edges():
         fused = CorrBlock.build_sheared_fused(t1, t2, 4)
         unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
         for lvl in range(4):
-            assert torch.equal(fused[lvl][..., :h * w].view(torch.int16), unfused[lvl][..., :h * w].view(torch.int16)), (n, lvl)
+            assert torch.equal(CorrBlock.map_pixels(fused[lvl], h, w).contiguous().view(torch.int16),
+                               CorrBlock.map_pixels(unfused[lvl], h, w).contiguous().view(torch.int16)), (n, lvl)
