@@ -30,13 +30,15 @@ $(PKG)/lib/libdba_hip.so: $(OBJS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-# the compiled `droid_backends` adapter (pybind11 over the C ABI; host C++ only: the torch headers, no device code)
+# the compiled `droid_backends` adapter (pybind11 over the C ABI; host C++ only: the torch headers, no device code).  The
+# torch variables are recursively expanded: python only imports torch when the ext target is actually rebuilt
 PY ?= python3
-TORCH_INC := $(shell $(PY) -c "from torch.utils import cpp_extension as c; print(' '.join('-isystem ' + p for p in c.include_paths()))")
-TORCH_LIB := $(shell $(PY) -c "import os, torch; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))")
-PY_INC := $(shell $(PY) -c "import sysconfig; print(sysconfig.get_paths()['include'])")
+TORCH_INC = $(shell $(PY) -c "from torch.utils import cpp_extension as c; print(' '.join('-isystem ' + p for p in c.include_paths()))")
+TORCH_LIB = $(shell $(PY) -c "import os, torch; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))")
+PY_INC = $(shell $(PY) -c "import sysconfig; print(sysconfig.get_paths()['include'])")
+TORCH_ABI = $(shell $(PY) -c "import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
 $(PKG)/droid_backends/_droid_backends_C.so: $(PKG)/csrc_ext/droid_backends_ext.cpp include/dba_hip.h $(PKG)/lib/libdba_hip.so
-	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=1 -DTORCH_EXTENSION_NAME=_droid_backends_C \
+	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$(TORCH_ABI) -DTORCH_EXTENSION_NAME=_droid_backends_C \
 	    -Iinclude $(TORCH_INC) -isystem $(PY_INC) -isystem /opt/rocm/include $< -o $@ \
 	    -L$(PKG)/lib -ldba_hip -L$(TORCH_LIB) -ltorch -ltorch_cpu -ltorch_python -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
 	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(TORCH_LIB)

@@ -85,6 +85,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   dba_ba_layout L;
   memset(&L, 0, sizeof(L));
   L.meta = take(sizeof(int) * 16);  // [8..15]: handshake flags of the solver's two workgroups (nothing else writes there)
+  const size_t o_gkey = take(sizeof(int) * (8 + 2 * (size_t)N));   // (right behind meta: dba_ba_workspace_init clears both)
   L.kx = take(sizeof(int) * (size_t)(Mmax > 0 ? Mmax : 1));
   const size_t o_fslot = take(sizeof(int) * (size_t)B);
   const size_t o_eoff = take(sizeof(int) * (size_t)(Mmax + 1));
@@ -134,6 +135,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->T.rowinfo = reinterpret_cast<int *>(base + o_rowinfo);
     plan->T.fhead = reinterpret_cast<int *>(base + o_fhead);
     plan->T.frow = reinterpret_cast<int *>(base + o_frow);
+    plan->T.gkey = reinterpret_cast<int *>(base + o_gkey);
     plan->T.Mmax = Mmax;
     plan->T.B = B;
     plan->W.E = reinterpret_cast<float *>(base + L.E);
@@ -175,8 +177,43 @@ int dba_ba_get_layout(int N, int B, int ht, int wd, int t0, int t1, dba_ba_layou
   return DBA_OK;
 }
 
+// Pinned, host-coherent status words the prepare kernel reports an eta / |kx| mismatch through (one set per process,
+// sticky until polled): [0] = 1 when set, [1] = the eta rows the call was given, [2] = |kx| of its graph.
+static int *eta_status() {
+  static int *p = [] {
+    int *q = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&q), 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return (int *)nullptr;
+    memset(q, 0, 64);
+    return q;
+  }();
+  return p;
+}
+
+int dba_ba_poll_eta_error(int *eta_rows, int *num_kx) {
+  int *st = eta_status();
+  if (!st || __atomic_load_n(st, __ATOMIC_ACQUIRE) == 0) return 0;
+  if (eta_rows) *eta_rows = st[1];
+  if (num_kx) *num_kx = st[2];
+  __atomic_store_n(st, 0, __ATOMIC_RELEASE);
+  return 1;
+}
+
+int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  // meta and the graph key are adjacent: no graph is recorded, nothing was solved
+  DBA_HIP_CHECK(hipMemsetAsync(plan.T.meta, 0, (size_t)((char *)(plan.T.gkey + 8) - (char *)plan.T.meta), (hipStream_t)stream));
+  return DBA_OK;
+}
+
 int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
                    void *ws, size_t ws_bytes, dba_stream_t stream) {
+  return dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, 0, 0, ws, ws_bytes, stream);
+}
+
+int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
+                         int check, void *ws, size_t ws_bytes, dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -193,7 +230,8 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
-                     (int)scan_ints, ba_schur_frame_form(N, plan.P) ? 1 : 0, plan.T);
+                     (int)scan_ints, ba_schur_frame_form(N, plan.P) ? 1 : 0, check ? 1 : 0, eta_rows,
+                     eta_rows > 1 ? eta_status() : nullptr, plan.T);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -368,7 +406,8 @@ static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1);
+  // (disp_floor > 0: one more block row per frame of the buffer, which clamp the frames this launch does not update)
+  dim3 grid((plan.HW + 255) / 256, plan.T.Mmax + 1 + (disp_floor > 0.f ? B : 0));
   hipLaunchKernelGGL(ba_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, poses_src, disps, jj, frame_owned,
                      plan.HW, t0, plan.P, update_poses, update_disps, dz_out, dx_out, plan.T, plan.W, disp_floor);
   DBA_LAUNCH_CHECK();
@@ -403,8 +442,9 @@ int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64
                        stream);
 }
 
-// prepared != 0: the index tables in `ws` are those of this graph already (a previous dba_ba / dba_ba_prepare with the
-// same ii, jj, sizes, t0, t1 and Schur form on this workspace): stage 0 is skipped.
+// prepared = 1: the index tables in `ws` are those of this graph already (a previous dba_ba / dba_ba_prepare with the
+// same ii, jj, sizes, t0, t1 and Schur form on this workspace): stage 0 is skipped.  prepared = 2: stage 0 decides that
+// itself, on the device, by comparing the edge list with the key it left in the workspace (dba_ba_prepare_keyed).
 static int ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
                   const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
                   const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
@@ -413,8 +453,8 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  if (!prepared) {
-    rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
+  if (prepared != 1) {
+    rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
   }
   const float alpha = 0.05f;  // droid_kernels.cu:1474
@@ -476,8 +516,8 @@ int dba_ba_run(float *poses, float *disps, const float *intrinsics, const float 
                float disp_floor) {
   if (!(disp_floor >= 0.f)) return DBA_ERR_ARG;
   return ba_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd, t0, t1,
-                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, prepared ? 1 : 0,
-                prepared ? solver_hint : 0, disp_floor);
+                iterations, lm, ep, motion_only, dx_out, dz_out, ws, ws_bytes, stream, (prepared == 1 || prepared == 2) ? prepared : 0,
+                prepared == 1 ? solver_hint : 0, disp_floor);
 }
 
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,
@@ -485,11 +525,22 @@ int dba_bacore_hessian(const float *poses, const float *disps, const float *intr
                        const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
                        int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
                        size_t ws_bytes, dba_stream_t stream) {
+  return dba_bacore_hessian_run(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd,
+                                t0, t1, H_host, v_host, ws, ws_bytes, stream, 0);
+}
+
+int dba_bacore_hessian_run(const float *poses, const float *disps, const float *intrinsics,
+                           const float *disps_sens, const float *targets, const float *weights,
+                           const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
+                           int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
+                           size_t ws_bytes, dba_stream_t stream, int prepared) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  rc = dba_ba_prepare(ii, jj, N, B, ht, wd, t0, t1, ws, ws_bytes, stream);
-  if (rc != DBA_OK) return rc;
+  if (prepared != 1) {
+    rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
+    if (rc != DBA_OK) return rc;
+  }
   rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, nullptr,
                         N, B, ht, wd, t0, t1, 0.001f /* :1872 */, ws, ws_bytes, stream);
   if (rc != DBA_OK) return rc;

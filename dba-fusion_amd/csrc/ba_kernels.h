@@ -34,6 +34,8 @@ struct BaTables {
   // out-edges with a pose inside the window, in list order)
   int *fhead;       // [Mmax][4]  frame id (-1: slot unused), first entry in frow, number of rows, -
   int *frow;        // [P+N][2]   row of E, pose index (- t0) it belongs to
+  int *gkey;        // [8 + 2N]   the graph these tables were built for: magic, N, B, t0, t1, Schur form, Mmax, -, then ii, jj
+                    //            as int32 (stage 0 compares a call's edge list with it and skips itself: dba_ba_prepare_keyed)
   int Mmax, B;
 };
 
@@ -63,8 +65,12 @@ struct BaPlan {  // host-side view of the workspace
 int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, BaPlan *plan);
 
 // kernels (ba_kernels.hip / ba_solve.hip)
+constexpr int GKEY_MAGIC = 0x6b657935;   // first word of a valid graph key
+// check != 0: leave at once when the workspace's key says the tables are those of this very graph
+// eta_rows > 1: must equal |kx| (droid_kernels.cu:1476 broadcasts eta over the rows of C); a mismatch is reported through
+// `status` (pinned host memory, may be null): [0] = 1, [1] = eta_rows, [2] = |kx|
 __global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1, int scan_ints,
-                                  int ftable, BaTables T);
+                                  int ftable, int check, int eta_rows, int *status, BaTables T);
 // which Schur kernel a window gets (ba_host.hip): the per-source-frame form on windows whose frames couple many rows
 bool ba_schur_frame_form(int N, int P);
 template <int PPL, bool MF, int EW>

@@ -94,30 +94,18 @@ struct __attribute__((aligned(16))) Half8v {
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-// Lookup kernel.  A workgroup is SH_WAVES independent waves; a wave = 64 consecutive x1 of one source row, one
-// pyramid level.
-//
-// Streaming form: the wave walks the plane-rows dy = by0 .. by1+7 of the union window one at a time.  Step jy
-// brings the nx (<= SH_NX) 128-byte lines (dy, bx0 .. bx0+nx-1) into a 2 KB LDS row (16-B loads issued one step
-// ahead, so they are in flight while the previous row is consumed); a lane whose own window starts ry rows
-// into the union reads its 8 taps of tap-row j = jy - ry, combines them with the previous tap-row it kept in
-// registers, and emits the 7 outputs (a, b = j-1).  LDS per wave is 2 KB, so occupancy is bounded by registers
-// (8 waves/SIMD), not by staging space.
-//
-// The kernel is bound by VALU issue (a wave64 op holds a 16-lane SIMD for 4 cycles), so the inner step is
-// written for instruction count: the blend runs on channel PAIRS with packed f16 ops (v_pk_mul_f16 /
-// v_pk_add_f16 round each half exactly like the scalar ops), taps arrive from LDS already packed
-// (d16 / d16_hi loads) and the odd-aligned pairs come from one v_alignbit each, the two tap-row register sets
-// alternate roles instead of being copied, stores go through a scalar base per channel column with one
-// per-lane offset, staging loads use a scalar row base that advances on the scalar unit, and all cross-lane
-// set-up runs on DPP.
-//
-// Lanes whose window origin is further than SH_BAND from the wave's reference ("outliers": flow
-// discontinuities, pixels thrown far away, and every lane of a ragged tile) are not allowed to widen the
-// streamed region; they are appended to a workgroup-wide list and gathered afterwards with all 64 lanes of
-// a wave busy, instead of each wave paying a full gather pass for its one or two odd pixels.
+// Two lookup kernels live here (the others that were tried -- the row-streaming, pair and band forms -- are shelved as
+// scratch/lookup_pruned_forms_r5.diff with their measurements in profiles/LOOKUP_NOTES.md):
+//   "rows over tiles"  maps whose rows are whole 64-pixel segments (tiled planes): plane-rows of the union window are
+//                      streamed through 2 KB LDS rows per tile, loaders per tile, workers per map row;
+//   "resident"         every other map shape (linear planes): the union of a 64-pixel strip's windows is held in LDS.
+// Both are bound by VALU issue and memory requests, so the inner steps are written for instruction count: the blend runs on
+// channel PAIRS with packed f16 ops (v_pk_mul_f16 / v_pk_add_f16 round each half exactly like the scalar ops), taps arrive
+// from LDS already packed (d16 / d16_hi loads) and the odd-aligned pairs come from one v_alignbit each, stores go through a
+// scalar base per channel column with one per-lane offset, and all cross-lane set-up runs on DPP.
+// Lanes whose window origin is further than SH_BAND from the wave's reference ("outliers": flow discontinuities, pixels
+// thrown far away) are not allowed to widen the staged region; they are gathered afterwards.
 constexpr int SH_NX = 16;     // plane-rows per step held in LDS (union width in x: 8 + spread <= 16)
-constexpr int SH_NY = 72;     // longest union in y walked by the streaming path
 // cache-policy bits of the buffer instructions (gfx950: 1 = sc0, 2 = nt, 16 = sc1); 0 = default policy
 #ifndef SH_LOAD_AUX
 // 2 (nt) is 10 % faster when the same windows are replayed out of the 256 MB Infinity Cache (76 vs 88 us on the 96-edge
@@ -132,20 +120,6 @@ constexpr int SH_NY = 72;     // longest union in y walked by the streaming path
 #define SH_BAND_CFG 4
 #endif
 constexpr int SH_BAND = SH_BAND_CFG;    // |origin - reference| <= SH_BAND streams
-#ifndef SH_WAVES_CFG
-#define SH_WAVES_CFG 8
-#endif
-#ifndef SH_DEPTH_CFG
-#define SH_DEPTH_CFG 2
-#endif
-#ifndef SH_OCC_CFG
-#define SH_OCC_CFG 8
-#endif
-constexpr int SH_WAVES = SH_WAVES_CFG;   // waves (source rows) per workgroup
-constexpr int SH_BLOCK = SH_WAVES * 64;
-constexpr int SH_DEPTH = SH_DEPTH_CFG;   // plane-rows in flight per wave (registers: 8 VGPRs per row)
-constexpr int SH_OCC = SH_OCC_CFG;       // waves per SIMD the register budget is set for
-
 // workgroup barrier that orders LDS traffic only: global loads and stores of the wave stay in flight across it
 __device__ __forceinline__ void lds_handoff() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -222,387 +196,6 @@ __device__ __forceinline__ void sh_read_taps(const _Float16 *tp, ShTaps &T) {
     const unsigned lo = __builtin_bit_cast(unsigned, T.e[k]);
     const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, T.e[k < 3 ? k + 1 : 3]) : 0u;
     T.o[k] = __builtin_bit_cast(h2v, __builtin_amdgcn_alignbit(hi, lo, 16));
-  }
-}
-
-template <int R>
-__global__ __launch_bounds__(SH_BLOCK, SH_OCC) void corr_lookup_sheared_kernel(ShLevels L,
-                                                                          const float2 *__restrict__ coords,
-                                                                          _Float16 *__restrict__ out, int n,
-                                                                          int h1, int w1, int h2, int w2,
-                                                                          int num_levels, int lvl0, int cflags,
-                                                                          const int *__restrict__ slots, ShReproj RP, int tiled) {
-  // tiled: the plane's pixel axis is in 4 x 16 tiles (common.h) and a wave owns one TILE instead of 64 pixels of a row
-  // slots: edge e's volumes live in slot slots[e] of every level's store (null: slot e) -- the slot-addressed CorrBlock,
-  // whose cat / index operations edit this table instead of moving volumes (dbaf/modules/corr.py:52-60)
-  // lvl0 / cflags: a launch may serve a sub-range of levels [lvl0, lvl0 + gridDim.y) of the pyramid (num_levels = levels
-  // in `out`, the first of them lvl0), with planar (bit 0) and / or pre-scaled (bit 1) coordinates: the per-level calls of
-  // the reference's unmodified CorrBlock (droid_backends.corr_index_forward on a flow-aligned shadow of the level)
-  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
-  static_assert(WN == 8, "the streaming lookup is written for radius 3");
-  const bool cplanar = (cflags & 1) != 0;
-  const bool reproj = (cflags & 4) != 0;
-  __shared__ __attribute__((aligned(16))) float geom_all[SH_WAVES][EDGE_GEOM_FLOATS];
-  __shared__ __attribute__((aligned(16))) _Float16 stage_all[SH_WAVES][SH_NX * 64];
-  __shared__ __attribute__((aligned(16))) _Float16 zero_taps[WN * 64];  // tap rows of lanes that touch nothing
-  __shared__ u4v keep_all[SH_WAVES][2][64];  // per staging slot: 16-bit keep mask per half (image-border pieces)
-  __shared__ int olist[SH_BLOCK];
-  __shared__ int ocount;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  _Float16 *stage = stage_all[wave];
-  const int xtiles = (w1 + 63) / 64;
-  const int HW1 = h1 * w1;
-#ifndef SH_NO_XCD_SWIZZLE
-  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of rows (whole edges), so that
-  // the 64 rows of a channel plane are written (and a plane's lines read) through ONE L2
-  // (XCD k receives the workgroups k, k + 8, ...: q + (k < r) of them for gridDim.x = 8 q + r; a bijection)
-  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
-  const int lb = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
-  const int lvl = blockIdx.y + lvl0;  // (levels stay apart in the dispatch order: interleaving them cost 30 %)
-  const int rowid = lb * SH_WAVES + wave;
-#else
-  const int lvl = blockIdx.y + lvl0;
-  const int rowid = blockIdx.x * SH_WAVES + wave;  // (e * h1 + y1) * xtiles + xt
-#endif
-  const int slvl = (cflags & 2) ? 0 : lvl;
-  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
-  // a wave's unit of work: 64 consecutive pixels of the plane's pixel axis = one 4 x 16 tile of the map, or (linear order)
-  // 64 consecutive x1 of one row
-  const int tiles_x = w1 >> SH_TW_LOG;
-  const int units = tiled ? (HW1 >> 6) : h1 * xtiles;   // per edge
-  const bool rowvalid = rowid < n * units;
-  auto unit_geometry = [&](int u, int &y1_, int &x1_, int &pbase_) {   // this lane's pixel, the unit's first plane index
-    if (tiled) {
-      const int tyi = u / tiles_x, txi = u - tyi * tiles_x;
-      y1_ = (tyi << SH_TH_LOG) + (lane >> SH_TW_LOG);
-      x1_ = (txi << SH_TW_LOG) + (lane & (SH_TW - 1));
-      pbase_ = u << 6;
-    } else {
-      y1_ = u / xtiles;
-      const int xt_ = u - y1_ * xtiles;
-      x1_ = xt_ * 64 + lane;
-      pbase_ = y1_ * w1 + xt_ * 64;
-    }
-  };
-  _Float16 *olvl = out + (size_t)blockIdx.y * RD * RD * HW1;  // + e * num_levels * RD * RD * HW1 + pixel
-  const size_t estride = (size_t)num_levels * RD * RD * HW1;
-  if (threadIdx.x == 0) ocount = 0;
-  for (int i = threadIdx.x; i < WN * 64; i += SH_BLOCK) zero_taps[i] = (_Float16)0.f;
-  // reprojection in the prologue: the geometry of an edge (relative pose, intrinsics: 20 floats) is formed once per
-  // workgroup and edge -- by the first wave of the workgroup that works on the edge -- and shared through LDS; every
-  // wave requests its pixels' inverse depths before the barrier
-  float dsrc = 0.f;
-  int gsrc = 0;
-  if (reproj && rowvalid) {
-    const int e = rowid / units;
-    int y1, x1, pb;
-    unit_geometry(rowid - e * units, y1, x1, pb);
-    const int ix = (int)RP.ii[e];
-    const int x1c = min(x1, w1 - 1);
-    dsrc = RP.disps[(size_t)ix * HW1 + y1 * w1 + x1c];
-#ifndef SH_NO_XCD_SWIZZLE
-    const int row0 = lb * SH_WAVES;
-#else
-    const int row0 = blockIdx.x * SH_WAVES;
-#endif
-    gsrc = max(0, e * units - row0);  // the wave of this workgroup that owns the edge's first unit here
-    if (wave == gsrc) {
-      const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);
-      if (lane == 0) {
-        float4 *g4 = reinterpret_cast<float4 *>(geom_all[wave]);
-        g4[0] = make_float4(G.R[0], G.R[1], G.R[2], G.R[3]);
-        g4[1] = make_float4(G.R[4], G.R[5], G.R[6], G.R[7]);
-        g4[2] = make_float4(G.R[8], G.t[0], G.t[1], G.t[2]);
-        g4[3] = make_float4(G.ifx, G.ify, G.cxi, G.cyi);
-        g4[4] = make_float4(G.fxj, G.fyj, G.cxj, G.cyj);
-      }
-    }
-  }
-  __syncthreads();
-
-  if (rowvalid) {
-    const int e = rowid / units;
-    int y1, x1, pbase;
-    unit_geometry(rowid - e * units, y1, x1, pbase);
-    const bool active = x1 < w1;
-    const int x1c = min(x1, w1 - 1);
-    float2 cxy;
-    if (reproj) {
-      const float4 *g4 = reinterpret_cast<const float4 *>(geom_all[gsrc]);
-      const float4 a = g4[0], b = g4[1], c = g4[2], d = g4[3], f = g4[4];
-      EdgeGeom G;
-      G.R[0] = a.x; G.R[1] = a.y; G.R[2] = a.z; G.R[3] = a.w; G.R[4] = b.x; G.R[5] = b.y; G.R[6] = b.z; G.R[7] = b.w;
-      G.R[8] = c.x; G.t[0] = c.y; G.t[1] = c.z; G.t[2] = c.w;
-      G.ifx = d.x; G.ify = d.y; G.cxi = d.z; G.cyi = d.w; G.fxj = f.x; G.fyj = f.y; G.cxj = f.z; G.cyj = f.w;
-      float ok;
-      cxy = reproject_pixel(G, (float)x1c, (float)y1, dsrc, ok);
-      if (lvl == 0 && active) {  // one level of the launch hands the coordinates to the caller
-        if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + y1 * w1 + x1] = cxy;
-        if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + y1 * w1 + x1] = ok;
-      }
-    } else {
-      cxy = sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1c);
-    }
-    const ShPixel P = sh_pixel<R>(cxy, lvl, x1c, y1, h2l, w2l, active, slvl);
-    const bool touches = P.touches;
-    const int ox = P.ox, oy = P.oy;
-    _Float16 *obase = olvl + (size_t)e * estride;     // uniform
-    const unsigned pix = (unsigned)(y1 * w1 + x1);   // this lane's pixel inside a channel plane (row-major, whatever the planes' order)
-
-    // (the streaming path addresses one edge's level through a buffer resource: 31-bit byte range)
-    const int xlast = __builtin_amdgcn_readlane(x1, 63);
-    const bool can_stream = ((w1 & 7) == 0) && (xlast < w1) &&
-                            ((size_t)h2l * w2l * HW1 * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
-    const unsigned long long tmask = __ballot(touches);
-    int refx = 0, refy = 0;
-    if (tmask) {
-      const int first = __ffsll((long long)tmask) - 1, last = 63 - __clzll((long long)tmask);
-      const int fxo = __builtin_amdgcn_readlane(ox, first), fyo = __builtin_amdgcn_readlane(oy, first);
-      const int lxo = __builtin_amdgcn_readlane(ox, last), lyo = __builtin_amdgcn_readlane(oy, last);
-      const bool nearf = touches && (abs(ox - fxo) <= SH_BAND) && (abs(oy - fyo) <= SH_BAND);
-      const bool nearl = touches && (abs(ox - lxo) <= SH_BAND) && (abs(oy - lyo) <= SH_BAND);
-      const bool usef = __popcll(__ballot(nearf)) >= __popcll(__ballot(nearl));
-      refx = usef ? fxo : lxo;
-      refy = usef ? fyo : lyo;
-    }
-    const bool inlier = can_stream && touches && (abs(ox - refx) <= SH_BAND) && (abs(oy - refy) <= SH_BAND);
-    const bool outlier = touches && !inlier;
-    if (outlier) olist[atomicAdd(&ocount, 1)] = (int)((unsigned)e * (unsigned)HW1 + pix);  // <= 64 per wave: the list cannot overflow
-
-    const int big = 1 << 28;
-    const bool any = __ballot(inlier) != 0ull;
-
-    if (!any) {
-      // nothing streams in this wave: lanes that touch nothing are exact zeros, outliers are written later
-      if (active && !outlier) {
-        _Float16 *o = obase + pix;
-#pragma unroll
-        for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
-      }
-    } else {
-      const int bx0 = wave_minmax<true>(inlier ? ox : big);
-      const int by0 = wave_minmax<true>(inlier ? oy : big), by1 = wave_minmax<false>(inlier ? oy : -big);
-      const int ny = min(by1 - by0 + WN, SH_NY);  // (the union is at most 16 x 16 by construction)
-      // window origin of this lane inside the union (0 for lanes that stream nothing: they read row 0 with zero
-      // weights and emit exact zeros -- except outliers, whose outputs are left to the gather phase)
-      const int rx = inlier ? ox - bx0 : 0, ry = inlier ? oy - by0 : 0;
-      // per 8-lane group (= one 16-byte piece of a line): the range of window origins inside the group, packed
-      // into one word so that a single cross-lane permute hands it to the lanes that fetch the group's pieces
-      const int gx0 = group8_minmax<true>(inlier ? rx : 15), gx1 = group8_minmax<false>(inlier ? rx : -1);
-      const int gy0 = group8_minmax<true>(inlier ? ry : 15), gy1 = group8_minmax<false>(inlier ? ry : -1);
-      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
-      const int sub = lane & 7;  // 16-byte piece (fixed for both staging slots of a lane)
-      const int pg = __builtin_amdgcn_ds_bpermute(sub * 32, packed);  // from lane 8 * sub
-      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
-      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
-      const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
-
-      // staging slots: lane + 64 t -> plane-row jx = (lane >> 3) + 8 t of the union, piece sub
-      // (the piece's 8 pixels are the lanes 8 sub .. 8 sub + 7: one row of the map in either pixel order)
-      const int xs = __builtin_amdgcn_ds_bpermute(sub * 32, x1);            // first x1 of this piece
-      const int ysl = __builtin_amdgcn_ds_bpermute(sub * 32, y1 >> lvl);    // its source row at this level
-      // union rows whose target row (ysl + by0 + row) lies inside the map, for this piece
-      const int vr0 = max(0, -(ysl + by0)), vr1 = min(min(by1 - by0 + WN, SH_NY), h2l - (ysl + by0));
-      unsigned goff[2], jlo[2], jlen[2];
-      int ldsoff[2];
-      u4v *keep = &keep_all[wave][0][lane];  // [t * 64]: parked in LDS, 8 VGPRs less in the streaming loop
-      bool edge_any = false;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int jx = (lane >> 3) + 8 * t;
-        const int dxv = bx0 + jx;
-        // (fetching the whole union box instead of the per-piece ranges, ~30 % more bytes, changes nothing: DESIGN 4.1)
-        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN);
-        // plane-rows [py0, py1 + WN) are read by this piece's lanes; of those, the ones inside the map are requested
-        const int r0 = max(py0, vr0), r1 = min(py1 + WN, vr1);
-        jlo[t] = (unsigned)r0;
-        jlen[t] = (act && r1 > r0) ? (unsigned)(r1 - r0) : 0u;
-        int m;
-        if (pow2) m = dxv & (w2l - 1);
-        else { m = dxv % w2l; m += (m < 0) ? w2l : 0; }
-        // valid q: 0 <= ((xs + q) >> lvl) + dxv < w2l  <=>  qa <= q < qb
-        const int lo = (dxv < 0) ? ((-dxv) << lvl) : 0;
-        const int hi = (w2l - dxv > 0) ? ((w2l - dxv) << lvl) : 0;
-        const int qa = max(0, lo - xs), qb = min(8, hi - xs);
-        // 16-bit keep mask per half of the piece
-        u4v k;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          const unsigned l_ = (2 * d >= qa && 2 * d < qb) ? 0x0000ffffu : 0u;
-          const unsigned h_ = (2 * d + 1 >= qa && 2 * d + 1 < qb) ? 0xffff0000u : 0u;
-          k[d] = l_ | h_;
-        }
-        keep[t * 64] = k;
-        edge_any |= act && (qa > 0 || qb < 8);
-        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + (unsigned)pbase + (unsigned)sub * 8u);  // bytes inside one plane-row dy
-        ldsoff[t] = jx * 64 + sub * 8;
-      }
-      const bool masked = __ballot(edge_any) != 0ull;  // some piece of this wave straddles the image border
-      int dym;
-      if (pow2) dym = by0 & (h2l - 1);
-      else { dym = by0 % h2l; dym += (dym < 0) ? h2l : 0; }
-      dym = __builtin_amdgcn_readfirstlane(dym);
-      const size_t rowstride = (size_t)w2l * HW1;  // elements between consecutive dy
-      const unsigned rowbytes = (unsigned)(2 * rowstride);
-
-      // Buffer resources (raw, bounds-checked): a lane that must not load / store presents an out-of-range offset,
-      // which the memory pipeline drops (loads return zeros).  No branches and no exec changes around the memory
-      // instructions, so every step issues the same instruction sequence and the waits on the loads that were
-      // issued SH_DEPTH steps earlier are exact counts instead of "everything outstanding".
-      constexpr unsigned OOR = 0x80000000u;
-      const int es = slots ? slots[e] : e;                                // uniform: the edge's slot in the stores
-      const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;  // uniform: this edge, this level
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)((unsigned)h2l * rowbytes), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rout =
-          __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
-
-      // packed weights and per-lane emission state
-      h2v W00, W01, W10, W11;
-      W00.x = W00.y = P.h00;
-      W01.x = W01.y = P.h01;
-      W10.x = W10.y = P.h10;
-      W11.x = W11.y = P.h11;
-      const bool writes = active && !outlier;
-      // lanes that touch nothing blend zero taps with zero weights: exact zeros without a select per channel pair
-      const _Float16 *tp = touches ? stage + rx * 64 + lane : zero_taps + lane;
-
-      auto request = [&](int row, int dy, u4v (&dst)[2]) {  // pieces of plane-row `row` of the union (dy = its plane)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const bool need = (((unsigned)row - jlo[t]) < jlen[t]);  // row in [jlo, jlo + jlen): inside the union, the map and ny
-          dst[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, need ? goff[t] : OOR, (unsigned)dy * rowbytes, SH_LOAD_AUX);
-        }
-      };
-
-      // ring of SH_DEPTH plane-rows in flight: regs[r] is receiving the pieces of row jy with jy % D == r
-      u4v regs[SH_DEPTH][2];
-      int dnext = dym;  // plane (mod h2l) of the next row to request
-#pragma unroll
-      for (int r = 0; r < SH_DEPTH; r++) {
-        request(r, dnext, regs[r]);
-        dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
-      }
-
-      // one plane-row: stage it, request the row SH_DEPTH ahead, read this lane's taps into `cur`, blend with `prev`
-      auto step = [&](int jy, const ShTaps &prev, ShTaps &cur, auto ring, auto emits) {
-        constexpr int r = decltype(ring)::value;
-        constexpr bool EMITS = decltype(emits)::value;  // false for row 0: no lane has a previous tap-row yet
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          u4v v = regs[r][t];
-          if (masked) v &= keep[t * 64];
-          *reinterpret_cast<u4v *>(&stage[ldsoff[t]]) = v;  // rows / pieces nobody needs arrive as zeros
-        }
-#ifndef SH_ABLATE_LOADS
-        request(jy + SH_DEPTH, dnext, regs[r]);
-#endif
-        dnext = (dnext + 1 == h2l) ? 0 : dnext + 1;
-        // LDS operations of one wave execute in program order: no wait between the row's writes and the tap reads
-        __builtin_amdgcn_wave_barrier();
-        sh_read_taps(tp, cur);
-        if constexpr (EMITS) {
-          const int j = jy - ry;
-          const bool emit = writes && ((unsigned)(j - 1) < (unsigned)RD);
-          const unsigned voff = emit ? 2u * (pix + (unsigned)(j - 1) * (unsigned)HW1) : OOR;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            h2v acc = prev.e[k] * W00;
-            acc = acc + cur.e[k] * W01;
-            acc = acc + prev.o[k] * W10;
-            acc = acc + cur.o[k] * W11;
-            const unsigned bits = __builtin_bit_cast(unsigned, acc);
-            const unsigned col = 2u * (unsigned)(2 * k * RD) * (unsigned)HW1;  // bytes to channel column a = 2k (uniform)
-#ifdef SH_ABLATE_STORES  // ablation builds only (scratch/): keep the value live, store one channel
-            if (k == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, SH_STORE_AUX); else asm volatile("" ::"v"(bits));
-#else
-            // (the high half goes through an explicit shift: handing the builtin `acc.y` directly makes this compiler
-            // store the LOW half of the packed register)
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, col, SH_STORE_AUX);
-            if (k < 3)
-              __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, col + 2u * RD * (unsigned)HW1, SH_STORE_AUX);
-#endif
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      };
-
-      ShTaps A, B;
-#pragma unroll
-      for (int k = 0; k < 4; k++) A.e[k] = A.o[k] = B.e[k] = B.o[k] = (h2v)((_Float16)0.f);
-      // unrolled over lcm(2, SH_DEPTH) rows: the two tap-row register sets alternate roles and the ring slot of a
-      // row is a compile-time index.  Rows past ny are requested out of range and emit nothing.
-      constexpr int UNR = (SH_DEPTH % 2 == 0) ? SH_DEPTH : 2 * SH_DEPTH;
-      auto body = [&](int jy, auto uc, auto emits) {
-        constexpr int u = decltype(uc)::value;
-        if constexpr (u % 2 == 0) step(jy + u, B, A, std::integral_constant<int, u % SH_DEPTH>{}, emits);
-        else step(jy + u, A, B, std::integral_constant<int, u % SH_DEPTH>{}, emits);
-      };
-      auto group = [&](int jy, auto first_emits) {
-        body(jy, std::integral_constant<int, 0>{}, first_emits);
-        if constexpr (UNR > 1) body(jy, std::integral_constant<int, 1>{}, std::true_type{});
-        if constexpr (UNR > 2) body(jy, std::integral_constant<int, 2>{}, std::true_type{});
-        if constexpr (UNR > 3) body(jy, std::integral_constant<int, 3>{}, std::true_type{});
-        if constexpr (UNR > 4) body(jy, std::integral_constant<int, 4>{}, std::true_type{});
-        if constexpr (UNR > 5) body(jy, std::integral_constant<int, 5>{}, std::true_type{});
-        static_assert(UNR <= 6, "SH_DEPTH up to 4");
-      };
-      group(0, std::false_type{});  // peeled: row 0 only loads taps (no lane has a previous tap-row yet); ny >= 8 > UNR
-      for (int jy = UNR; jy < ny; jy += UNR) group(jy, std::true_type{});
-    }
-  }
-
-  // ---- gather phase: the workgroup's outliers, 64 per wave, straight from the sheared volume ---------------
-  __syncthreads();
-  const int cnt = ocount;
-  for (int t = threadIdx.x; t < cnt; t += SH_BLOCK) {
-    const int pix = olist[t];  // (e * h1 + y1) * w1 + x1
-    const int x1 = pix % w1, ey = pix / w1;
-    const int y1 = ey % h1, e = ey / h1;
-    float2 cxy;
-    if (reproj) {
-      const int ix = (int)RP.ii[e];
-      float ok;
-      cxy = reproject_pixel(edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]), (float)x1, (float)y1,
-                            RP.disps[(size_t)ix * HW1 + y1 * w1 + x1], ok);
-    } else {
-      cxy = sh_coord(coords, cplanar, (size_t)e, HW1, y1 * w1 + x1);
-    }
-    const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, true, slvl);
-    const int es = slots ? slots[e] : e;
-    const _Float16 *vol = L.vol[lvl] + (size_t)es * h2l * w2l * HW1 + (size_t)sh_pixel_index(y1, x1, w1, tiled != 0);
-    _Float16 *o = olvl + (size_t)e * estride + (size_t)y1 * w1 + x1;
-    int dxm[WN];
-    bool cok[WN];
-#pragma unroll
-    for (int i = 0; i < WN; i++) {
-      int m = (P.ox + i) % w2l;
-      m += (m < 0) ? w2l : 0;
-      dxm[i] = m;
-      const int tx = P.ix0 + i;
-      cok[i] = (tx >= 0) && (tx < w2l);
-    }
-    int dym = P.oy % h2l;
-    dym += (dym < 0) ? h2l : 0;
-    _Float16 prev[WN];
-#pragma unroll
-    for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
-    for (int j = 0; j < WN; j++) {
-      const int ty = P.iy0 + j;
-      const bool rok = (ty >= 0) && (ty < h2l);
-      _Float16 cur[WN];
-#pragma unroll
-      for (int i = 0; i < WN; i++)
-        cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1] : (_Float16)0.f;
-      if (j >= 1) {
-#pragma unroll
-        for (int a = 0; a < RD; a++)
-          o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
-      }
-#pragma unroll
-      for (int i = 0; i < WN; i++) prev[i] = cur[i];
-      dym = (dym + 1 == h2l) ? 0 : dym + 1;
-    }
   }
 }
 
@@ -918,578 +511,6 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
 #pragma unroll
           for (int a = 0; a < RD; a++)
             o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
-        }
-#pragma unroll
-        for (int i = 0; i < WN; i++) prev[i] = cur[i];
-        dym = (dym + 1 == h2l) ? 0 : dym + 1;
-      }
-    }
-  }
-}
-
-
-// =====================================================================================================================
-// Lookup, third form ("pair"): the resident form with TWO ADJACENT PIXELS PER LANE.
-//
-//   * a wave = 128 consecutive pixels of the flattened (y1, x1) index (two aligned 128-byte lines of every plane); lane l
-//     owns the pixels 2 l and 2 l + 1 and keeps their taps in ONE register per tap column -- low half: pixel 2 l, high half:
-//     pixel 2 l + 1 -- so that the blend is `v_pk_*_f16` over PIXELS with per-pixel packed weights: 49 packed operations
-//     per tap row and pixel pair (the channel-pair forms need 28 + 3 re-alignments per pixel), and an output channel
-//     leaves as ONE 4-byte store per lane (256 bytes per instruction): half the store instructions per pixel of the
-//     resident form, 0.4 of the streaming form's;
-//   * everything per wave (coordinates -> window origins -> union -> addresses) is paid once per 128 pixels;
-//   * the union of the 128 pixels' windows is held in LDS (exec-masked LDS-DMA of the 16-byte pieces some 8-pixel group
-//     needs), lanes walk their own tap rows in lock-step; lanes far from the others go to later passes, then to a gather.
-// Needs an even map width and an even number of 64-pixel strips per plane (64x64 and 48x64 maps; others use the other
-// forms).  Arithmetic: each half of a packed operation rounds like the scalar operation -- identical to the other forms
-// and to the reference, bit for bit (same order w00, w01, w10, w11: correlation_kernels.cu:55-65).
-#ifndef SH3_LCAP_CFG
-#define SH3_LCAP_CFG 288
-#endif
-constexpr int SH3_LCAP = SH3_LCAP_CFG;                 // lines (128 B) of staging per wave
-constexpr int SH3_WAVE_BYTES = SH3_LCAP * 128 + 2048;  // + 8 zero line pairs
-constexpr int SH3_MAXPASS = 3;
-
-template <bool IS_MIN>
-__device__ __forceinline__ int group4_minmax(int x) {  // result in all 4 lanes of the quad
-  x = dpp_minmax<0xB1, 0xf, IS_MIN>(x);  // quad_perm [1,0,3,2]
-  x = dpp_minmax<0x4E, 0xf, IS_MIN>(x);  // quad_perm [2,3,0,1]
-  return x;
-}
-
-template <int R>
-__global__ __launch_bounds__(64, 1) void corr_lookup_pair_kernel(
-    ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP, int tiled) {
-  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
-  static_assert(WN == 8, "written for radius 3");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int HW1 = h1 * w1;
-  const int pstrips = HW1p >> 7;  // 128-pixel strips per edge
-  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
-  const int sid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);  // XCD-contiguous order (see the streaming form)
-  const int lvl = blockIdx.y + lvl0;
-  const int slvl = (cflags & 2) ? 0 : lvl;
-  const bool cplanar = (cflags & 1) != 0;
-  if (sid >= n * pstrips) return;
-  const int e = sid / pstrips, p0 = (sid - e * pstrips) << 7;
-  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
-  const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
-  const float inv_w2l = 1.0f / (float)w2l, inv_h2l = 1.0f / (float)h2l;
-
-  unsigned char *const stage = smem;                    // [row][nxa][128 pixels] halves
-  unsigned char *const zeros = stage + SH3_LCAP * 128;  // 8 line pairs of zeros
-  {
-    u4v z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u4v *>(zeros + lane * 16) = z;
-    *reinterpret_cast<u4v *>(zeros + 1024 + lane * 16) = z;
-  }
-
-  // ---- this lane's two pixels (same row: w1 is even and pA is even)
-  const int pA = p0 + 2 * lane;    // index on the planes' pixel axis (even: its neighbour 2 l + 1 is the next pixel of the
-  const bool active = pA < HW1;    // same row in the linear AND in the tiled order); HW1 is even: both pixels or none
-  const int pcp = min(pA, HW1 - 2);
-  int y1, x1;
-  sh_pixel_yx(pcp, w1, inv_w1, tiled != 0, y1, x1);
-  const int pc = y1 * w1 + x1;     // row-major index of pixel A: coordinates, inverse depths, outputs
-  float2 cA, cB;
-  if (cflags & 4) {  // the reprojection taken along (ShReproj)
-    const int ix = (int)RP.ii[e];
-    const float2 d2 = *reinterpret_cast<const float2 *>(RP.disps + (size_t)ix * HW1 + pc);
-    const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);  // uniform
-    float okA, okB;
-    cA = reproject_pixel(G, (float)x1, (float)y1, d2.x, okA);
-    cB = reproject_pixel(G, (float)(x1 + 1), (float)y1, d2.y, okB);
-    if (lvl == 0 && active) {
-      if (RP.coords_out) *reinterpret_cast<float4 *>(RP.coords_out + (size_t)e * HW1 + pc) = make_float4(cA.x, cA.y, cB.x, cB.y);
-      if (RP.valid_out) *reinterpret_cast<float2 *>(RP.valid_out + (size_t)e * HW1 + pc) = make_float2(okA, okB);
-    }
-  } else if (!cplanar) {
-    const float4 c4 = *reinterpret_cast<const float4 *>(coords + (size_t)e * HW1 + pc);
-    cA = make_float2(c4.x, c4.y);
-    cB = make_float2(c4.z, c4.w);
-  } else {
-    cA = sh_coord(coords, true, (size_t)e, HW1, pc);
-    cB = sh_coord(coords, true, (size_t)e, HW1, pc + 1);
-  }
-  const ShPixel PA = sh_pixel<R>(cA, lvl, x1, y1, h2l, w2l, active, slvl);
-  const ShPixel PB = sh_pixel<R>(cB, lvl, x1 + 1, y1, h2l, w2l, active, slvl);
-  const bool tA = PA.touches, tB = PB.touches, tany = tA || tB;
-
-  _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;  // this edge, this level: [49][HW1]
-  const size_t rowstride = (size_t)w2l * HW1p;
-  const unsigned rowbytes = (unsigned)(2 * rowstride);
-  const int es = slots ? slots[e] : e;
-  const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
-  const bool can_stream = ((size_t)h2l * rowbytes < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
-  constexpr unsigned OOR = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rin =
-      __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, can_stream ? (int)((unsigned)h2l * rowbytes) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout =
-      __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, can_stream ? (int)(2u * RD * RD * (unsigned)HW1) : 0, 0x00020000);
-
-  // pixel-packed weights: low half pixel A, high half pixel B
-  h2v W00, W01, W10, W11;
-  W00.x = PA.h00; W00.y = PB.h00;
-  W01.x = PA.h01; W01.y = PB.h01;
-  W10.x = PA.h10; W10.y = PB.h10;
-  W11.x = PA.h11; W11.y = PB.h11;
-
-  // validity of the taps (image border), per pixel: columns i in [ia, ib), rows j in [ja, jb); as packed keep masks
-  const int iaA = max(0, -PA.ix0), ibA = min(WN, w2l - PA.ix0), jaA = max(0, -PA.iy0), jbA = min(WN, h2l - PA.iy0);
-  const int iaB = max(0, -PB.ix0), ibB = min(WN, w2l - PB.ix0), jaB = max(0, -PB.iy0), jbB = min(WN, h2l - PB.iy0);
-  const bool clipA = tA && (iaA > 0 || ibA < WN || jaA > 0 || jbA < WN);
-  const bool clipB = tB && (iaB > 0 || ibB < WN || jaB > 0 || jbB < WN);
-
-  unsigned long long todo = can_stream ? __ballot(tany) : 0ull;
-  unsigned long long never_ = 0ull;
-  const unsigned long long untouched = __ballot(active && !tany);
-  bool first = true;
-  const int big = 1 << 28;
-
-  for (int pass = 0; pass < SH3_MAXPASS && (todo != 0ull || (first && untouched != 0ull)); pass++) {
-    const bool mine = ((todo >> lane) & 1ull) != 0ull;
-    bool in = mine;
-    int bx0 = 0, by0 = 0, nxa = 8, ny = 8;
-    // this lane's origin range over its touching pixels
-    const int lox0 = min(tA ? PA.ox : big, tB ? PB.ox : big), lox1 = max(tA ? PA.ox : -big, tB ? PB.ox : -big);
-    const int loy0 = min(tA ? PA.oy : big, tB ? PB.oy : big), loy1 = max(tA ? PA.oy : -big, tB ? PB.oy : -big);
-    if (todo != 0ull) {
-      const int fl = __ffsll((long long)todo) - 1;
-      const int refx = __builtin_amdgcn_readlane(lox0, fl), refy = __builtin_amdgcn_readlane(loy0, fl);
-      int band = 64;
-      for (;;) {
-        in = mine && (lox0 - refx >= -band) && (lox1 - refx <= band) && (loy0 - refy >= -band) && (loy1 - refy <= band);
-        bx0 = wave_minmax<true>(in ? lox0 : big);
-        by0 = wave_minmax<true>(in ? loy0 : big);
-        const int bx1 = wave_minmax<false>(in ? lox1 : -big), by1 = wave_minmax<false>(in ? loy1 : -big);
-        nxa = bx1 - bx0 + WN;
-        ny = by1 - by0 + WN;
-        if (nxa <= 16 && ny <= 16 && 2 * nxa * ny <= SH3_LCAP) break;
-        band = (band > 4) ? 4 : (band >> 1);  // 64 -> 4 -> 2 -> 1 -> 0 (band 0 with one lane: <= 9 x 9 offsets)
-        if (band == 0) {  // the reference lane alone (its two windows may differ: it still has to fit)
-          in = mine && (lane == fl);
-          bx0 = refx;
-          by0 = refy;
-          nxa = __builtin_amdgcn_readlane(lox1, fl) - refx + WN;
-          ny = __builtin_amdgcn_readlane(loy1, fl) - refy + WN;
-          if (!(nxa <= 16 && ny <= 16 && 2 * nxa * ny <= SH3_LCAP)) in = false;  // two far-apart windows: gather
-          break;
-        }
-      }
-    } else {
-      in = false;
-    }
-    const unsigned long long inmask = __ballot(in);
-    unsigned long long drop = 0ull;  // lanes that can never stream (band-0 lane whose own two windows are too far apart)
-    if (todo != 0ull && inmask == 0ull) drop = 1ull << (__ffsll((long long)todo) - 1);
-
-    // ---- staging --------------------------------------------------------------------------------------------------
-    if (inmask != 0ull) {
-      const int rx0 = in ? lox0 - bx0 : 31, rx1 = in ? lox1 - bx0 : -1, ry0 = in ? loy0 - by0 : 31, ry1 = in ? loy1 - by0 : -1;
-      const int gx0 = group4_minmax<true>(rx0), gx1 = group4_minmax<false>(rx1);
-      const int gy0 = group4_minmax<true>(ry0), gy1 = group4_minmax<false>(ry1);
-      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
-      const int sub = lane & 15;                                       // 16-byte piece of a 256-byte line pair
-      const int pg = __builtin_amdgcn_ds_bpermute(sub * 16, packed);   // from lane 4 * sub
-      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
-      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
-      unsigned goff[4], jlen[4];
-      const unsigned jlo = (unsigned)py0;
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int jx = (lane >> 4) + 4 * t;
-        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN) && (jx < nxa);
-        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
-        const int m = sh2_mod(bx0 + jx, w2l, inv_w2l, pow2);
-        goff[t] = 2u * ((unsigned)m * (unsigned)HW1p + (unsigned)p0 + (unsigned)sub * 8u);
-      }
-      int dym = __builtin_amdgcn_readfirstlane(sh2_mod(by0, h2l, inv_h2l, pow2));
-      const int nt = (nxa + 3) >> 2;  // staging instructions per row
-      unsigned ldsrow = 0u;
-      const unsigned ldspitch = (unsigned)nxa * 256u;
-      for (int row = 0; row < ny; row++) {
-        const unsigned soff = (unsigned)dym * rowbytes;
-        dym = (dym + 1 == h2l) ? 0 : dym + 1;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          if (t < nt) {
-            if (((unsigned)row - jlo) < jlen[t])
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow + 1024u * t),
-                                                       16, goff[t], soff, 0, SH_LOAD_AUX);
-          }
-        }
-        ldsrow += ldspitch;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- compute: tap rows j = 0..7 of both pixels of every lane in lock-step -----------------------------------------
-    const bool zero_lane = first && active && !tany;
-    const bool writes = in || zero_lane;
-    const unsigned long long wm = __ballot(writes);
-    const bool masked = __ballot(in && (clipA || clipB)) != 0ull;
-    const bool useA = in && tA, useB = in && tB;
-    const unsigned zb = (unsigned)(zeros - smem) + 4u * (unsigned)lane;
-    const unsigned tbA = useA ? (unsigned)(((PA.oy - by0) * nxa + (PA.ox - bx0)) * 256) + 4u * (unsigned)lane : zb;
-    const unsigned tbB = useB ? (unsigned)(((PB.oy - by0) * nxa + (PB.ox - bx0)) * 256) + 4u * (unsigned)lane + 2u : zb + 2u;
-    const unsigned radvA = useA ? (unsigned)nxa * 256u : 0u, radvB = useB ? (unsigned)nxa * 256u : 0u;
-    const unsigned voff = writes ? 2u * (unsigned)pc : OOR;
-    const unsigned chb = 2u * (unsigned)HW1;
-
-    unsigned cmask[WN];  // per tap column: keep mask of (pixel A | pixel B)
-    if (masked) {
-#pragma unroll
-      for (int i = 0; i < WN; i++)
-        cmask[i] = ((!useA || !clipA || (i >= iaA && i < ibA)) ? 0x0000ffffu : 0u) |
-                   ((!useB || !clipB || (i >= iaB && i < ibB)) ? 0xffff0000u : 0u);
-    }
-    struct Row { h2v t[WN]; };
-    auto load_row = [&](int j, Row &T) {
-      const _Float16 *a = reinterpret_cast<const _Float16 *>(smem + tbA + (unsigned)j * radvA);
-      const _Float16 *b = reinterpret_cast<const _Float16 *>(smem + tbB + (unsigned)j * radvB);
-#pragma unroll
-      for (int i = 0; i < WN; i++) {
-        h2v v;
-        v.x = a[i * 128];
-        v.y = b[i * 128];
-        T.t[i] = v;
-      }
-      if (masked) {
-        const unsigned rmask = ((!useA || !clipA || (j >= jaA && j < jbA)) ? 0x0000ffffu : 0u) |
-                               ((!useB || !clipB || (j >= jaB && j < jbB)) ? 0xffff0000u : 0u);
-#pragma unroll
-        for (int i = 0; i < WN; i++)
-          T.t[i] = __builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, T.t[i]) & cmask[i] & rmask);
-      }
-    };
-    auto emit = [&](int b, const Row &prev, const Row &cur) {  // output row b of all 7 columns a, both pixels
-#pragma unroll
-      for (int a = 0; a < RD; a++) {
-        h2v acc = prev.t[a] * W00;
-        acc = acc + cur.t[a] * W01;
-        acc = acc + prev.t[a + 1] * W10;
-        acc = acc + cur.t[a + 1] * W11;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc), rout, voff, (unsigned)(a * RD + b) * chb,
-                                              SH_STORE_AUX);
-      }
-    };
-    if (wm != 0ull) {
-      Row A_, B_;
-      load_row(0, A_);
-      load_row(1, B_); emit(0, A_, B_);
-      load_row(2, A_); emit(1, B_, A_);
-      load_row(3, B_); emit(2, A_, B_);
-      load_row(4, A_); emit(3, B_, A_);
-      load_row(5, B_); emit(4, A_, B_);
-      load_row(6, A_); emit(5, B_, A_);
-      load_row(7, B_); emit(6, A_, B_);
-    }
-    __builtin_amdgcn_wave_barrier();  // the next pass overwrites the staging area
-    todo &= ~(inmask | drop);
-    never_ |= drop;  // (these lanes go to the gather below)
-    first = false;
-  }
-
-  // ---- what no pass took (or could take): per-pixel gather straight from the sheared volume --------------------------
-  const bool left = can_stream ? ((((todo | never_) >> lane) & 1ull) != 0ull) : active;
-  if (left) {
-#pragma unroll 1
-    for (int q = 0; q < 2; q++) {
-      const ShPixel &P = q ? PB : PA;
-      const _Float16 *vol = vedge + pA + q;
-      _Float16 *o = obase + pc + q;
-      if (!P.touches) {
-#pragma unroll
-        for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
-      } else {
-        int dxm[WN];
-        bool cok[WN];
-#pragma unroll
-        for (int i = 0; i < WN; i++) {
-          dxm[i] = sh2_mod(P.ox + i, w2l, inv_w2l, pow2);
-          const int tx = P.ix0 + i;
-          cok[i] = (tx >= 0) && (tx < w2l);
-        }
-        int dym = sh2_mod(P.oy, h2l, inv_h2l, pow2);
-        _Float16 prev[WN];
-#pragma unroll
-        for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
-        for (int j = 0; j < WN; j++) {
-          const int ty = P.iy0 + j;
-          const bool rok = (ty >= 0) && (ty < h2l);
-          _Float16 cur[WN];
-#pragma unroll
-          for (int i = 0; i < WN; i++)
-            cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1p] : (_Float16)0.f;
-          if (j >= 1) {
-#pragma unroll
-            for (int a = 0; a < RD; a++)
-              o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
-          }
-#pragma unroll
-          for (int i = 0; i < WN; i++) prev[i] = cur[i];
-          dym = (dym + 1 == h2l) ? 0 : dym + 1;
-        }
-      }
-    }
-  }
-}
-
-
-// =====================================================================================================================
-// Lookup, fourth form ("band"): tiles for the READS, rows for the WRITES.
-//
-// With the planes' pixel axis in 4 x 16 tiles (common.h) a 128-byte line serves a compact patch of the map, and the union
-// of a tile's windows is 79 lines where a 64 x 1 strip needs 92 (bench scene) -- but a wave that OWNS a tile stores every
-// output channel as four 32-byte pieces of four different lines, and the vector memory pipe pays per line: the tile-owning
-// forms lose more on their stores than they gain on their reads (round 4: 111 against 95 us).  Here a workgroup of four
-// waves takes a BAND of the map (4 rows x 64 columns = the four tiles of one tile row; maps 64 pixels wide):
-//   phase 1  wave w is the LOADER of tile w: window origins of the tile's pixels, their union, exec-masked LDS-DMA of the
-//            pieces some 8-pixel group needs into the tile's LDS region (the resident form's staging);
-//   barrier
-//   phase 2  wave w is the WORKER of map row w of the band: lane = x1; a pixel's taps sit in the region of ITS tile
-//            (x1 >> 4) at the slot of its position in that tile; lock-step over the tap rows, and every store instruction
-//            writes one channel of one whole map row: a full 128-byte line, as in the row-owning forms;
-//   phase 3  pixels a loader could not take into its tile's union (far from the others) are gathered by that loader's lane.
-// Arithmetic identical to the other forms (channel-pair packed f16), bit for bit.
-constexpr int SH4_LCAP = 144;                        // lines per tile region
-constexpr int SH4_REGION = SH4_LCAP * 128;
-constexpr int SH4_ZEROS = 4 * SH4_REGION;            // 8 zero lines
-constexpr int SH4_META = SH4_ZEROS + 1024;           // per tile: refx, refy, band, bx0, by0, nxa, any, -
-constexpr int SH4_BYTES = SH4_META + 4 * 32;
-
-template <int R>
-__global__ __launch_bounds__(256) void corr_lookup_band_kernel(ShLevels L, const float2 *__restrict__ coords,
-                                                               _Float16 *__restrict__ out, int n, int h1, int w1, int h2,
-                                                               int w2, int num_levels, int lvl0, int cflags,
-                                                               const int *__restrict__ slots, ShReproj RP) {
-  constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
-  static_assert(WN == 8, "written for radius 3");
-  static_assert(SH_TW == 16 && SH_TH == 4, "a band is one row of 4 x 16 tiles");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..3: tile (phase 1) / map row (phase 2) of the band
-  const int HW1 = h1 * w1;                                             // (w1 == 64)
-  const int bands = h1 >> 2;
-  const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
-  const int bid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);      // XCD-contiguous order
-  const int lvl = blockIdx.y + lvl0;
-  const int slvl = (cflags & 2) ? 0 : lvl;
-  const bool cplanar = (cflags & 1) != 0;
-  const int e = bid / bands, band = bid - e * bands;                   // (grid.x == n * bands exactly)
-  const int h2l = h2 >> lvl, w2l = w2 >> lvl;
-  const bool pow2 = ((w2l & (w2l - 1)) == 0) && ((h2l & (h2l - 1)) == 0);
-  const float inv_w2l = 1.0f / (float)w2l, inv_h2l = 1.0f / (float)h2l;
-  int *const meta = reinterpret_cast<int *>(smem + SH4_META);
-  if (threadIdx.x < 64) {
-    u4v z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u4v *>(smem + SH4_ZEROS + threadIdx.x * 16) = z;
-  }
-
-  EdgeGeom G;
-  int ix = 0;
-  if (cflags & 4) {
-    ix = (int)RP.ii[e];
-    G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);   // uniform
-  }
-  auto pixel = [&](int y1, int x1, bool hand_out) {             // coordinates -> lookup state of pixel (y1, x1)
-    const int plin = y1 * w1 + x1;
-    float2 c;
-    if (cflags & 4) {
-      float ok;
-      c = reproject_pixel(G, (float)x1, (float)y1, RP.disps[(size_t)ix * HW1 + plin], ok);
-      if (hand_out && lvl == 0) {
-        if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + plin] = c;
-        if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + plin] = ok;
-      }
-    } else {
-      c = sh_coord(coords, cplanar, (size_t)e, HW1, plin);
-    }
-    return sh_pixel<R>(c, lvl, x1, y1, h2l, w2l, true, slvl);
-  };
-
-  const size_t rowstride = (size_t)w2l * HW1;   // (tiled maps have no plane padding)
-  const unsigned rowbytes = (unsigned)(2 * rowstride);
-  const int es = slots ? slots[e] : e;
-  const _Float16 *vedge = L.vol[lvl] + (size_t)es * h2l * rowstride;
-  _Float16 *obase = out + ((size_t)e * num_levels + blockIdx.y) * RD * RD * HW1;
-  constexpr unsigned OOR = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)vedge, 0, (int)((unsigned)h2l * rowbytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (int)(2u * RD * RD * (unsigned)HW1), 0x00020000);
-  const int big = 1 << 28;
-
-  // ---- phase 1: loader of tile (band, wave) ------------------------------------------------------------------------------
-  const int ly = (band << 2) + (lane >> 4), lx = (wave << 4) + (lane & 15);
-  bool leftover;   // a touching pixel of this tile that its union does not cover: gathered in phase 3
-  {
-    const ShPixel P = pixel(ly, lx, false);
-    const unsigned long long tmask = __ballot(P.touches);
-    bool in = false;
-    int refx = 0, refy = 0, bw = -1, bx0 = 0, by0 = 0, nxa = 8, ny = 8;
-    if (tmask != 0ull) {
-      const int fl = __ffsll((long long)tmask) - 1;
-      refx = __builtin_amdgcn_readlane(P.ox, fl);
-      refy = __builtin_amdgcn_readlane(P.oy, fl);
-      bw = 64;
-      for (;;) {
-        in = P.touches && (abs(P.ox - refx) <= bw) && (abs(P.oy - refy) <= bw);
-        bx0 = wave_minmax<true>(in ? P.ox : big);
-        by0 = wave_minmax<true>(in ? P.oy : big);
-        const int bx1 = wave_minmax<false>(in ? P.ox : -big), by1 = wave_minmax<false>(in ? P.oy : -big);
-        nxa = bx1 - bx0 + WN;
-        ny = by1 - by0 + WN;
-        if (nxa <= 16 && ny <= 16 && nxa * ny <= SH4_LCAP) break;
-        bw = (bw > 4) ? 4 : (bw >> 1);   // 64 -> 4 -> 2 -> 1 -> 0 (one window: 8 x 8 lines)
-      }
-    }
-    leftover = P.touches && !in;
-    if (lane == 0) {
-      int *m = meta + 8 * wave;
-      m[0] = refx, m[1] = refy, m[2] = bw, m[3] = bx0, m[4] = by0, m[5] = nxa;
-    }
-    if (tmask != 0ull) {
-      const int rx = in ? P.ox - bx0 : 0, ry = in ? P.oy - by0 : 0;
-      const int gx0 = group8_minmax<true>(in ? rx : 31), gx1 = group8_minmax<false>(in ? rx : -1);
-      const int gy0 = group8_minmax<true>(in ? ry : 31), gy1 = group8_minmax<false>(in ? ry : -1);
-      const int packed = (gx0 & 0xff) | ((gx1 & 0xff) << 8) | ((gy0 & 0xff) << 16) | ((gy1 & 0xff) << 24);
-      const int sub = lane & 7;
-      const int pg = __builtin_amdgcn_ds_bpermute(sub * 32, packed);
-      const int px0 = (int)(signed char)(pg & 0xff), px1 = (int)(signed char)((pg >> 8) & 0xff);
-      const int py0 = (int)(signed char)((pg >> 16) & 0xff), py1 = (int)(signed char)((pg >> 24) & 0xff);
-      const unsigned p0 = (unsigned)((((band << 2) + wave)) << 6);   // plane index of the tile's first pixel (tiles_x == 4)
-      unsigned goff[2], jlen[2];
-      const unsigned jlo = (unsigned)py0;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int jx = (lane >> 3) + 8 * t;
-        const bool act = (px1 >= px0) && (jx >= px0) && (jx < px1 + WN) && (jx < nxa);
-        jlen[t] = act ? (unsigned)(py1 - py0 + WN) : 0u;
-        const int m = sh2_mod(bx0 + jx, w2l, inv_w2l, pow2);
-        goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + p0 + (unsigned)sub * 8u);
-      }
-      int dym = __builtin_amdgcn_readfirstlane(sh2_mod(by0, h2l, inv_h2l, pow2));
-      const bool wide = nxa > 8;
-      unsigned ldsrow = (unsigned)(wave * SH4_REGION);
-      const unsigned ldspitch = (unsigned)nxa * 128u;
-      for (int row = 0; row < ny; row++) {
-        const unsigned soff = (unsigned)dym * rowbytes;
-        dym = (dym + 1 == h2l) ? 0 : dym + 1;
-        if (((unsigned)row - jlo) < jlen[0])
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow), 16, goff[0],
-                                                   soff, 0, SH_LOAD_AUX);
-        if (wide) {
-          if (((unsigned)row - jlo) < jlen[1])
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(smem + ldsrow + 1024u), 16,
-                                                     goff[1], soff, 0, SH_LOAD_AUX);
-        }
-        ldsrow += ldspitch;
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- phase 2: worker of map row (band, wave) ----------------------------------------------------------------------------
-  {
-    const int y1 = (band << 2) + wave, x1 = lane;
-    const ShPixel P = pixel(y1, x1, true);
-    const int tx = lane >> 4;                                    // the pixel's tile, whose loader staged its window
-    const int slot = (wave << 4) | (lane & 15);                  // ... and its position in that tile
-    const int4 m0 = *reinterpret_cast<const int4 *>(meta + 8 * tx);
-    const int2 m1 = *reinterpret_cast<const int2 *>(meta + 8 * tx + 4);
-    const int refx = m0.x, refy = m0.y, bw = m0.z, bx0 = m0.w, by0 = m1.x, nxa = m1.y;
-    const bool in = P.touches && (abs(P.ox - refx) <= bw) && (abs(P.oy - refy) <= bw);   // the loader's decision, re-made
-    const bool writes = in || !P.touches;                        // (untouched pixels: exact zeros through zero weights)
-    h2v W00, W01, W10, W11;
-    W00.x = W00.y = P.h00;
-    W01.x = W01.y = P.h01;
-    W10.x = W10.y = P.h10;
-    W11.x = W11.y = P.h11;
-    const int ia = max(0, -P.ix0), ib = min(WN, w2l - P.ix0);
-    const int ja = max(0, -P.iy0), jb = min(WN, h2l - P.iy0);
-    const bool clipped = in && (ia > 0 || ib < WN || ja > 0 || jb < WN);
-    unsigned cm[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      cm[k] = ((2 * k >= ia && 2 * k < ib) ? 0x0000ffffu : 0u) | ((2 * k + 1 >= ia && 2 * k + 1 < ib) ? 0xffff0000u : 0u);
-    const bool masked = __ballot(clipped) != 0ull;
-    const unsigned tb = in ? (unsigned)(tx * SH4_REGION) + (unsigned)(((P.oy - by0) * nxa + (P.ox - bx0)) * 128) + 2u * (unsigned)slot
-                           : (unsigned)SH4_ZEROS + 2u * (unsigned)lane;
-    const unsigned radv = in ? (unsigned)nxa * 128u : 0u;
-    const unsigned voff = writes ? 2u * (unsigned)(y1 * w1 + x1) : OOR;
-    const unsigned chb = 2u * (unsigned)HW1;
-    ShTaps A, B;
-    auto load_row = [&](int j, ShTaps &T) {
-      sh_read_taps(reinterpret_cast<const _Float16 *>(smem + tb + (unsigned)j * radv), T);
-      if (masked) {
-        const bool rowok = (j >= ja) && (j < jb);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned keep = clipped ? (rowok ? cm[k] : 0u) : 0xffffffffu;
-          T.e[k] = __builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, T.e[k]) & keep);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned lo = __builtin_bit_cast(unsigned, T.e[k]);
-          const unsigned hi = (k < 3) ? __builtin_bit_cast(unsigned, T.e[k < 3 ? k + 1 : 3]) : 0u;
-          T.o[k] = __builtin_bit_cast(h2v, __builtin_amdgcn_alignbit(hi, lo, 16));
-        }
-      }
-    };
-    auto emit = [&](int b, const ShTaps &prev, const ShTaps &cur) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        h2v acc = prev.e[k] * W00;
-        acc = acc + cur.e[k] * W01;
-        acc = acc + prev.o[k] * W10;
-        acc = acc + cur.o[k] * W11;
-        const unsigned bits = __builtin_bit_cast(unsigned, acc);
-        const unsigned soff = (unsigned)((2 * k) * RD + b) * chb;
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bits, rout, voff, soff, SH_STORE_AUX);
-        if (k < 3)
-          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(bits >> 16), rout, voff, soff + (unsigned)RD * chb, SH_STORE_AUX);
-      }
-    };
-    load_row(0, A);
-    load_row(1, B); emit(0, A, B);
-    load_row(2, A); emit(1, B, A);
-    load_row(3, B); emit(2, A, B);
-    load_row(4, A); emit(3, B, A);
-    load_row(5, B); emit(4, A, B);
-    load_row(6, A); emit(5, B, A);
-    load_row(7, B); emit(6, A, B);
-  }
-
-  // ---- phase 3: what a loader left out of its tile's union, pixel by pixel ---------------------------------------------
-  if (__ballot(leftover) != 0ull) {
-    if (leftover) {
-      const ShPixel P = pixel(ly, lx, false);
-      const _Float16 *vol = vedge + ((((band << 2) + wave)) << 6) + lane;
-      _Float16 *o = obase + ly * w1 + lx;
-      int dxm[WN];
-      bool cok[WN];
-#pragma unroll
-      for (int i = 0; i < WN; i++) {
-        dxm[i] = sh2_mod(P.ox + i, w2l, inv_w2l, pow2);
-        const int txx = P.ix0 + i;
-        cok[i] = (txx >= 0) && (txx < w2l);
-      }
-      int dym = sh2_mod(P.oy, h2l, inv_h2l, pow2);
-      _Float16 prev[WN];
-#pragma unroll
-      for (int i = 0; i < WN; i++) prev[i] = (_Float16)0.f;
-      for (int j = 0; j < WN; j++) {
-        const int ty = P.iy0 + j;
-        const bool rok = (ty >= 0) && (ty < h2l);
-        _Float16 cur[WN];
-#pragma unroll
-        for (int i = 0; i < WN; i++) cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1] : (_Float16)0.f;
-        if (j >= 1) {
-#pragma unroll
-          for (int a = 0; a < RD; a++) o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], P);
         }
 #pragma unroll
         for (int i = 0; i < WN; i++) prev[i] = cur[i];
@@ -1839,11 +860,11 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
 
 using namespace dba;
 
-// 0 = automatic, 1 = streaming form, 2 = resident form, 3 = pair form (initialised from DBA_LOOKUP_KERNEL)
+// 0 = automatic, 2 = resident form, 5 = rows over tiles (initialised from DBA_LOOKUP_KERNEL = resident | rowtile; the
+// numbers are those of round 4's C ABI, whose forms 1, 3 and 4 no longer ship)
 static std::atomic<int> g_lookup_select{[] {
   const char *e = getenv("DBA_LOOKUP_KERNEL");
-  return (e && e[0] == 's') ? 1 : (e && e[0] == 'r' && e[1] == 'e') ? 2 : (e && e[0] == 'p') ? 3 : (e && e[0] == 'b') ? 4
-         : (e && e[0] == 'r' && e[1] == 'o') ? 5 : 0;   // stream | resident | pair | band | rowtile
+  return (e && e[0] == 'r' && e[1] == 'e') ? 2 : (e && e[0] == 'r' && e[1] == 'o') ? 5 : 0;
 }()};
 
 // events armed for the next lookup launch of this thread (dba_corr_lookup_arm_timing)
@@ -1858,7 +879,7 @@ int dba_corr_lookup_arm_timing(void *start_event, void *stop_event) {
 }
 
 int dba_corr_lookup_select(int kernel) {
-  if (kernel < 0 || kernel > 5) return DBA_ERR_ARG;
+  if (kernel != 0 && kernel != 2 && kernel != 5) return DBA_ERR_ARG;
   g_lookup_select.store(kernel, std::memory_order_relaxed);
   return DBA_OK;
 }
@@ -1896,61 +917,18 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
                                  const ShReproj &RP = ShReproj{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
   if ((long)n * h1 * w1 >= 2147483647L) return DBA_ERR_UNSUPPORTED;
   const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
-  // Two forms of the kernel (see the comments at each): "streaming" walks the union row by row (2 KB of LDS per wave,
-  // any union height; needs waves that are whole 64-pixel rows), "resident" holds the union in LDS (any map size, 7
-  // lock-step steps, full-line stores).  Measured from HBM (rotating pyramid copies): 64x64 maps, 96 / 512 edges:
-  // streaming 95.8 / 523 us, resident 102 / 535 us; 28x107, 122 edges: streaming 128, resident 104 us; 55x55 streams
-  // only in the resident form.  Automatic choice: streaming for 64-pixel-wide rows, resident otherwise;
-  // dba_corr_lookup_select() / DBA_LOOKUP_KERNEL=stream|resident override it.
+  // "rows over tiles" on tiled planes (maps whose rows are whole 64-pixel segments, common.h), "resident" on every other
+  // shape and on planes too large for the row walk's 32-bit offsets; dba_corr_lookup_select() / DBA_LOOKUP_KERNEL override.
   const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the planes' pixel order (common.h): a wave owns a 4 x 16 tile of the map
-  const bool stream_ok = (w1 % 64 == 0) || tiled;
   const int sel = g_lookup_select.load(std::memory_order_relaxed);
-  const bool want_stream = (sel == 1) || (sel == 0 && stream_ok);
   hipEvent_t e0 = g_time_start, e1 = g_time_stop;
   g_time_start = g_time_stop = nullptr;
-  // "band" form (tiles for the reads, rows for the writes): tiled planes of 64-pixel-wide maps
   const bool rowtile_ok = tiled && SH_TW == 16 && (w1 & 63) == 0 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * h1 * w1 * 2 < ((size_t)1 << 31);
-  const bool band_ok = tiled && SH_TW == 16 && w1 == 64 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * h1 * w1 * 2 < ((size_t)1 << 31);
-  if (sel == 4 && band_ok) {
-    static DeviceOnce band_once;
-    if (band_once.needed()) {
-      DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_lookup_band_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      band_once.done();
-    }
-    dim3 grid((unsigned)((long)n * (h1 / 4)), nlv);
-    hipExtLaunchKernelGGL((corr_lookup_band_kernel<3>), grid, dim3(256), (size_t)SH4_BYTES, (hipStream_t)stream, e0, e1, 0, L,
-                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2, nlv, lvl0,
-                          cflags, slots, RP);
-    DBA_LAUNCH_CHECK();
-    return DBA_OK;
-  }
-  if ((sel == 5 || sel == 0) && rowtile_ok) {   // "rows over tiles": the streaming walk, loaders per tile, workers per map row
+  if ((sel == 5 || sel == 0) && rowtile_ok) {   // loaders per tile, workers per map row
     dim3 grid((unsigned)((long)n * (h1 / 4) * (w1 / 64)), nlv);
     hipExtLaunchKernelGGL((corr_lookup_rowtile_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, L,
                           reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2, nlv, lvl0,
                           cflags, slots, RP);
-    DBA_LAUNCH_CHECK();
-    return DBA_OK;
-  }
-  // "pair" form (two adjacent pixels per lane, 4-byte stores): even map width, whole 128-pixel strips
-  const bool pair_ok = ((w1 & 1) == 0) && ((HW1p & 127) == 0) && (((h1 * w1) & 1) == 0);
-  if (sel == 3 && pair_ok) {
-    const long pst = (long)n * (HW1p / 128);
-    dim3 grid((unsigned)pst, nlv);
-    hipExtLaunchKernelGGL((corr_lookup_pair_kernel<3>), grid, dim3(64), (size_t)SH3_WAVE_BYTES, (hipStream_t)stream, e0, e1, 0, L,
-                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP, tiled);
-    DBA_LAUNCH_CHECK();
-    return DBA_OK;
-  }
-  if (want_stream && stream_ok) {
-    const int xtiles = (w1 + 63) / 64;
-    const long rows = tiled ? (long)n * (h1 * w1 / 64) : (long)n * h1 * xtiles;
-    dim3 grid((unsigned)((rows + SH_WAVES - 1) / SH_WAVES), nlv);
-    hipExtLaunchKernelGGL((corr_lookup_sheared_kernel<3>), grid, dim3(SH_BLOCK), 0, (hipStream_t)stream, e0, e1, 0, L,
-                          reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                          nlv, lvl0, cflags, slots, RP, tiled);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }

@@ -3,9 +3,11 @@
 // behaviour (CHECK_CONTIGUOUS -> c10::Error -> RuntimeError), every function a thin adapter over the C ABI of
 // include/dba_hip.h (libdba_hip.so: the hand-written gfx950 kernels).  No kernels here, no torch types below this file.
 //
-//   module name      _droid_backends_C   (dba-fusion_amd/droid_backends/__init__.py re-exports it next to the caching /
-//                                          shadowing policies that live in Python; `import _droid_backends_C as
-//                                          droid_backends` is a complete drop-in by itself)
+//   module name      _droid_backends_C   (dba-fusion_amd/droid_backends/__init__.py re-exports its stateless operators;
+//                                          `import _droid_backends_C as droid_backends` is a drop-in by itself: ba and
+//                                          BACore keep one workspace per window shape here too and let stage 0 recognise
+//                                          an unchanged edge list on the device.  Only the flow-aligned shadows of
+//                                          corr_index_forward are a policy of the Python package alone.)
 //   built by         make ext            (g++ against the torch headers; links libdba_hip.so by $ORIGIN-relative rpath)
 //
 // Work is enqueued on the caller's CURRENT HIP stream (c10::hip::getCurrentHIPStream), like every torch op around it.
@@ -14,7 +16,10 @@
 #include <c10/hip/HIPStream.h>
 
 #include <cstdint>
+#include <list>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "dba_hip.h"
@@ -57,17 +62,58 @@ BaDims ba_dims(const torch::Tensor &disps, const torch::Tensor &eta, const torch
   return d;
 }
 
-torch::Tensor workspace(const BaDims &d, const torch::Tensor &like, size_t *nbytes) {
+// One workspace per (pool, device, stream, window shape), the latest few, marked "no graph prepared" when allocated
+// (dba_ba_workspace_init): stage 0 of a later call compares its edge list with the key the previous one left there and skips
+// itself when the graph is unchanged -- the reference's caller hands over NEW ii / jj tensors with the same edges on every
+// update (torch.cat, dbaf/covisible_graph.py:242-247), so tensor identity would never hit.  pool 0: ba, pool 1: BACore (so
+// that nothing ba does can fall between a BACore's hessian and retract).
+torch::Tensor workspace(const BaDims &d, const torch::Tensor &like, size_t *nbytes, int pool) {
+  using Key = std::tuple<int, int, void *, int, int, int, int, int, int>;
+  static std::mutex mu;
+  static std::list<std::pair<Key, torch::Tensor>> cache;
   *nbytes = dba_ba_workspace_bytes(d.N, d.B, d.ht, d.wd, d.t0, d.t1);
   TORCH_CHECK(*nbytes > 0, "dba_ba_workspace_bytes: invalid sizes");
-  return torch::empty({(int64_t)*nbytes}, like.options().dtype(torch::kUInt8));
+  const Key key{pool, (int)like.get_device(), (void *)stream_of(like), d.N, d.B, d.ht, d.wd, d.t0, d.t1};
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto it = cache.begin(); it != cache.end(); ++it)
+    if (it->first == key) {
+      cache.splice(cache.begin(), cache, it);
+      return cache.front().second;
+    }
+  torch::Tensor ws = torch::empty({(int64_t)*nbytes}, like.options().dtype(torch::kUInt8));
+  check(dba_ba_workspace_init(d.N, d.B, d.ht, d.wd, d.t0, d.t1, ws.data_ptr(), *nbytes, stream_of(like)), "dba_ba_workspace_init");
+  cache.emplace_front(key, ws);
+  if (cache.size() > 8) cache.pop_back();
+  return ws;
 }
 
-// ba (src/droid.cpp:109-138): in place on poses[t0:t1], disps[kx]; returns {dx, dz}
-std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens,
-                              torch::Tensor targets, torch::Tensor weights, torch::Tensor eta, torch::Tensor ii,
-                              torch::Tensor jj, const int t0, const int t1, const int iterations, const float lm,
-                              const float ep, const bool motion_only) {
+// eta.view(-1, HW) must have one row or |kx| rows (droid_kernels.cu:1476).  |kx| only exists on the device: stage 0 compares
+// and records a mismatch in pinned memory, which the NEXT call into this module raises (the reference raises in the call
+// itself, whose torch::_unique stops the host anyway; these calls never do).
+void raise_pending_eta_error() {
+  int rows = 0, nk = 0;
+  TORCH_CHECK(!dba_ba_poll_eta_error(&rows, &nk), "an earlier droid_backends.ba / BACore.hessian call was given eta with ", rows,
+              " rows; it must have 1 or |unique(arange(t0,t1) U ii)| = ", nk, " rows (droid_kernels.cu:1476)");
+}
+
+void check_eta_bounds(const BaDims &d) {   // what is known without the device
+  const int P = std::max(d.t1 - d.t0, 0);
+  TORCH_CHECK(d.eta_rows == 1 || (d.eta_rows <= P + d.N && d.eta_rows >= std::min(P, 1)), "eta has ", d.eta_rows,
+              " rows; it must have 1 or |unique(arange(t0,t1) U ii)| rows (at most ", P + d.N, " here)");
+}
+
+// |kx| for the shape of the returned dz: eta's row count when it has one row per kx entry (as DBA-Fusion passes it,
+// covisible_graph.py:330; verified by stage 0), else counted on the device like the reference's torch::_unique (a sync)
+int64_t num_kx(const BaDims &d, const torch::Tensor &ii) {
+  if (d.eta_rows > 1) return d.eta_rows;
+  torch::Tensor ts = torch::arange(d.t0, d.t1, ii.options());
+  return std::get<0>(at::_unique(torch::cat({ts, ii}, 0))).size(0);
+}
+
+std::vector<torch::Tensor> ba_impl(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens,
+                                   torch::Tensor targets, torch::Tensor weights, torch::Tensor eta, torch::Tensor ii,
+                                   torch::Tensor jj, const int t0, const int t1, const int iterations, const float lm,
+                                   const float ep, const bool motion_only, const float disp_floor) {
   CHECK_INPUT(targets);
   CHECK_INPUT(weights);
   CHECK_INPUT(poses);
@@ -78,21 +124,43 @@ std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::T
   CHECK_INPUT(jj);
   eta = eta.contiguous();   // the reference takes eta.view(-1, ht*wd) of whatever it is given
   CHECK_DEVICE(eta);
-  if (iterations <= 0) return {torch::Tensor(), torch::Tensor()};   // (two undefined tensors, nothing touched: :1437)
+  raise_pending_eta_error();
   const BaDims d = ba_dims(disps, eta, ii, t0, t1);
+  check_eta_bounds(d);
+  if (iterations <= 0) return {torch::Tensor(), torch::Tensor()};   // (two undefined tensors, nothing touched: :1437)
   size_t nbytes;
-  torch::Tensor ws = workspace(d, poses, &nbytes);
+  torch::Tensor ws = workspace(d, poses, &nbytes, 0);
   const int P = t1 - t0;
   const int Mmax = std::min(d.B, P + d.N);
   torch::Tensor dx = torch::empty({P, 6}, poses.options());
   torch::Tensor dz = torch::empty({Mmax, (int64_t)d.ht * d.wd}, poses.options());
-  check(dba_ba(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), disps_sens.data_ptr<float>(),
-               targets.data_ptr<float>(), weights.data_ptr<float>(), eta.data_ptr<float>(), d.eta_rows, ii.data_ptr<int64_t>(),
-               jj.data_ptr<int64_t>(), d.N, d.B, d.ht, d.wd, t0, t1, iterations, lm, ep, motion_only ? 1 : 0,
-               dx.data_ptr<float>(), dz.data_ptr<float>(), ws.data_ptr(), nbytes, stream_of(poses)),
+  check(dba_ba_run(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), disps_sens.data_ptr<float>(),
+                   targets.data_ptr<float>(), weights.data_ptr<float>(), eta.data_ptr<float>(), d.eta_rows, ii.data_ptr<int64_t>(),
+                   jj.data_ptr<int64_t>(), d.N, d.B, d.ht, d.wd, t0, t1, iterations, lm, ep, motion_only ? 1 : 0,
+                   dx.data_ptr<float>(), dz.data_ptr<float>(), ws.data_ptr(), nbytes, stream_of(poses), /*prepared=*/2, 0,
+                   disp_floor),
         "dba_ba");
   if (motion_only) return {dx, torch::Tensor()};
-  return {dx, dz};   // rows [0, |kx|) of dz are written (|kx| is known on the device only)
+  return {dx, dz.narrow(0, 0, num_kx(d, ii))};   // [|kx|, ht*wd], the reference's shape
+}
+
+// ba (src/droid.cpp:109-138): in place on poses[t0:t1], disps[kx]; returns {dx, dz}
+std::vector<torch::Tensor> ba(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens,
+                              torch::Tensor targets, torch::Tensor weights, torch::Tensor eta, torch::Tensor ii,
+                              torch::Tensor jj, const int t0, const int t1, const int iterations, const float lm,
+                              const float ep, const bool motion_only) {
+  return ba_impl(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only, 0.f);
+}
+
+// ba followed by the caller's `disps.clamp_(min=disp_floor)` (dbaf/depth_video.py:559-560) in one call (dba_ba_run): not a
+// reference binding, see droid_backends.ba_clamped
+std::vector<torch::Tensor> ba_clamped(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor disps_sens,
+                                      torch::Tensor targets, torch::Tensor weights, torch::Tensor eta, torch::Tensor ii,
+                                      torch::Tensor jj, const int t0, const int t1, const int iterations, const float lm,
+                                      const float ep, const bool motion_only, const float disp_floor) {
+  TORCH_CHECK(disp_floor > 0.f, "ba_clamped: disp_floor must be positive");
+  return ba_impl(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only,
+                 disp_floor);
 }
 
 // frame_distance (src/droid.cpp:181-197)
@@ -249,9 +317,11 @@ class BACore {
     CHECK_INPUT(jj);
     poses_ = poses, disps_ = disps, intrinsics_ = intrinsics, disps_sens_ = disps_sens, targets_ = targets, weights_ = weights;
     eta_ = eta.contiguous(), ii_ = ii, jj_ = jj;
+    raise_pending_eta_error();
     d_ = ba_dims(disps, eta_, ii, t0, t1);
+    check_eta_bounds(d_);
     lm_ = lm, ep_ = ep;
-    ws_ = workspace(d_, poses, &nbytes_);
+    ws_ = workspace(d_, poses, &nbytes_, 1);
     ready_ = true;
   }
 
@@ -264,12 +334,13 @@ class BACore {
     const bool direct = H.is_contiguous() && v.is_contiguous() && H.dim() == 2 && H.size(0) == n && H.size(1) == n && v.numel() == n;
     torch::Tensor Hh = direct ? H : torch::zeros({n, n}, H.options());
     torch::Tensor vh = direct ? v : torch::zeros({n}, v.options());
-    check(dba_bacore_hessian(poses_.data_ptr<float>(), disps_.data_ptr<float>(), intrinsics_.data_ptr<float>(),
+    check(dba_bacore_hessian_run(poses_.data_ptr<float>(), disps_.data_ptr<float>(), intrinsics_.data_ptr<float>(),
                              disps_sens_.data_ptr<float>(), targets_.data_ptr<float>(), weights_.data_ptr<float>(),
                              eta_.data_ptr<float>(), d_.eta_rows, ii_.data_ptr<int64_t>(), jj_.data_ptr<int64_t>(), d_.N, d_.B,
                              d_.ht, d_.wd, d_.t0, d_.t1, Hh.data_ptr<double>(), vh.data_ptr<double>(), ws_.data_ptr(), nbytes_,
-                             stream_of(poses_)),
+                             stream_of(poses_), /*prepared=*/2),
           "dba_bacore_hessian");
+    raise_pending_eta_error();   // (hessian synchronises the stream: the verdict of its own stage 0 is in)
     if (!direct) {   // the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
       H.copy_(Hh.slice(0, 0, H.size(0)).slice(1, 0, H.size(1)));
       v.copy_(vh.slice(0, 0, v.size(0)));
@@ -291,13 +362,13 @@ class BACore {
     const int P = d_.t1 - d_.t0;
     TORCH_CHECK(dxh.numel() >= 6 * P, "BACore.retract: dx must have ", 6 * P, " entries");
     torch::Tensor dx = torch::zeros({P, 6}, poses_.options());
-    torch::Tensor dz = torch::zeros({std::min(d_.B, P + d_.N), (int64_t)d_.ht * d_.wd}, poses_.options());
+    torch::Tensor dz = torch::empty({std::min(d_.B, P + d_.N), (int64_t)d_.ht * d_.wd}, poses_.options());
     check(dba_bacore_retract(poses_.data_ptr<float>(), disps_.data_ptr<float>(), ii_.data_ptr<int64_t>(), jj_.data_ptr<int64_t>(),
                              d_.N, d_.B, d_.ht, d_.wd, d_.t0, d_.t1, dxh.data_ptr<double>(), dx.data_ptr<float>(),
                              dz.data_ptr<float>(), ws_.data_ptr(), nbytes_, stream_of(poses_)),
           "dba_bacore_retract");
     dx_ = dx;
-    return {dx, dz};
+    return {dx, dz.narrow(0, 0, num_kx(d_, ii_))};
   }
 
  private:
@@ -315,6 +386,8 @@ PYBIND11_MODULE(_droid_backends_C, m) {
   m.def("version", [] { return std::string(dba_version()); });
   // bundle adjustment kernels (src/droid.cpp:299-302)
   m.def("ba", &ba, "bundle adjustment");
+  m.def("ba_clamped", &ba_clamped, "bundle adjustment + the caller's clamp of the inverse depths");
+  m.def("check_async_errors", &raise_pending_eta_error, "raises what an earlier asynchronous call found wrong on the device");
   m.def("frame_distance", &frame_distance, "frame_distance");
   m.def("projmap", &projmap, "projmap");
   m.def("depth_filter", &depth_filter, "depth_filter");

@@ -28,6 +28,9 @@ SYMBOLS = {
     "dba_ba_workspace_bytes": (c_size_t, [c_int] * 6),
     "dba_ba_get_layout": (c_int, [c_int] * 6 + [ctypes.POINTER(BaLayout)]),
     "dba_ba_prepare": (c_int, [_P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
+    "dba_ba_prepare_keyed": (c_int, [_P, _P] + [c_int] * 8 + [_P, c_size_t, _P]),
+    "dba_ba_workspace_init": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
+    "dba_ba_poll_eta_error": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dba_ba_linearize": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
     "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_ba_schur_select": (c_int, [c_int]),
@@ -48,6 +51,7 @@ SYMBOLS = {
     "dba_ba_run": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
                                                                          c_size_t, _P, c_int, c_int, c_float]),
     "dba_bacore_hessian": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P]),
+    "dba_bacore_hessian_run": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P, c_int]),
     "dba_bacore_retract": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
     "dba_bacore_optimize": (c_int, [_P, _P] + [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),
     "dba_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),

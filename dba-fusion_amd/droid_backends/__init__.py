@@ -69,25 +69,26 @@ def _ws(N, B, ht, wd, t0, t1, device):
 
 
 class _BaWorkspaces:
-    """One BA workspace per (device, window shape), kept across calls, and a note of which covisibility graph its index
-    tables were last prepared for.
+    """One BA workspace per (device, stream, window shape), kept across calls.
 
-    CovisibleGraph.update() runs droid_backends.ba several times on the SAME edge tensors (covisible_graph.py:229-236:
-    ii, jj = self.ii, self.jj) before the graph changes; the tables of stage 0 (dba_ba_prepare) depend on nothing but
-    (ii, jj, t0, t1, sizes), so a call that finds the workspace prepared for the very same tensor OBJECTS at the same
-    in-place version skips that launch (dba_ba_prepared).  Identity is checked through weak references -- an id() can only
-    be reused after its object died, which clears the note -- and `_version`, which every in-place write bumps.  A new
-    tensor (torch.cat in add_factors, boolean indexing in rm_factors, the cat with the inactive edges) is simply a miss.
+    The index tables of stage 0 depend on nothing but (ii, jj, t0, t1, sizes, Schur form), and CovisibleGraph.update() runs
+    droid_backends.ba on the same EDGE LIST many times before the graph changes -- but, with use_inactive=True (every update
+    of the frontend, dbaf_frontend.py:251,357,474-483), through NEW tensor objects each time (`torch.cat([self.ii_inac[m],
+    self.ii])`, covisible_graph.py:242-247).  So "the same graph" is decided on the device, on the contents: stage 0 keeps a
+    key of the edge list it built its tables for in the workspace, and a call whose edges compare equal leaves that launch
+    after ~2 us (dba_ba_run with prepared = 2; no host synchronisation on either outcome).  On top of that, a call that hands
+    over the very same tensor OBJECTS at the same in-place version (what update() does with use_inactive=False) does not
+    launch stage 0 at all (prepared = 1): identity through weak references -- an id() can only be reused after its object
+    died, which clears the note -- and `_version`, which every in-place write bumps.
     All calls are stream-ordered on the caller's current stream, like the reference's (one workspace is safe to reuse
     there); DBA_WS_CACHE=0 falls back to a fresh workspace and a full dba_ba per call."""
 
     def __init__(self):
         import os
         self.enabled = os.environ.get("DBA_WS_CACHE", "1") != "0"
-        self.ws = {}        # (device, dims) -> (tensor, nbytes)
-        self.graph = {}     # (device, dims) -> (ref(ii), version, ref(jj), version, schur form generation)
-        self.plan = {}      # (device, dims) -> which skyline-solver variant solved this graph last time (meta[7])
-        self.kx_count = {}  # (device, dims) -> |kx| of the graph the workspace is prepared for
+        self.ws = {}        # (device, stream, dims) -> (tensor, nbytes)
+        self.graph = {}     # key -> (ref(ii), version, ref(jj), version, schur form generation, eta rows it was checked with)
+        self.plan = {}      # key -> which skyline-solver variant solved this graph last time (meta[7])
         self.max_entries = 4
 
     def workspace(self, key, dims, device):
@@ -98,25 +99,26 @@ class _BaWorkspaces:
                 self.ws.pop(old)
                 self.graph.pop(old, None)
                 self.plan.pop(old, None)
-                self.kx_count.pop(old, None)
             ent = _ws(*dims, device)
+            # "no graph prepared yet": the key area stage 0 compares against must not be whatever the allocator left there
+            _lib.check(_lib.load().dba_ba_workspace_init(*dims, _ptr(ent[0]), ent[1], _stream()), "dba_ba_workspace_init")
             self.ws[key] = ent
         return ent
 
-    def prepared_for(self, key, ii, jj):
+    def prepared_for(self, key, ii, jj, eta_rows):
         g = self.graph.get(key)
         return (g is not None and g[0]() is ii and g[2]() is jj and g[1] == ii._version and g[3] == jj._version
-                and g[4] == _lib.schur_generation())
+                and g[4] == _lib.schur_generation() and g[5] == eta_rows)
 
-    def note(self, key, ii, jj):
+    def note(self, key, ii, jj, eta_rows):
         import weakref
-        self.graph[key] = (weakref.ref(ii), ii._version, weakref.ref(jj), jj._version, _lib.schur_generation())
+        self.graph[key] = (weakref.ref(ii), ii._version, weakref.ref(jj), jj._version, _lib.schur_generation(), eta_rows)
         self.plan.pop(key, None)
-        self.kx_count.pop(key, None)    # |kx| belongs to the graph the tables were prepared for
 
     def solver_hint(self, key, dims):
         """windows of 30-64 poses: which skyline-solver variant took this graph's structure in the previous call (meta[7] of
-        the workspace; ONE stream synchronisation per graph, at its second update) -> what dba_ba_prepared need not queue"""
+        the workspace; ONE stream synchronisation per graph, at its second update on the same tensor objects) -> what
+        dba_ba_prepared need not queue"""
         N, B, ht, wd, t0, t1 = dims
         if not (174 < 6 * (t1 - t0) <= 384):
             return 0
@@ -135,12 +137,11 @@ _BA_WS = _BaWorkspaces()
 
 def _num_kx(eta, ii, t0, t1, ht, wd):
     """|kx| = |unique(arange(t0,t1) U ii)| without a device sync when eta has one row per kx entry
-    (as DBA-Fusion always passes it, covisible_graph.py:330)."""
+    (as DBA-Fusion always passes it, covisible_graph.py:330; the row count is verified on the device, see _ba)."""
     rows = eta.numel() // (ht * wd)
     if rows > 1:
         return rows
-    ts = torch.arange(t0, t1, device=ii.device, dtype=ii.dtype)
-    return int(torch.unique(torch.cat([ts, ii])).numel())
+    return _num_kx_exact(ii, t0, t1)
 
 
 def _num_kx_exact(ii, t0, t1):
@@ -148,10 +149,30 @@ def _num_kx_exact(ii, t0, t1):
     return int(torch.unique(torch.cat([ts, ii])).numel())
 
 
+_ETA_CHECK_SYNC = _os.environ.get("DBA_ETA_CHECK", "") == "sync"
+
+
+def _raise_pending_eta_error():
+    """eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): one row, or one per kx entry.  The
+    reference raises a broadcast error in the call itself (its torch::_unique synchronises the host anyway); here |kx| only
+    exists on the device, stage 0 compares, and a mismatch surfaces at the NEXT call of this module (or at an explicit
+    droid_backends.check_async_errors() after a synchronisation) -- the price of a call that never stops the host.
+    DBA_ETA_CHECK=sync restores the synchronous check."""
+    r, k = ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().dba_ba_poll_eta_error(ctypes.byref(r), ctypes.byref(k)):
+        raise RuntimeError("an earlier droid_backends.ba / BACore.hessian call was given eta with %d rows; it must have 1 or "
+                           "|unique(arange(t0,t1) U ii)| = %d rows (droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C "
+                           "row by row); that call reused the last eta row for the missing ones" % (r.value, k.value))
+
+
+def check_async_errors():
+    """raises what an earlier asynchronous call of this module found wrong on the device (today: the eta row count); only
+    complete after the stream was synchronised"""
+    _raise_pending_eta_error()
+
+
 def _check_eta_rows(eta_rows, ii, t0, t1):
-    """eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): one row, or one per kx entry.
-    The reference raises a broadcast error otherwise; here the count is checked on the host when it is cheap to know
-    (t1 - t0 >= all source frames is the common case: kx = arange(min(ii, t0), t1)) and bounded otherwise."""
+    """the bounds on the row count that are known without the device (the exact count is checked by stage 0)"""
     if eta_rows == 1:
         return
     P, N = max(t1 - t0, 0), int(ii.shape[0])
@@ -188,9 +209,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
 def ba_clamped(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
                motion_only, disp_floor=0.001):
     """`ba(...)` followed by the caller's `disps.clamp_(min=disp_floor)` (DepthVideo.ba, dbaf/depth_video.py:559-560) in ONE
-    call: the clamp rides in the call's last launch instead of being an elementwise launch of its own over the whole
-    buffer (dba_ba_run; same state bit for bit, see include/dba_hip.h).  Not a reference binding: an integration that
-    wants it replaces the two statements of depth_video.py by this one call."""
+    call: the clamp rides in the call's last launch instead of being an elementwise launch of its own -- over the whole
+    buffer, like the caller's (frames outside kx and motion_only calls included: the caller rescales depths between BA
+    calls, dbaf_frontend.py:570,814), so the state is the same bit for bit (dba_ba_run, include/dba_hip.h).  Not a
+    reference binding: an integration that wants it replaces the two statements of depth_video.py by this one call."""
     if not (float(disp_floor) > 0.0):
         raise RuntimeError("ba_clamped: disp_floor must be positive")
     return _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
@@ -202,6 +224,7 @@ def _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0,
     eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
     t0, t1 = int(t0), int(t1)
     P = t1 - t0
+    _raise_pending_eta_error()
     _check_eta_rows(eta_rows, ii, t0, t1)
     if int(iterations) <= 0:   # the reference returns two undefined tensors and touches nothing (:1437, :1511)
         return [None, None]
@@ -210,40 +233,32 @@ def _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0,
     if _BA_WS.enabled:
         key = (poses.device, torch.cuda.current_stream().cuda_stream, dims)
         ws, nbytes = _BA_WS.workspace(key, dims, poses.device)
-        prepared = _BA_WS.prepared_for(key, ii, jj)
-        hint = _BA_WS.solver_hint(key, dims) if prepared else 0
-        fn = (lambda *a: lib.dba_ba_prepared(*a, hint)) if prepared else lib.dba_ba
+        # the same tensor objects as last time: stage 0 is not even launched; anything else: stage 0 compares the edge list
+        # with the key in the workspace and leaves at once when it is the graph the tables were built for
+        prepared = 1 if _BA_WS.prepared_for(key, ii, jj, eta_rows) else 2
+        hint = _BA_WS.solver_hint(key, dims) if prepared == 1 else 0
     else:
-        key, prepared, hint = None, False, 0
+        key, prepared, hint = None, 0, 0
         ws, nbytes = _ws(*dims, poses.device)
-        fn = lib.dba_ba
-    if disp_floor > 0.0:
-        fn = lambda *a: lib.dba_ba_run(*a, int(bool(prepared)), int(hint), disp_floor)  # noqa: E731
-    dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
-    Mmax = min(B, P + N)
-    dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
-    if eta_rows > 1:
-        # eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): the reference raises on any
-        # other row count, the kernels would silently reuse the last row.  |kx| lives on the device; it is counted once per
-        # graph (a stream synchronisation whenever the edge list is new, which is also when the reference's own .item()
-        # calls synchronise) and remembered with the prepared tables.
-        nk = _BA_WS.kx_count.get(key) if prepared else None
-        if nk is None:
-            nk = _num_kx_exact(ii, t0, t1)
+    if _ETA_CHECK_SYNC and eta_rows > 1 and prepared != 1:
+        nk = _num_kx_exact(ii, t0, t1)
         if eta_rows != nk:
             raise RuntimeError("eta has %d rows; it must have 1 or |unique(arange(t0,t1) U ii)| = %d rows "
                                "(droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C row by row)" % (eta_rows, nk))
-    rc = fn(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
-            _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1,
-            int(iterations), float(lm), float(ep), int(bool(motion_only)), _ptr(dx),
-            _ptr(dz_full), _ptr(ws), nbytes, _stream())
+    dx = torch.empty(P, 6, dtype=torch.float32, device=poses.device)       # fully written by the last iteration
+    Mmax = min(B, P + N)
+    dz_full = torch.empty(Mmax, ht * wd, dtype=torch.float32, device=poses.device)  # rows [0,|kx|) written
+    rc = lib.dba_ba_run(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(disps_sens), _ptr(targets),
+                        _ptr(weights), _ptr(eta), eta_rows, _ptr(ii), _ptr(jj), N, B, ht, wd, t0, t1,
+                        int(iterations), float(lm), float(ep), int(bool(motion_only)), _ptr(dx),
+                        _ptr(dz_full), _ptr(ws), nbytes, _stream(), prepared, int(hint), float(disp_floor))
     _lib.check(rc, "dba_ba")
-    if key is not None and not prepared:
-        _BA_WS.note(key, ii, jj)
-    if key is not None and eta_rows > 1:
-        _BA_WS.kx_count[key] = nk       # (after note(): a new graph dropped the previous graph's count)
+    if key is not None and prepared != 1:
+        _BA_WS.note(key, ii, jj, eta_rows)
     if motion_only:
         return [dx, None]
+    # (eta with one row per kx entry: that IS the count; a single-row eta needs the count from the device, which
+    # synchronises -- as the reference's own torch::_unique does in every call)
     return [dx, dz_full[:_num_kx(eta, ii, t0, t1, ht, wd)]]
 
 
@@ -316,7 +331,18 @@ class BACore:
         self.t0, self.t1, self.lm, self.ep = int(t0), int(t1), float(lm), float(ep)
         self.N, self.B, self.ht, self.wd, self.eta_rows = N, B, ht, wd, eta_rows
         self.P = self.t1 - self.t0
-        self.ws, self.nbytes = _ws(N, B, ht, wd, self.t0, self.t1, poses.device)
+        _raise_pending_eta_error()
+        _check_eta_rows(eta_rows, ii, self.t0, self.t1)
+        # one workspace per window shape, kept across the BACore objects DepthVideo.ba creates per call (its own pool:
+        # nothing droid_backends.ba does to its workspaces can fall between hessian and retract); stage 0 recognises an
+        # unchanged edge list by its key, so the second hessian() of an update finds its tables in place
+        if _BA_WS.enabled:
+            key = ("bacore", poses.device, torch.cuda.current_stream().cuda_stream, self._dims())
+            self.ws, self.nbytes = _BA_WS.workspace(key, self._dims(), poses.device)
+            self._prepared = 2
+        else:
+            self.ws, self.nbytes = _ws(N, B, ht, wd, self.t0, self.t1, poses.device)
+            self._prepared = 0
         self.dx = None
         # pinned host staging for the hand-off to the factor-graph side: the reduced system leaves
         # the device with ONE DMA per hessian() call and is only then copied into the caller's pageable H, v
@@ -337,11 +363,13 @@ class BACore:
                   and tuple(H.shape) == (n, n) and tuple(v.shape) == (n,))
         Hh = H if direct else self._stage[:n * n].view(n, n)   # DMA target: the caller's own pinned buffers, or ours
         vh = v if direct else self._stage[n * n:]
-        rc = _lib.load().dba_bacore_hessian(
+        rc = _lib.load().dba_bacore_hessian_run(
             _ptr(self.poses), _ptr(self.disps), _ptr(self.intrinsics), _ptr(self.disps_sens), _ptr(self.targets),
             _ptr(self.weights), _ptr(self.eta), self.eta_rows, _ptr(self.ii), _ptr(self.jj), *self._dims(),
-            ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream())
+            ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream(),
+            self._prepared)
         _lib.check(rc, "dba_bacore_hessian")
+        _raise_pending_eta_error()    # (hessian() synchronises the stream: the verdict of its own stage 0 is in)
         if not direct:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
             H.copy_(Hh[:H.shape[0], :H.shape[1]])
             v.copy_(vh[:v.shape[0]])

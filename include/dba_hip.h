@@ -75,6 +75,22 @@ int dba_ba_get_layout(int N, int B, int ht, int wd, int t0, int t1, dba_ba_layou
  * ba_cuda :1416-1424, accum_cuda :993-1043 and schur_block :1307-1347). */
 int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
                    void *ws, size_t ws_bytes, dba_stream_t stream);
+/* Stage 0 keyed on the CONTENTS of the edge list.  The reference's caller hands droid_backends.ba new ii / jj tensors with
+ * the same edges on every update (torch.cat with the inactive edges, dbaf/covisible_graph.py:242-247), so "same graph as
+ * last time" cannot be decided on tensor identity.  Stage 0 leaves a key in the workspace (N, B, t0, t1, Schur form, ii, jj);
+ * check != 0: the launch compares the call's edge list with that key on the device and returns at once when the tables
+ * are those of this graph already (no host synchronisation either way).  check != 0 needs a workspace whose key area is
+ * valid: one that went through dba_ba_workspace_init (fresh memory) or an earlier stage 0.
+ * eta_rows > 1: the number of rows of the call's eta, which must equal |kx| (droid_kernels.cu:1476 adds eta.view(-1, HW) to
+ * the |kx| rows of C; the reference raises a broadcast error otherwise).  |kx| only exists on the device, so a mismatch is
+ * recorded in pinned host memory and reported by dba_ba_poll_eta_error (the kernels then reuse the last eta row). */
+int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
+                         int check, void *ws, size_t ws_bytes, dba_stream_t stream);
+/* marks a freshly allocated workspace as "no graph prepared" (clears meta and the key header; asynchronous on `stream`) */
+int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
+/* 1 (and the two counts) if a stage 0 that has COMPLETED since the last poll saw eta_rows != |kx|, else 0; clears the record.
+ * Host memory only: no synchronisation.  The adapters poll at the top of every ba call and raise for the earlier one. */
+int dba_ba_poll_eta_error(int *eta_rows, int *num_kx);
 
 /* stage 1: fused per-source-frame linearisation (projective_transform_kernel :220-468 +
  * accum_kernel :899-919 + C/w/Q assembly :1474-1478); also clears H, b.  alpha = 0.05 for
@@ -181,17 +197,28 @@ int dba_ba_prepared(float *poses, float *disps, const float *intrinsics, const f
  * the queue was a net for, a partner workgroup more than a second late at the hand-shake, then gives a failed solve, i.e. a
  * zero update, instead of a slower correct one). */
 
-/* dba_ba / dba_ba_prepared (prepared != 0) with the caller's next statement taken along: DepthVideo.ba clamps the inverse
+/* dba_ba (prepared = 0) / dba_ba_prepared (prepared = 1) / stage 0 decided on the device by the graph key (prepared = 2, see
+ * dba_ba_prepare_keyed; solver_hint is ignored) with the caller's next statement taken along: DepthVideo.ba clamps the inverse
  * depths right after droid_backends.ba returns (`self.disps.clamp_(min=0.001)`, dbaf/depth_video.py:560), a launch of its
- * own over the whole buffer.  disp_floor > 0: the LAST iteration's update writes max(d, disp_floor) (torch.clamp's select: a
- * NaN stays a NaN) for the frames it updates -- the same state, bit for bit, whenever the frames this call does not update
- * are at or above the floor already (they are: each was clamped after the call that updated it); earlier iterations and the
+ * own over the whole buffer.  disp_floor > 0: the LAST launch of the call writes max(d, disp_floor) (torch.clamp's select: a
+ * NaN stays a NaN) for the frames it updates and applies the same floor to every other frame of the buffer (also when
+ * motion_only leaves the depths alone): the same state, bit for bit, as the call followed by the caller's clamp over the
+ * whole buffer -- the reference's caller rescales inverse depths between BA calls (dbaf_frontend.py:570,814), so frames
+ * outside kx can be below the floor as well.  Earlier iterations and the
  * returned dz are untouched, exactly as when the clamp follows the call.  disp_floor = 0: dba_ba / dba_ba_prepared. */
 int dba_ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
                const float *targets, const float *weights, const float *eta, int eta_rows,
                const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1,
                int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
                void *ws, size_t ws_bytes, dba_stream_t stream, int prepared, int solver_hint, float disp_floor);
+
+/* dba_bacore_hessian with stage 0 as in dba_ba_run (prepared = 0 | 1 | 2): BACore.hessian runs twice per update on one
+ * graph (dbaf/depth_video.py:527), the second call finds the tables in place */
+int dba_bacore_hessian_run(const float *poses, const float *disps, const float *intrinsics,
+                           const float *disps_sens, const float *targets, const float *weights,
+                           const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N,
+                           int B, int ht, int wd, int t0, int t1, double *H_host, double *v_host,
+                           void *ws, size_t ws_bytes, dba_stream_t stream, int prepared);
 
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
  * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */
@@ -247,8 +274,9 @@ int dba_corr_sheared_plane_elems(int h1, int w1);
  * maps: pixel = y1 * w1 + x1.  Returns the tile width (16) for the tiled order, 0 for the row-major one (DBA_SHEAR_TILES=0
  * keeps every shape row-major). */
 int dba_corr_sheared_tiled(int h1, int w1);
-/* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 1 = streaming
- * (64-pixel-wide rows only, falls back to resident otherwise), 2 = resident.  Process-wide; results are bit-identical. */
+/* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 2 = resident
+ * (any shape), 5 = rows over tiles (tiled planes only, falls back to resident otherwise).  Process-wide; results are
+ * bit-identical.  (1, 3, 4 were round 4's streaming / pair / band forms, which no longer ship: DBA_ERR_ARG.) */
 int dba_corr_lookup_select(int kernel);
 /* Measurement hook: the next dba_corr_lookup_pyramid_sheared call of this thread attaches the two hipEvent_t to its
  * kernel dispatch (hipExtLaunchKernelGGL: the dispatch's own start / end timestamps, no marker packets in the stream),

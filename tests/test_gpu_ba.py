@@ -119,6 +119,31 @@ def test_ba_clamped_is_ba_followed_by_the_callers_clamp(name, itrs, motion_only)
         droid_backends.ba_clamped(*args(b), disp_floor=0.0)
 
 
+@pytest.mark.parametrize("motion_only", [False, True])
+def test_ba_clamped_floors_the_whole_buffer_like_the_callers_clamp(motion_only):
+    """`self.disps.clamp_(min=0.001)` is over the WHOLE buffer, and the reference's caller rescales inverse depths between BA
+    calls (dbaf_frontend.py:570,814 `disps[i] /= s`), so frames outside kx -- and every frame of a motion_only call -- can sit
+    below the floor when ba is entered: ba_clamped floors them in its last launch too (NaNs stay NaNs, as with clamp_)"""
+    import droid_backends
+    W = syn.make_window(*syn.graph_banded(6, 2), 6, 12, 16, seed=5, buffer=11)     # frames 6..10 of the buffer are in no edge
+    assert W.B > W.M
+    a, b = to_dev(W), to_dev(W)
+    floor = float(np.median(W.disps))
+    for d in (a, b):
+        d["disps"][W.B - 2] *= 0.01            # a frame outside kx far below the floor
+        d["disps"][W.B - 1, 0, 0] = float("nan")
+        d["disps"][1] *= 0.5                   # ... and one inside
+    args = lambda d: (d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"],  # noqa: E731
+                      d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, motion_only)
+    droid_backends.ba(*args(a))
+    a["disps"].clamp_(min=floor)
+    droid_backends.ba_clamped(*args(b), disp_floor=floor)
+    torch.cuda.synchronize()
+    assert torch.equal(a["poses"], b["poses"])
+    assert torch.equal(a["disps"].view(torch.int32), b["disps"].view(torch.int32))     # (bit patterns: the NaN included)
+    assert torch.isnan(b["disps"][W.B - 1, 0, 0]) and float(b["disps"][W.B - 2].min()) == floor
+
+
 def _bacore_system(W, form):
     """the Schur-reduced camera system of W as BACore.hessian hands it to the host, with the given Schur kernel form"""
     import droid_backends
@@ -340,20 +365,146 @@ def test_ba_eta_broadcast_row():
 
 def test_ba_rejects_an_eta_with_the_wrong_number_of_rows():
     """1 < rows != |kx|: the reference's eta.view(-1, HW) would fail to broadcast against C (:1476); the kernels would
-    silently reuse the last row -- the adapter counts |kx| once per graph and raises"""
+    silently reuse the last row.  |kx| only exists on the device: stage 0 compares and records the mismatch in pinned
+    memory, and the module raises at its next call (or at check_async_errors() after a synchronisation) -- the call itself
+    never stops the host.  The graph is the same in every call here, so the check also runs on the early-out path."""
     import droid_backends
     W = syn.window_tiny_b(85)
     d = to_dev(W)
     assert W.M > 2
+    torch.cuda.synchronize()
+    droid_backends.check_async_errors()
+    args = lambda eta: (d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], eta, d["ii"],  # noqa: E731
+                        d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
     for rows in (2, W.M - 1, W.M + 1):
         eta = torch.full((rows, W.h, W.w), 3e-7, device="cuda")
-        with pytest.raises(RuntimeError):
-            droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], eta, d["ii"],
-                              d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+        if rows > (W.t1 - W.t0) + W.N:          # more rows than kx can have entries: known without the device
+            with pytest.raises(RuntimeError):
+                droid_backends.ba(*args(eta))
+            continue
+        droid_backends.ba(*args(eta))            # (asynchronous: returns; the last eta row was reused)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="eta with %d rows.*= %d rows" % (rows, W.M)):
+            droid_backends.check_async_errors()
+        droid_backends.check_async_errors()      # reported once
+        droid_backends.ba(*args(eta))
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="earlier"):     # ... or by whatever call comes next
+            droid_backends.ba(*args(d["eta"]))
     p0 = d["poses"].clone()
-    droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"],
-                      d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+    droid_backends.ba(*args(d["eta"]))
+    torch.cuda.synchronize()
+    droid_backends.check_async_errors()
     assert not torch.equal(d["poses"], p0)
+
+
+def test_ba_never_synchronises_the_host():
+    """droid_backends.ba on NEW edge tensors in every call (what CovisibleGraph.update hands over with use_inactive=True:
+    torch.cat creates them, covisible_graph.py:242-247) must not stop the host: torch's sync debug mode raises on any
+    synchronising torch call inside, and the library's own calls are checked by timing the host against a long kernel
+    queued in front"""
+    import time
+    import droid_backends
+    W = syn.window_25_96(3)
+    d = to_dev(W)
+    n_in = W.N // 3
+    ii_in, jj_in, ii_ac, jj_ac = d["ii"][:n_in].clone(), d["jj"][:n_in].clone(), d["ii"][n_in:].clone(), d["jj"][n_in:].clone()
+
+    def call():
+        ii = torch.cat([ii_in, ii_ac], 0)       # new objects, same contents
+        jj = torch.cat([jj_in, jj_ac], 0)
+        return droid_backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"],
+                                 ii, jj, W.t0, W.t1, 2, W.lm, W.ep, False)
+
+    call()
+    torch.cuda.synchronize()
+    big = torch.empty(1 << 28, device="cuda")    # 1 GiB fills: ~10 ms of queued work in front of the calls
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(40):
+            big.fill_(1.0)
+        t = time.perf_counter()
+        for _ in range(5):
+            call()
+        host = time.perf_counter() - t
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    t = time.perf_counter()
+    torch.cuda.synchronize()
+    drained = time.perf_counter() - t
+    assert drained > 2 * host, "the host waited for the device inside droid_backends.ba (%.1f ms host, %.1f ms left)" % (
+        1e3 * host, 1e3 * drained)
+
+
+def test_ba_stage0_recognises_the_graph_by_its_contents():
+    """the key stage 0 leaves in the workspace: new tensor objects with the same edges leave stage 0 at once, a changed edge,
+    another window, another Schur form or a re-ordered list rebuild -- every call gives what a cold call gives, and the
+    skip is visible in the workspace (meta[7], which only a rebuild resets)"""
+    import ctypes
+    import droid_backends
+    from droid_backends import _BA_WS
+    from dbaf_amd import _lib
+    W = syn.window_tiny_b(83)
+
+    def cold(Wx):
+        saved = _BA_WS.enabled
+        _BA_WS.enabled = False
+        try:
+            return _run_gpu_ba(Wx)
+        finally:
+            _BA_WS.enabled = saved
+
+    def warm(Wx):
+        dd = to_dev(Wx)                            # new tensors for everything, ii / jj included
+        droid_backends.ba(dd["poses"], dd["disps"], dd["intrinsics"], dd["disps_sens"], dd["target"], dd["weight"], dd["eta"],
+                          dd["ii"], dd["jj"], Wx.t0, Wx.t1, 2, Wx.lm, Wx.ep, False)
+        return dd["poses"].cpu().numpy(), dd["disps"].cpu().numpy()
+
+    def meta7():
+        dims = (W.N, W.B, W.h, W.w, W.t0, W.t1)
+        key = [k for k in _BA_WS.ws if k[-1] == dims and k[0] != "bacore"][0]
+        lay = _lib.BaLayout()
+        _lib.load().dba_ba_get_layout(*dims, ctypes.byref(lay))
+        return _BA_WS.ws[key][0][lay.meta + 28:lay.meta + 32].view(torch.int32)
+
+    ref = cold(W)
+    for rep in range(3):
+        p, z = warm(W)
+        assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1]), rep
+        if rep == 0:
+            meta7().fill_(77)                      # a mark a rebuild would erase
+        else:
+            assert int(meta7().item()) == 77, "stage 0 rebuilt the tables of an unchanged graph"
+    W2 = syn.window_tiny_b(83)
+    W2.jj = W2.jj.copy()
+    W2.jj[3] = 5 if W2.jj[3] != 5 else 4           # one edge re-targeted: same shapes, same workspace
+    ref2 = cold(W2)
+    p, z = warm(W2)
+    assert np.array_equal(p, ref2[0]) and np.array_equal(z, ref2[1])
+    assert int(meta7().item()) != 77, "stage 0 kept the tables of another graph"
+    p, z = warm(W)                                 # ... and back
+    assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1])
+    W3 = syn.window_tiny_b(83)                     # the same edges in another order: other tables (edge ids), a rebuild
+    perm = np.arange(W.N)[::-1].copy()
+    for name in ("ii", "jj", "target", "weight"):
+        setattr(W3, name, np.ascontiguousarray(getattr(W, name)[perm]))
+    ref3 = cold(W3)
+    meta7().fill_(77)
+    p, z = warm(W3)
+    assert int(meta7().item()) != 77
+    np.testing.assert_allclose(p, ref3[0], rtol=0, atol=0)
+    assert np.array_equal(z, ref3[1])
+    lib = _lib.load()                               # another Schur form needs other tables
+    try:
+        p, z = warm(W)
+        meta7().fill_(77)
+        lib.dba_ba_schur_select(2)
+        refs = cold(W)
+        p, z = warm(W)
+        assert int(meta7().item()) != 77
+        assert np.array_equal(p, refs[0]) and np.array_equal(z, refs[1])
+    finally:
+        lib.dba_ba_schur_select(0)
 
 
 def test_ba_rejects_cpu_and_noncontiguous():
@@ -397,9 +548,10 @@ def test_ba_with_update_and_linearisation_in_separate_launches():
 
 
 def test_ba_prepared_workspace_is_reused_only_for_the_same_graph():
-    """droid_backends.ba keeps one workspace per window shape and skips stage 0 when it finds it prepared for the very same
-    edge tensors (CovisibleGraph.update calls ba repeatedly on self.ii / self.jj): repeated calls, an in-place edit of jj,
-    another graph of the same shape in between, and fresh tensors with the same contents all give what a cold call gives"""
+    """droid_backends.ba keeps one workspace per window shape and does not launch stage 0 when it finds it prepared for the
+    very same edge tensor OBJECTS (CovisibleGraph.update with use_inactive=False calls ba on self.ii / self.jj): repeated
+    calls, an in-place edit of jj, another graph of the same shape in between, and fresh tensors with the same contents all
+    give what a cold call gives"""
     import droid_backends
     from droid_backends import _BA_WS
     assert _BA_WS.enabled
@@ -426,25 +578,25 @@ def test_ba_prepared_workspace_is_reused_only_for_the_same_graph():
         p, z = state(dd)
         assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1]), rep
     key = [k for k in _BA_WS.graph if k[-1] == (W.N, W.B, W.h, W.w, W.t0, W.t1)]
-    assert key and _BA_WS.prepared_for(key[0], ii, jj)
+    assert key and _BA_WS.prepared_for(key[0], ii, jj, W.M)
     # a different graph of the same shape (same N, so the same workspace): edge 3 re-targeted, in place (version bump)
     W2 = syn.window_tiny_b(81)
     W2.jj = W2.jj.copy()
     W2.jj[3] = 5 if W2.jj[3] != 5 else 4
     ref2 = cold(W2)
     jj[3] = int(W2.jj[3])
-    assert not _BA_WS.prepared_for(key[0], ii, jj)
+    assert not _BA_WS.prepared_for(key[0], ii, jj, W.M)
     dd = to_dev(W2)
     dd["ii"], dd["jj"] = ii, jj
     droid_backends.ba(*args(dd))
     p, z = state(dd)
     assert np.array_equal(p, ref2[0]) and np.array_equal(z, ref2[1])
-    # fresh tensors holding the first graph again: a miss, the tables are rebuilt
+    # fresh tensors holding the first graph again: not the noted objects; stage 0 decides by the key (here: a rebuild)
     dd = to_dev(W)
     droid_backends.ba(*args(dd))
     p, z = state(dd)
     assert np.array_equal(p, ref[0]) and np.array_equal(z, ref[1])
-    assert not _BA_WS.prepared_for(key[0], ii, jj) and _BA_WS.prepared_for(key[0], dd["ii"], dd["jj"])
+    assert not _BA_WS.prepared_for(key[0], ii, jj, W.M) and _BA_WS.prepared_for(key[0], dd["ii"], dd["jj"], W.M)
 
 
 def test_ba_solver_plan_of_a_64_pose_window_is_learnt_from_the_first_solve():

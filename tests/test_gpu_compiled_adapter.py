@@ -37,7 +37,19 @@ def test_compiled_ba_equals_the_ctypes_adapter_bit_for_bit_in_deterministic_mode
             d = to_dev(W)
             r = fn(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
                    W.t0, W.t1, 2, W.lm, W.ep, False)
-            outs.append((d["poses"].clone(), d["disps"].clone(), r[0].clone(), r[1][:W.M].clone()))
+            assert tuple(r[1].shape) == (W.M, W.h * W.w)      # [|kx|, ht*wd], the reference's shape, from both
+            outs.append((d["poses"].clone(), d["disps"].clone(), r[0].clone(), r[1].clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        # ... and ba_clamped: the clamp over the whole buffer in the last launch
+        outs = []
+        floor = float(np.median(W.disps))
+        for fn in (db.ba_clamped, C.ba_clamped):
+            d = to_dev(W)
+            fn(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+               W.t0, W.t1, 2, W.lm, W.ep, False, floor)
+            assert float(d["disps"].min()) >= floor
+            outs.append((d["poses"].clone(), d["disps"].clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
         # motion-only: no depth update; iterations <= 0: nothing touched
@@ -103,6 +115,19 @@ def test_compiled_error_behaviour():
         C.frame_distance(d["poses"].t().contiguous().t(), d["disps"], d["intrinsics"], d["ii"], d["jj"], 0.3)
     with pytest.raises(RuntimeError):   # host tensor: no CPU path
         C.iproj(d["poses"].cpu(), d["disps"], d["intrinsics"])
+    # eta with a row count that is neither 1 nor |kx|: found by stage 0 on the device, raised by the module's next call
+    torch.cuda.synchronize()
+    C.check_async_errors()
+    assert W.M > 2
+    eta = torch.full((W.M - 1, W.h, W.w), 3e-7, device="cuda")
+    C.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], eta, d["ii"], d["jj"], W.t0, W.t1, 1,
+         W.lm, W.ep, False)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="eta with %d rows" % (W.M - 1)):
+        C.check_async_errors()
+    with pytest.raises(RuntimeError):   # more rows than kx can have: known on the host
+        C.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"],
+             torch.zeros(W.t1 - W.t0 + W.N + 1, W.h, W.w, device="cuda"), d["ii"], d["jj"], W.t0, W.t1, 1, W.lm, W.ep, False)
     with pytest.raises(RuntimeError):   # BACore.hessian wants CPU float64
         core = C.BACore()
         core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],

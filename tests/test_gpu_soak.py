@@ -45,7 +45,7 @@ def test_300_updates_with_graph_churn():
     CorrBlock.default_capacity, cap_before = 32, CorrBlock.default_capacity
     # (caches of earlier tests hold memory that this run would release: start from empty ones)
     _SHADOWS.clear()
-    for dct in (_BA_WS.ws, _BA_WS.graph, _BA_WS.plan, _BA_WS.kx_count):
+    for dct in (_BA_WS.ws, _BA_WS.graph, _BA_WS.plan):
         dct.clear()
     torch.cuda.empty_cache()
     try:
