@@ -160,6 +160,7 @@ def _raise_pending_eta_error():
     DBA_ETA_CHECK=sync restores the synchronous check."""
     r, k = ctypes.c_int(0), ctypes.c_int(0)
     if _lib.load().dba_ba_poll_eta_error(ctypes.byref(r), ctypes.byref(k)):
+        _BA_WS.graph.clear()   # (whichever note remembered that row count as checked must not skip stage 0 with it again)
         raise RuntimeError("an earlier droid_backends.ba / BACore.hessian call was given eta with %d rows; it must have 1 or "
                            "|unique(arange(t0,t1) U ii)| = %d rows (droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C "
                            "row by row); that call reused the last eta row for the missing ones" % (r.value, k.value))
