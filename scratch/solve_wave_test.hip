@@ -1,0 +1,86 @@
+// scratch: correctness + timing of the one-wave window solver (csrc/ba_solve_wave.hip) vs host Cholesky and the tile kernel
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+#define PROFILE_SOLVE 1
+namespace dba { long long *g_tile_prof; }
+#include "../dba-fusion_amd/csrc/ba_solve_tile.hip"
+#include "ba_solve_wave_experiment.hip"
+namespace dba { void set_last_error(const char*, hipError_t) {} }
+static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
+  for (int j = 0; j < n; j++) {
+    double d = A[j*n+j]; for (int k = 0; k < j; k++) d -= A[j*n+k]*A[j*n+k];
+    if (!(d > 0)) return false; d = std::sqrt(d); A[j*n+j] = d;
+    for (int i = j+1; i < n; i++) { double s = A[i*n+j]; for (int k = 0; k < j; k++) s -= A[i*n+k]*A[j*n+k]; A[i*n+j] = s/d; }
+  }
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= A[i*n+k]*b[k]; b[i] = s/A[i*n+i]; }
+  for (int i = n-1; i >= 0; i--) { double s = b[i]; for (int k = i+1; k < n; k++) s -= A[k*n+i]*b[k]; b[i] = s/A[i*n+i]; }
+  x = b; return true;
+}
+static long long *g_wprof;
+// P poses, pose p coupled with p-w..p (+ one extra pair), spd: make one diagonal entry negative otherwise
+int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
+  const int n = 6 * P;
+  std::vector<double> H(n*n, 0.0), b(n); std::vector<int> fpose(P);
+  srand(P*131 + w*7 + 1);
+  auto rnd = [] { return ((rand() % 2001) - 1000) / 1000.0; };
+  for (int p = 0; p < P; p++) {
+    fpose[p] = p;
+    for (int q = 0; q <= p; q++) {
+      const bool on = (p - q <= w) || (p == ex_p && q == ex_q);
+      if (!on) continue;
+      if (q < fpose[p]) fpose[p] = q;
+      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
+        if (p == q && c > a) continue;
+        const double v = 0.3 * rnd();
+        H[(6*p+a)*n + 6*q+c] = v; H[(6*q+c)*n + 6*p+a] = v;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) { double s = 0; for (int j = 0; j < n; j++) s += std::fabs(H[i*n+j]); H[i*n+i] = spd ? s + 1.0 + (rand()%100)/50.0 : ((i == n/2) ? -1.0 : s + 1.0); b[i] = std::sin(i*1.3); }
+  const double lm = 1e-4, ep = 0.1;
+  std::vector<double> Hd = H; for (int i = 0; i < n; i++) Hd[i*n+i] += ep + lm*Hd[i*n+i];
+  std::vector<double> xr; bool ok = host_solve(Hd, b, n, xr);
+  // the device reads the lower triangle only: poison the upper one
+  std::vector<double> Hl = H; for (int i = 0; i < n; i++) for (int j = i+1; j < n; j++) Hl[i*n+j] = 1e300;
+  double *dH, *db; float* dx; int* meta; int *dfp;
+  hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64); hipMalloc(&dfp, P*4);
+  hipMemcpy(dH, Hl.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
+  hipMemcpy(dfp, fpose.data(), P*4, hipMemcpyHostToDevice); hipMemset(meta, 0, 64); hipMemset(dx, 0xff, n*4);
+  int rc = dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, 0, nullptr);
+  hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess || rc) { printf("P=%d launch error %s rc=%d\n", P, hipGetErrorString(e), rc); return 1; }
+  std::vector<float> x(n); int hm[8]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 32, hipMemcpyDeviceToHost);
+  if (!hm[3]) { printf("wave P=%2d w=%d extra=(%d,%d): NOT ADMITTED\n", P, w, ex_p, ex_q); return 0; }
+  double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
+  printf("wave P=%2d n=%3d w=%d extra=(%d,%d) spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", P, n, w, ex_p, ex_q, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
+  if (getenv("HARNESS_DUMP")) { for (int i = 0; i < n; i++) if (fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6) printf("    x[%3d] dev % .6e ref % .6e\n", i, x[i], ok ? xr[i] : 0.0); }
+  if (timeit) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    // full matrix for the tile kernel (it reads the lower triangle too, mirrors the diagonal tiles)
+    hipMemset(g_wprof, 0, 256);
+    for (int mode = 0; mode < 2; mode++) {
+      if (mode == 1 && !dba::ba_solve_tile_supported(n)) continue;
+      hipEventRecord(e0);
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, 0, g_wprof); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
+      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
+      if (mode == 0 && getenv("HARNESS_STEPS")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
+      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us: [wave 0] load+first panel %.2f factor %.2f | [wave 1] init+forward (behind wave 0) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100, hp[1]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
+    }
+  }
+  hipFree(dH); hipFree(db); hipFree(dx); hipFree(meta); hipFree(dfp);
+  return 0;
+}
+int main() {
+  hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048);
+  hipMalloc(&g_wprof, 256); hipMemset(g_wprof, 0, 256);
+  run(24, 4, true, true); run(24, 3, true, true); run(25, 4, true, true); run(24, 2, true, false); run(24, 1, true, false); run(24, 0, true, false);
+  run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
+  run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);
+  run(24, 5, true, true); run(24, 6, true, true); run(24, 7, true, false); run(24, 23, true, false);   // wider bands: NT = 4, then not admitted
+  run(24, 4, false, false); run(63, 4, false, false); run(8, 2, false, false);                          // not positive definite
+  run(24, 2, true, false, 20, 3); run(24, 2, true, false, 9, 5); run(24, 3, true, false, 23, 17);       // an extra coupling: arrow / inside the window
+  return 0;
+}
