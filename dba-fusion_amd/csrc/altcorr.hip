@@ -570,7 +570,7 @@ extern "C" int dba_altcorr_pyramid_forward(const void *fmap1, const void *const 
   if (B < 0 || S < 0 || H1 <= 0 || W1 <= 0 || C <= 0 || num_levels < 1 || num_levels > 8) return DBA_ERR_ARG;
   if ((long)B * S == 0) return DBA_OK;
   if ((long)B * S * num_levels > 65535) return DBA_ERR_UNSUPPORTED;
-  if (!fmap1 || !fmap2_levels || !coords || !corr) return DBA_ERR_ARG;
+  if (!fmap1 || !fmap2_levels || !coords || !corr || !ii || !jj) return DBA_ERR_ARG;
   if ((H1 >> (num_levels - 1)) < 1 || (W1 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
   AltLevels Lv;
   for (int l = 0; l < 8; l++) Lv.f2[l] = (l < num_levels) ? fmap2_levels[l] : nullptr;
@@ -591,7 +591,7 @@ extern "C" int dba_altcorr_pyramid_forward_f16maps(const void *fmap1, const void
   if ((long)H1 * W1 * C >= 2147483647L) return DBA_ERR_UNSUPPORTED;   // (a level's map is addressed with 32-bit offsets)
   if ((long)B * S == 0) return DBA_OK;
   if ((long)B * S * num_levels > 65535) return DBA_ERR_UNSUPPORTED;
-  if (!fmap1 || !fmap2_levels || !coords || !corr) return DBA_ERR_ARG;
+  if (!fmap1 || !fmap2_levels || !coords || !corr || !ii || !jj) return DBA_ERR_ARG;
   if ((H1 >> (num_levels - 1)) < 1 || (W1 >> (num_levels - 1)) < 1) return DBA_ERR_ARG;
   AltLevels Lv;
   for (int l = 0; l < 8; l++) Lv.f2[l] = (l < num_levels) ? fmap2_levels[l] : nullptr;

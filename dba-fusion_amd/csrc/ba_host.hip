@@ -557,6 +557,16 @@ int dba_bacore_hessian_run(const float *poses, const float *disps, const float *
   return DBA_OK;
 }
 
+// the externally solved update as a kernel ARGUMENT (up to 64 poses: 1.5 KB of the 4 KB an argument block may have): it reaches
+// the device with the launch itself -- no staging copy, no stream synchronisation before the host buffer may go away
+struct DxArg {
+  float v[384];
+};
+__global__ void ba_dx_from_arg_kernel(DxArg a, float *__restrict__ dx, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = a.v[i];
+}
+
 int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int N, int B, int ht,
                        int wd, int t0, int t1, const double *dx_host, float *dx_out, float *dz_out, void *ws,
                        size_t ws_bytes, dba_stream_t stream) {
@@ -564,7 +574,13 @@ int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int6
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int n = 6 * plan.P;
-  if (n > 0) {
+  if (n > 0 && n <= 384) {
+    if (!dx_host) return DBA_ERR_ARG;
+    DxArg a;
+    for (int i = 0; i < n; i++) a.v[i] = (float)dx_host[i];  // f64 -> f32 (:1929-1930)
+    hipLaunchKernelGGL(ba_dx_from_arg_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, a, plan.W.dx, n);
+    DBA_LAUNCH_CHECK();
+  } else if (n > 0) {
     if (!dx_host) return DBA_ERR_ARG;
     std::vector<float> dxf((size_t)n);
     for (int i = 0; i < n; i++) dxf[i] = (float)dx_host[i];  // f64 -> f32 (:1929-1930)

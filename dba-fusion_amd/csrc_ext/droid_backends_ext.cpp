@@ -172,7 +172,7 @@ torch::Tensor frame_distance(torch::Tensor poses, torch::Tensor disps, torch::Te
   CHECK_INPUT(ii);
   CHECK_INPUT(jj);
   const int N = (int)ii.size(0);
-  torch::Tensor dist = torch::zeros({N}, poses.options());
+  torch::Tensor dist = torch::empty({N}, poses.options());   // (every entry is written by its workgroup)
   check(dba_frame_distance(poses.data_ptr<float>(), disps.data_ptr<float>(), intrinsics.data_ptr<float>(), ii.data_ptr<int64_t>(),
                            jj.data_ptr<int64_t>(), N, (int)disps.size(1), (int)disps.size(2), beta, dist.data_ptr<float>(),
                            stream_of(poses)),

@@ -492,6 +492,11 @@ class AltCorrBlock:
                 and B * N * S * self.num_levels <= 65535:
             ii_ = torch.as_tensor(ii, device=cs.device).to(torch.int64).reshape(-1)
             jj_ = torch.as_tensor(jj, device=cs.device).to(torch.int64).reshape(-1)
+            # (the reference fails on its reshape when the index lists do not match the coordinates; this path would read
+            # out of bounds on the device.  The index VALUES are the caller's contract, as in the reference's gather.)
+            if ii_.numel() != N or jj_.numel() != N:
+                raise RuntimeError("AltCorrBlock: ii / jj must have one entry per edge (%d), got %d / %d"
+                                   % (N, ii_.numel(), jj_.numel()))
             if B > 1:   # frame index inside the flattened [B * F] maps
                 off = (torch.arange(B, device=cs.device) * F_)[:, None]
                 ii_, jj_ = (off + ii_[None]).reshape(-1), (off + jj_[None]).reshape(-1)

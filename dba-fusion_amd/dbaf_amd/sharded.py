@@ -343,13 +343,14 @@ class _FormPin:
         self.stages, self.window = stages, window
 
     def __enter__(self):
+        self.prev = 0
         if hasattr(self.stages, "select_schur_form"):
             w = self.window
-            self.stages.select_schur_form(w, len(w.ii_all), w.t1 - w.t0)
+            self.prev = self.stages.select_schur_form(w, len(w.ii_all), w.t1 - w.t0) or 0
 
     def __exit__(self, *exc):
         if hasattr(self.stages, "release_schur_form"):
-            self.stages.release_schur_form()
+            self.stages.release_schur_form(self.prev)
         return False
 
 
@@ -366,12 +367,15 @@ class HipStages:
         lib = _lib.load()
         if window.schur_form is None:
             window.schur_form = int(lib.dba_ba_schur_auto_form(int(n_edges), int(n_poses)))
+        prev = int(lib.dba_ba_schur_thread_form())           # whatever this thread had pinned before (usually nothing: 0)
         lib.dba_ba_schur_select_thread(window.schur_form)   # (a per-thread pin: cheap, and other callers keep their choice)
         self._form_pin = window.schur_form
+        return prev
 
-    def release_schur_form(self):
-        """the pin lasts for one sharded call: single-GPU calls of the same thread get the automatic choice back"""
-        _lib.load().dba_ba_schur_select_thread(0)
+    def release_schur_form(self, prev=0):
+        """the pin lasts for one sharded call: afterwards the thread has what it had before (the automatic choice, or a pin
+        the caller set with dba_ba_schur_select_thread)"""
+        _lib.load().dba_ba_schur_select_thread(int(prev))
 
     def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
         lib = _lib.load()

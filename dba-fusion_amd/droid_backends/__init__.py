@@ -34,9 +34,12 @@ compiled = None
 if _os.environ.get("DBA_ADAPTER", "") != "ctypes":
     try:
         from . import _droid_backends_C as compiled   # noqa: F401
-    except ImportError:
+    except ImportError as _e:
         if _os.environ.get("DBA_ADAPTER", "") == "compiled":
             raise
+        import warnings as _w   # once per process: the ctypes path serves everything, but nobody should find out by accident
+        _w.warn("droid_backends: the compiled adapter (_droid_backends_C, `make ext`) failed to import (%s); every call goes "
+                "through ctypes" % _e)
 ADAPTER = "compiled (pybind11) + ctypes policies" if compiled is not None else "ctypes"
 
 
@@ -398,9 +401,9 @@ class BACore:
         if dxh.numel() < 6 * self.P:
             raise RuntimeError("BACore.retract: dx must have %d entries" % (6 * self.P))
         dev = self.poses.device
-        dx = torch.zeros(self.P, 6, dtype=torch.float32, device=dev)
-        Mmax = min(self.B, self.P + self.N)
-        dz_full = torch.zeros(Mmax, self.ht * self.wd, dtype=torch.float32, device=dev)
+        dx = torch.empty(self.P, 6, dtype=torch.float32, device=dev)        # (both fully written: dx by the copy of the
+        Mmax = min(self.B, self.P + self.N)                                 #  workspace's slot, dz rows [0, |kx|) by the update)
+        dz_full = torch.empty(Mmax, self.ht * self.wd, dtype=torch.float32, device=dev)
         rc = _lib.load().dba_bacore_retract(_ptr(self.poses), _ptr(self.disps), _ptr(self.ii), _ptr(self.jj),
                                             *self._dims(), ctypes.c_void_p(dxh.data_ptr()), _ptr(dx),
                                             _ptr(dz_full), _ptr(self.ws), self.nbytes, _stream())
@@ -416,7 +419,7 @@ def frame_distance(poses, disps, intrinsics, ii, jj, beta):
         _check(x, nm, dt)
     N = int(ii.shape[0])
     _, ht, wd = disps.shape
-    dist = torch.zeros(N, dtype=torch.float32, device=poses.device)
+    dist = torch.empty(N, dtype=torch.float32, device=poses.device)     # (every entry is written by its workgroup)
     _lib.check(_lib.load().dba_frame_distance(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj), N,
                                               int(ht), int(wd), float(beta), _ptr(dist), _stream()),
                "dba_frame_distance")
@@ -663,7 +666,8 @@ class _VolumeShadows:
                 for s_ in set(m for m in mapping if m >= 0):
                     st.ref[s_] -= 1
                 if slots_new is None:
-                    return None                          # over budget: the direct kernel serves this tensor
+                    ent["uses"] = -(1 << 40)             # over budget: the direct kernel serves this tensor from now on (no
+                    return None                          # signature / match work, no D2H, at every later lookup)
                 src = torch.tensor(todo, dtype=torch.int32, device=volume.device)
                 dst = torch.tensor(slots_new, dtype=torch.int32, device=volume.device)
                 _lib.check(_lib.load().dba_corr_shear_level_slots(_ptr(volume), _ptr(st.store), _ptr(src), _ptr(dst),

@@ -229,7 +229,8 @@ int dba_bacore_hessian(const float *poses, const float *disps, const float *intr
                        size_t ws_bytes, dba_stream_t stream);
 
 /* BACore::retract: dx_host [6P] float64 (HOST) -> f32 on device, then stage 4 using the E, Q, w
- * cached by the last dba_bacore_hessian on the same workspace. */
+ * cached by the last dba_bacore_hessian on the same workspace.  Up to 64 poses the update travels as a kernel argument:
+ * dx_host is consumed before the call returns and nothing synchronises the stream. */
 int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int N, int B,
                        int ht, int wd, int t0, int t1, const double *dx_host, float *dx_out,
                        float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream);

@@ -69,7 +69,10 @@ def test_ba_matches_oracle(name):
         # update shrinks the depth the latter is the harsher scale, and the single worst pixel of the 25-KF window has moved
         # between 0.3e-4 and 1.06e-4 of it with every change of a summation order this round -- the fp32 oracle's own worst
         # pixel sits at 0.75e-4)
-        msg = check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps, ref32_disps=None, frac=0.9999)
+        # (the fp32-faithful oracle's state goes into the report -- |device - ref32| and ref32's own distance from the
+        # arbiter, depths and poses -- and widens nothing)
+        msg = check_state(poses, clamp(disps), r64["poses"], clamp(r64["disps"]), W.disps, ref32_disps=None, frac=0.9999,
+                          log32_disps=clamp(r32["disps"]), log32_poses=r32["poses"])
     else:
         # small fixtures (16x16, 24x32, 28x107 maps, 4-8 keyframes): the fp32-faithful oracle is itself 0.9e-4 / 2.0e-4
         # (tiny_a / KITTI shape) from the arbiter at its worst pixel; bound 1.5e-4 or 2 x the oracle's own deviation

@@ -192,9 +192,10 @@ def test_recorded_ba_calls_at_the_north_star_tolerance(dumps):
                           _t(b["eta"]), _t(b["ii"]), _t(b["jj"]), *args[9:])
         disps.clamp_(min=0.001)                                   # depth_video.py:560
         clamp = lambda a: np.maximum(a, 0.001)                    # noqa: E731
-        # the recorded outputs are the reference's fp32 arithmetic (restated) on the authoring box: the second yardstick
+        # north_star's bound as written (1e-4 of the depth, 1e-5 m / 1e-6 rad), no allowance; the recorded outputs -- the
+        # reference's fp32 arithmetic (restated) on the authoring box -- are logged as the second yardstick (measured 2-4e-6)
         check_state(poses.cpu().numpy(), disps.cpu().numpy(), r64["poses"], clamp(r64["disps"]), b["disps"],
-                    ref32_disps=clamp(b["disps_out"]), ref32_poses=b["poses_out"], d_rtol=1.5e-4)
+                    ref32_disps=None, d_rtol=1e-4, log32_disps=clamp(b["disps_out"]), log32_poses=b["poses_out"])
         if bool(b["motion_only"]):
             assert torch.equal(disps, _t(b["disps"]).clamp(min=0.001))
 

@@ -40,7 +40,7 @@ def _record(rec):
 
 
 def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None, t_tol=1e-5, r_tol=1e-6,
-                d_rtol=1e-4, frac=0.995, ref32_factor=2.0, ref32_poses=None):
+                d_rtol=1e-4, frac=0.995, ref32_factor=2.0, ref32_poses=None, log32_disps=None, log32_poses=None):
     """north_star tolerances: poses 1e-5 m / 1e-6 rad; inverse depths 1e-4 relative -- measured against the
     float64 arbiter instantiation of the oracle.
 
@@ -54,6 +54,8 @@ def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None,
     Pose criterion: t_tol / r_tol; with ref32_poses (the fp32-faithful oracle's poses) the bound of each is widened to
     ref32_factor x the fp32 oracle's OWN distance from the arbiter where that is larger -- and that distance is recorded,
     so the report shows whether "the reference's fp32 arithmetic is no better" is true of the poses too.
+    log32_disps / log32_poses: the fp32-faithful oracle's state FOR THE REPORT ONLY -- north_star's comparator is the
+    reference's fp32 CUDA path, so |device - ref32| is logged next to the two distances from the arbiter; nothing is widened.
     Every call appends its measured worst cases to gpurun_out/parity_report.jsonl."""
     poses, ref_poses = np.asarray(poses, np.float64), np.asarray(ref_poses, np.float64)
     dt = np.abs(poses[:, :3] - ref_poses[:, :3]).max()
@@ -87,11 +89,35 @@ def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None,
                ref32_own_dt_m=dt32, ref32_own_dr_rad=dr32,
                tol=dict(t=t_tol, r=r_tol, d_rtol=d_rtol, frac=frac,
                         ref32_factor=ref32_factor if ref32_disps is not None else None))
+    # device against the fp32-faithful oracle directly (what north_star names: the reference's fp32 path)
+    l32d = log32_disps if log32_disps is not None else ref32_disps
+    l32p = log32_poses if log32_poses is not None else ref32_poses
+    if l32d is not None:
+        q = np.asarray(l32d, np.float64)
+        e32 = np.abs(d - q)
+        sc32 = np.maximum(np.abs(q), np.abs(o))
+        sol32 = np.abs(q) >= 0.1 * np.abs(o)
+        rec["device_vs_ref32_depth_max_err_over_scale"] = float((e32 / np.maximum(sc32, 1e-12)).max())
+        rec["device_vs_ref32_depth_max_err_over_dref32_noncancelling"] = float(
+            (e32[sol32] / np.abs(q[sol32])).max()) if sol32.any() else 0.0
+        rec["ref32_own_depth_max_dev_over_scale"] = float((np.abs(q - r) / np.maximum(scale, 1e-12)).max())
+        rec["ref32_own_depth_max_dev_over_dref_noncancelling"] = float(
+            (np.abs(q - r)[solid] / np.abs(r[solid])).max()) if solid.any() else 0.0
+    if l32p is not None:
+        p32 = np.asarray(l32p, np.float64)
+        rec["device_vs_ref32_dt_m"] = float(np.abs(poses[:, :3] - p32[:, :3]).max())
+        rec["device_vs_ref32_dr_rad"] = float(quat_angle(poses[:, 3:], p32[:, 3:]).max())
+        if rec.get("ref32_own_dt_m") is None:
+            rec["ref32_own_dt_m"] = float(np.abs(p32[:, :3] - ref_poses[:, :3]).max())
+            rec["ref32_own_dr_rad"] = float(quat_angle(p32[:, 3:], ref_poses[:, 3:]).max())
     # where the worst pixel is and what kind of pixel it is (a depth the update shrinks, a far point ...)
     wi = int(np.argmax(err / np.maximum(scale, 1e-12)))
     rec["worst_pixel"] = dict(index=[int(v) for v in np.unravel_index(wi, err.shape)], d_ref=float(r.flat[wi]),
                               d_old=float(o.flat[wi]), err=float(err.flat[wi]),
-                              ref32_err=(float(dev32.flat[wi]) if ref32_disps is not None else None))
+                              ref32_err=(float(np.abs(np.asarray(l32d, np.float64) - r).flat[wi]) if l32d is not None else None))
+    wp = int(np.argmax(np.where(solid, err / np.maximum(np.abs(r), 1e-300), 0.0)))      # ... and on the |d_ref| scale
+    rec["worst_pixel_over_dref"] = dict(index=[int(v) for v in np.unravel_index(wp, err.shape)], d_ref=float(r.flat[wp]),
+                                        d_old=float(o.flat[wp]), err_over_dref=float(err.flat[wp] / max(abs(r.flat[wp]), 1e-300)))
     _record(rec)
     msg = ("dt=%.3e m dr=%.3e rad depth max(err/allowed)=%.3f max(err/scale)=%.3e max(err/|d_ref|)=%.3e "
            "pure-rel frac=%.6f ref32-allowance pixels=%d/%d" % (
