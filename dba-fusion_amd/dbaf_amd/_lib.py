@@ -20,6 +20,15 @@ class BaLayout(ctypes.Structure):
                [("P", c_int), ("Mmax", c_int), ("nchunks", c_int)]
 
 
+class ShardExchange(ctypes.Structure):
+    """dba_shard_exchange of include/dba_hip.h"""
+    _fields_ = [("world", c_int), ("rank", c_int), ("comm", c_void_p), ("peer_regions", c_void_p),
+                ("peer_epoch", ctypes.POINTER(ctypes.c_uint)), ("peer_max_doubles", c_size_t), ("peer_status", c_void_p),
+                ("band_idx", c_void_p), ("band_len", c_size_t), ("band_buf", c_void_p),
+                ("my_rows", c_void_p), ("n_mine", c_int), ("kmax", c_int), ("all_rows", c_void_p), ("all_slots", c_void_p),
+                ("n_all", c_int), ("send", c_void_p), ("recv", c_void_p)]
+
+
 # every exported symbol of include/dba_hip.h with its (restype, argtypes); pointers are void*
 _P = c_void_p
 SYMBOLS = {
@@ -44,6 +53,13 @@ SYMBOLS = {
     "dba_ba_update": (c_int, [_P] * 5 + [c_int] * 8 + [_P, _P, c_size_t, _P]),
     "dba_ba_shard_front": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, c_int, _P, c_size_t, _P]),
     "dba_ba_shard_back": (c_int, [_P] * 5 + [c_int] * 6 + [c_float, c_float, c_int, _P, c_int, _P, c_size_t, _P]),
+    "dba_comm_unique_id": (c_int, [_P]),
+    "dba_comm_create": (c_int, [_P, c_int, c_int, ctypes.POINTER(_P)]),
+    "dba_comm_destroy": (c_int, [_P]),
+    "dba_comm_allreduce_f64": (c_int, [_P, c_size_t, _P]),
+    "dba_ba_sharded_run": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 7 + [c_float, c_float, c_float, c_int, _P, c_int,
+                                                                                  c_int, ctypes.POINTER(ShardExchange), _P,
+                                                                                  c_size_t, _P]),
     "dba_ba": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,
                                                                      c_size_t, _P]),
     "dba_ba_prepared": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 7 + [c_float, c_float, c_int, _P, _P, _P,

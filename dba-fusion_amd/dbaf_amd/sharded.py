@@ -16,6 +16,7 @@ The stage executor is pluggable so the partition / exchange logic is testable on
 (tests/test_sharded_cpu.py drives it with a CPU stand-in); the product executor is `HipStages` (C ABI).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -70,6 +71,55 @@ def window_fpose(ii, jj, t0, t1):
         if 0 <= p < P:
             fp[p] = min(fp[p], m)
     return fp.astype(np.int32)
+
+
+class _Comms:
+    """RCCL communicators of libdba_hip.so (dba_comm_*), one per process group: the collectives of a sharded ba are then
+    issued by the library itself on the caller's stream, inside dba_ba_sharded_run, instead of by Python between stage
+    calls.  The unique id is made by rank 0 and handed round through the process group ONCE (torch.distributed is only the
+    set-up channel).  DBA_SHARDED_IN_STREAM=0 keeps the staged path."""
+    _by_group = {}
+    enabled = os.environ.get("DBA_SHARDED_IN_STREAM", "1") != "0"
+
+    @classmethod
+    def for_dist(cls, dist, device):
+        """a dba_comm* for `dist` if it is a real device process group (backend nccl = RCCL), else None"""
+        if not cls.enabled or dist is None or not hasattr(dist, "get_backend"):
+            return None
+        try:
+            if str(dist.get_backend()) != "nccl":
+                return None
+        except Exception:
+            return None
+        key = (id(dist), str(device))
+        ent = cls._by_group.get(key)
+        if ent is None:
+            lib = _lib.load()
+            world, rank = dist.get_world_size(), dist.get_rank()
+            buf = (ctypes.c_ubyte * 128)()
+            box = [None]
+            if rank == 0:
+                rc = lib.dba_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+                box = [bytes(buf) if rc == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                cls._by_group[key] = ent = (None,)
+                return None
+            idb = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+            comm = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.dba_comm_create(ctypes.cast(idb, ctypes.c_void_p), world, rank, ctypes.byref(comm)),
+                           "dba_comm_create")
+            cls._by_group[key] = ent = (comm,)
+        return ent[0]
+
+    @classmethod
+    def close(cls):
+        lib = _lib.load()
+        for ent in cls._by_group.values():
+            if ent[0] is not None:
+                lib.dba_comm_destroy(ent[0])
+        cls._by_group.clear()
 
 
 class ShardedWindow:
@@ -186,11 +236,17 @@ class ShardedWindow:
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
         eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
         n6 = 6 * (self.t1 - self.t0)
+        # the whole call as ONE enqueued sequence of the library (stage 0, front / exchange / back per iteration, depth
+        # all-gather): whenever the exchange is something the library can issue itself -- nothing (one rank), its own RCCL
+        # communicator, or the peer-read kernel
+        route = self._in_stream_route(stages, dist, poses.device)
         ctx = stages.begin(poses, disps, intrinsics, disps_sens, targets, weights, eta_loc, ii, jj, d["owned"],
-                           self.t0, self.t1, alpha)
+                           self.t0, self.t1, alpha, **({"defer_prepare": True} if route is not None else {}))
         if isinstance(ctx, dict):
             ctx["fpose"] = d["fpose"]      # the complete graph's skyline for the solver (the summed system has it)
             ctx["solver_hint"] = 1 if self._solver_plan == 1 else 0
+        if route is not None:
+            return self._ba_in_stream(route, ctx, stages, d, disps, dist, iterations, lm, ep, motion_only, n6)
         inplace = getattr(stages, "system_view", None)
         for _ in range(int(iterations)):
             stages.linearize_reduce(ctx, motion_only)
@@ -218,6 +274,59 @@ class ShardedWindow:
         if self._solver_plan is None and 174 < n6 <= 384 and hasattr(stages, "solver_plan") and int(iterations) > 0:
             self._solver_plan = stages.solver_plan(ctx)
         assert hb.numel() >= n6 * n6 + n6
+        return stages.finish(ctx)
+
+    def _in_stream_route(self, stages, dist, device):
+        """("none" | "comm" | "peer", handle) when dba_ba_sharded_run can carry this call, else None (CPU stages of the tests,
+        host-staged / in-process stand-ins for torch.distributed, DBA_SHARDED_IN_STREAM=0)"""
+        if not _Comms.enabled or not isinstance(stages, HipStages) or not hasattr(_lib.load(), "dba_ba_sharded_run"):
+            return None
+        if dist is None:
+            return ("none", None)
+        from .peer import PeerDist
+        if isinstance(dist, PeerDist):
+            return ("peer", dist.peer)
+        comm = _Comms.for_dist(dist, device)
+        return ("comm", comm) if comm is not None else None
+
+    def _ba_in_stream(self, route, ctx, stages, d, disps, dist, iterations, lm, ep, motion_only, n6):
+        kind, handle = route
+        x = _lib.ShardExchange()
+        x.world, x.rank = self.world, self.rank
+        keep = []
+        if kind == "comm":
+            x.comm = handle
+            key = ("merge", tuple(disps.shape[1:]), disps.dtype)
+            if key not in d:
+                d[key] = (disps.new_zeros((self.kmax,) + tuple(disps.shape[1:])),
+                          disps.new_empty((self.world * self.kmax,) + tuple(disps.shape[1:])))
+            send, recv = d[key]
+            x.my_rows, x.n_mine, x.kmax = d["my_rows"].data_ptr(), int(d["my_rows"].numel()), self.kmax
+            x.all_rows, x.all_slots, x.n_all = d["all_rows"].data_ptr(), d["all_slots"].data_ptr(), int(d["all_rows"].numel())
+            x.send, x.recv = send.data_ptr(), recv.data_ptr()
+        elif kind == "peer":
+            x.peer_regions = ctypes.cast(handle._regions, ctypes.c_void_p)
+            if not hasattr(handle, "_epoch_c"):
+                handle._epoch_c = ctypes.c_uint(handle.epoch)
+            handle._epoch_c.value = handle.epoch
+            x.peer_epoch = ctypes.pointer(handle._epoch_c)
+            x.peer_max_doubles, x.peer_status = handle.max_doubles, handle._status.data_ptr()
+        if kind != "none":
+            mode = os.environ.get("DBA_BAND_EXCHANGE")
+            if ((n6 >= 192) if mode is None else (mode == "1")) and "hb" in ctx:
+                idx = self.band_index(ctx["hb"].device, ctx["hb"].numel())
+                bkey = ("band_buf", int(idx.numel()))
+                if bkey not in d:
+                    d[bkey] = torch.empty(idx.numel(), dtype=torch.float64, device=idx.device)
+                x.band_idx, x.band_len, x.band_buf = idx.data_ptr(), int(idx.numel()), d[bkey].data_ptr()
+        stages.run_in_stream(ctx, x, iterations, lm, ep, motion_only)
+        if kind == "peer":
+            handle.epoch = handle._epoch_c.value
+            if not motion_only:
+                self.merge_disps(disps, dist)          # (the peer-read exchange carries the reduced system only)
+            dist.check()
+        if self._solver_plan is None and 174 < n6 <= 384 and int(iterations) > 0:
+            self._solver_plan = stages.solver_plan(ctx)
         return stages.finish(ctx)
 
     def bacore(self, dist, stages=None):
@@ -377,7 +486,8 @@ class HipStages:
         the caller set with dba_ba_schur_select_thread)"""
         _lib.load().dba_ba_schur_select_thread(int(prev))
 
-    def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha):
+    def begin(self, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, owned, t0, t1, alpha,
+              defer_prepare=False):
         lib = _lib.load()
         B, ht, wd = disps.shape
         N = int(ii.shape[0])
@@ -387,6 +497,7 @@ class HipStages:
         if base is None:
             nbytes = lib.dba_ba_workspace_bytes(*dims)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=poses.device)
+            _lib.check(lib.dba_ba_workspace_init(*dims, self._p(ws), nbytes, self._s()), "dba_ba_workspace_init")
             lay = _lib.BaLayout()
             _lib.check(lib.dba_ba_get_layout(*dims, ctypes.byref(lay)), "dba_ba_get_layout")
             n = 6 * (int(t1) - int(t0))
@@ -410,12 +521,26 @@ class HipStages:
         pk = base.get("prepared")
         same = (pk is not None and pk[0]() is ii and pk[2]() is jj and pk[1] == ii._version and pk[3] == jj._version
                 and pk[4] == (lib.dba_ba_schur_generation(), form))
+        # (new tensor objects: stage 0 compares the edge list with the key it left in the workspace and rebuilds only when the
+        # graph changed -- dba_ba_prepare_keyed; on the in-stream path that launch belongs to dba_ba_sharded_run)
+        ctx["prepared"] = 1 if same else 2
         if not same:
-            _lib.check(lib.dba_ba_prepare(self._p(ii), self._p(jj), *dims, self._p(ctx["ws"]), ctx["nbytes"], self._s()),
-                       "dba_ba_prepare")
+            if not defer_prepare:
+                _lib.check(lib.dba_ba_prepare_keyed(self._p(ii), self._p(jj), *dims, ctx["eta_rows"], 1, self._p(ctx["ws"]),
+                                                    ctx["nbytes"], self._s()), "dba_ba_prepare_keyed")
             base["prepared"] = (weakref.ref(ii), ii._version, weakref.ref(jj), jj._version,
                                 (lib.dba_ba_schur_generation(), form))
         return ctx
+
+    def run_in_stream(self, c, x, iterations, lm, ep, motion_only):
+        """dba_ba_sharded_run: stage 0, `iterations` x (front, exchange, back), depth all-gather -- one call, one stream"""
+        p = self._p
+        _lib.check(c["lib"].dba_ba_sharded_run(p(c["poses"]), p(c["disps"]), p(c["intr"]), p(c["dsens"]), p(c["targets"]),
+                                               p(c["weights"]), p(c["eta"]), c["eta_rows"], p(c["ii"]), p(c["jj"]),
+                                               p(c["owned"]), *c["dims"], int(iterations), float(lm), float(ep), c["alpha"],
+                                               int(bool(motion_only)), p(c.get("fpose")), int(c.get("solver_hint", 0)),
+                                               int(c["prepared"]), ctypes.byref(x), p(c["ws"]), c["nbytes"], self._s()),
+                   "dba_ba_sharded_run")
 
     @staticmethod
     def _p(x):

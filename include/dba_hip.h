@@ -172,6 +172,52 @@ int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64
  * solver_hint: as for dba_ba_prepared (0 = none; 1 = meta[7] read 1 after an earlier solve of this window's summed system:
  * the several-tiles-per-thread skyline variant need not be queued behind the first one). */
 
+/* ---- the sharded BA of one rank as ONE enqueued sequence (csrc/ba_sharded_host.hip) --------------------------------------
+ * RCCL called from this library, on the caller's stream.  librccl is loaded with dlopen at the first dba_comm_* call (the copy
+ * the process already has -- PyTorch ships one -- else /opt/rocm/lib); DBA_ERR_UNSUPPORTED when there is none.  The unique id
+ * (128 bytes, ncclUniqueId) is made by one rank and handed to the others by the caller (dbaf_amd/sharded.py broadcasts it
+ * through torch.distributed once per process group); dba_comm_create is collective and binds the calling thread's device. */
+typedef struct dba_comm dba_comm;
+int dba_comm_unique_id(void *id128);
+int dba_comm_create(const void *id128, int world, int rank, dba_comm **out);
+int dba_comm_destroy(dba_comm *c);
+int dba_comm_allreduce_f64(dba_comm *c, double *buf, size_t count, dba_stream_t stream);   /* in-place sum */
+
+/* who carries what between the ranks in dba_ba_sharded_run.  world = 1: nothing is exchanged (the other fields are ignored).
+ *   the reduced system [H | b] (float64, once per iteration): `comm` (RCCL all-reduce) or `peer_regions` (one-shot peer-read
+ *     kernel, dba_peer_allreduce_f64: regions of all ranks, *peer_epoch is advanced by the call, peer_status as there);
+ *     band_len > 0: only the entries band_idx[0..band_len) of the range travel (the skyline band of large windows, gathered
+ *     into band_buf and scattered back);
+ *   the inverse depths (float32, once per call, `comm` only -- a caller on the peer-read exchange gathers them itself):
+ *     my_rows[n_mine] = the frames this rank owns, kmax = the largest n_mine over the ranks, send [kmax, ht*wd] /
+ *     recv [world*kmax, ht*wd] staging, and for every owned row of every rank its frame all_rows[i] and its place
+ *     all_slots[i] in recv. */
+typedef struct {
+  int world, rank;
+  dba_comm *comm;
+  void *const *peer_regions;
+  unsigned *peer_epoch;
+  size_t peer_max_doubles;
+  int *peer_status;
+  const int64_t *band_idx;
+  size_t band_len;
+  double *band_buf;
+  const int64_t *my_rows;
+  int n_mine, kmax;
+  const int64_t *all_rows, *all_slots;
+  int n_all;
+  float *send, *recv;
+} dba_shard_exchange;
+
+/* stage 0 (prepared = 0 | 1 | 2 as in dba_ba_run), then `iterations` x { dba_ba_shard_front -> sum of [H | b] over the ranks
+ * -> dba_ba_shard_back }, then the all-gather of the owned depth maps: everything enqueued on `stream`, nothing waits on the
+ * host.  The alignment gap between H and b in the workspace must be zero (it is summed along). */
+int dba_ba_sharded_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens, const float *targets,
+                       const float *weights, const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                       const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+                       float ep, float alpha, int motion_only, const int32_t *window_fpose, int solver_hint, int prepared,
+                       const dba_shard_exchange *x, void *ws, size_t ws_bytes, dba_stream_t stream);
+
 /* droid_backends.ba: `iterations` x (stage 1..4), all enqueued on `stream` with no host sync.
  * dx_out [P,6] and dz_out [>=|kx|, ht*wd] receive the last iteration's update (either may be NULL). */
 int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
