@@ -399,6 +399,11 @@ int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float e
   return ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false);
 }
 
+int dba_ba_solve_skyline(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, const int32_t *fpose, void *ws,
+                         size_t ws_bytes, dba_stream_t stream) {
+  return ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, false, fpose);
+}
+
 static int ba_update_launch(float *poses, float *disps, const int64_t *jj, const uint8_t *frame_owned, int N, int B,
                             int ht, int wd, int t0, int t1, int update_poses, int update_disps, float *dz_out,
                             float *dx_out, void *ws, size_t ws_bytes, dba_stream_t stream,

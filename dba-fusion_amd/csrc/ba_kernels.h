@@ -109,6 +109,11 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
                          bool last = false);  // last: nothing is queued behind this launch (a hand-shake that times out fails the solve)
 int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, double ep, float *dx, int *meta,
                          hipStream_t stream);
+// five-wave window solver for banded systems (ba_solve_wave.hip); needs the pose-level skyline table; a system it does not
+// admit is solved by the general kernel's code in the same launch, *verdict (pinned host memory, may be null) = 1 admitted / 2 not
+bool ba_solve_wave_supported(int n);
+int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
+                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof = nullptr);
 size_t ba_solve_scratch_doubles(int n);
 constexpr int SOLVE_MAX_LDS_BYTES = 160 * 1024;
 

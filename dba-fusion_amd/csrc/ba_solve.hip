@@ -20,6 +20,9 @@
 #include "ba_kernels.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace dba {
 
@@ -38,65 +41,13 @@ namespace dba {
 #define PROF(slot)
 #endif
 
-constexpr int NB = 12;
 constexpr int SOLVE_THREADS = 512;  // 2 waves/SIMD: 256 VGPRs, enough to hoist a whole 4x4 tile's operands
 
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
+}  // namespace dba
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+#include "ba_solve_general.inc"
 
-template <int LANE>
-__device__ __forceinline__ double readlane_f64(double v) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d) to double precision: v_rsq_f64 seed + two Newton steps (d > 0).  Only the reciprocal of the
-// diagonal sits on the factorisation's critical path; sqrt(d) = d * r is formed off it.
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  const double hd = -0.5 * d;
-  y = y * fma(hd, y * y, 1.5);
-#ifndef SOLVE_ONE_NEWTON
-  y = y * fma(hd, y * y, 1.5);
-#endif
-  return y;
-}
-
-// ---- D: factor the diagonal block with rows across lanes (right-looking, column J) ---------------
-template <int J, int K>
-__device__ __forceinline__ void diag_rank1(double (&a)[NB], double col) {
-  if constexpr (K < NB) {
-    const double ck = readlane_f64<K>(col);
-    a[K] = fma(-col, ck, a[K]);
-    diag_rank1<J, K + 1>(a, col);
-  }
-}
-
-template <int J>
-__device__ __forceinline__ void diag_column(double (&a)[NB], int lane, bool &bad, double *invd) {
-  double d = readlane_f64<J>(a[J]);
-  if (!(d > 0.0)) { bad = true; d = 1.0; }
-  const double r = rsqrt_nr(d);
-  const double col = (lane == J) ? d * r : a[J] * r;
-  a[J] = col;
-  if (lane == 0) invd[J] = r;
-  if constexpr (J + 1 < NB) {
-    diag_rank1<J, J + 1>(a, col);  // a[k] -= col_i * col_k for k > J
-    diag_column<J + 1>(a, lane, bad, invd);
-  }
-}
-
-// ---- backward triangle: solve L11^T x = t with columns across lanes ------------------------------
-// lane c holds t[c], rd = 1/L[c][c] and lcol[j] = L[j][c] for j > c.
-template <int J>
-__device__ __forceinline__ void back_column(const double (&lcol)[NB], double &t, int lane, double rd) {
-  const double xj = readlane_f64<J>(t * rd);
-  if (lane == J) t = xj;
-  else if (lane < J) t = fma(-lcol[J], xj, t);
-  if constexpr (J > 0) back_column<J - 1>(lcol, t, lane, rd);
-}
+namespace dba {
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *__restrict__ H,
@@ -109,186 +60,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void ba_solve_kernel(const double *_
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // queued behind the skyline kernel (ba_solve_band.hip), which leaves meta[3] = 1 when it handled the system
   if (skip_if_solved && meta[3] != 0) return;
-  // layout: [A packed, n+1 rows (LDS mode only)] [rdiag: n] [D: NB*NB] [invd: NB] [rowflag: n+1 ints] [fail]
-  const int n1 = n + 1;
-  double *A;
-  double *rdiag;
-  if constexpr (USE_LDS) {
-    A = smem;
-    rdiag = smem + (size_t)n1 * (n1 + 1) / 2;
-  } else {
-    A = Lglobal;
-    rdiag = smem;
-  }
-  double *D = rdiag + n;
-  double *invd = D + NB * NB;
-  int *rowflag = (int *)(invd + NB);
-  int *fail = rowflag + n1 + 1;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int wave = tid >> 6, lane = tid & 63;
-
-  PROF_DECL;
-  if (tid == 0) *fail = 0;
-  // load the lower triangle with damping diag += ep + lm * diag (:1252-1253); row n = rhs
-  for (int e = tid; e < n * n; e += nt) {
-    const int i = e / n, j = e - i * n;
-    if (j > i) continue;
-    double v = H[e];
-    if (i == j) v += ep + lm * v;
-    A[tri(i, j)] = v;
-  }
-  for (int j = tid; j <= n; j += nt) A[tri(n, j)] = (j < n) ? bvec[j] : 0.0;
-  __syncthreads();
-  PROF(0);
-
-  for (int kb = 0; kb < n; kb += NB) {
-    const int nb = min(NB, n - kb);
-    // ---- D
-    if (wave == 0) {
-      double a[NB];
-#pragma unroll
-      for (int c = 0; c < NB; c++) {
-        double v = (lane >= nb && c == lane) ? 1.0 : 0.0;  // identity rows pad a ragged last block
-        if (lane < nb && c <= lane) v = A[tri(kb + lane, kb + c)];
-        a[c] = v;
-      }
-      bool bad = false;
-      diag_column<0>(a, lane, bad, invd);
-      if (lane < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-          D[lane * NB + c] = (c <= lane) ? a[c] : 0.0;
-          if (lane < nb && c <= lane) A[tri(kb + lane, kb + c)] = a[c];
-        }
-      }
-      if (bad && lane == 0) *fail = 1;
-    }
-    __syncthreads();
-    PROF(1);
-    const int r0 = kb + nb;  // first trailing row
-    // ---- P: rows r0..n (row n is the right-hand side)
-    for (int i = r0 + tid; i <= n; i += nt) {
-      double xr[NB];
-      const int base = tri(i, kb);
-#pragma unroll
-      for (int j = 0; j < NB; j++) xr[j] = (j < nb) ? A[base + j] : 0.0;
-      bool nz = false;
-      // right-looking substitution: two dependent ops per column instead of a j-long chain
-#pragma unroll
-      for (int c = 0; c < NB; c++) {
-        xr[c] *= invd[c];
-        nz |= (xr[c] != 0.0);
-#pragma unroll
-        for (int j = c + 1; j < NB; j++) xr[j] = fma(-xr[c], D[j * NB + c], xr[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        if (j < nb) A[base + j] = xr[j];
-      rowflag[i] = nz ? 1 : 0;
-    }
-    if (tid < nb) rdiag[kb + tid] = invd[tid];
-    __syncthreads();
-    PROF(2);
-    // ---- U: A22 -= X X^T on the f64 matrix cores: 16x16 tiles over rows r0..n, columns r0..n-1, one
-    // v_mfma_f64_16x16x4_f64 per 4 panel columns (A = -X rows, B = X rows; C/D row = (lane>>4) + 4 reg,
-    // col = lane & 15).  Tiles whose panel rows or columns are exactly zero are skipped.
-    {
-      const int Tn = (n1 - r0 + 15) >> 4;  // row tiles (the last one may hang over the rhs row); <= 32 here
-      const int nw = nt >> 6;
-      const int li = lane & 15, lk = lane >> 4;
-      // which row tiles have a non-zero panel row?  (wave-uniform bit mask from ballots over the row flags)
-      unsigned tmask = 0;
-      for (int base = 0; base < Tn * 16; base += 64) {
-        const int i = r0 + base + lane;
-        const unsigned long long b = __ballot(i <= n && rowflag[i] != 0);
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-          if ((b >> (16 * g)) & 0xffffull) tmask |= 1u << ((base >> 4) + g);
-      }
-      PROF(4);
-      // enumerate the active lower-triangular tile pairs (ti >= tj, both active); wave w takes every nw-th
-      int pair = 0;
-      for (unsigned mi = tmask; mi; mi &= mi - 1) {
-        const int ti = __builtin_ctz(mi);
-        for (unsigned mj = tmask & ((2u << ti) - 1u); mj; mj &= mj - 1) {
-          const int tj = __builtin_ctz(mj);
-          if ((pair++ % nw) != wave) continue;
-        const int i0 = r0 + 16 * ti, j0 = r0 + 16 * tj;
-        // per-lane operand rows (clamped; rows past the rhs row contribute zeros)
-        const int ia = i0 + li, jb = j0 + li;
-        const bool va = ia <= n, vb = jb <= n;
-        const int ba = tri(min(ia, n), kb), bb = tri(min(jb, n), kb);
-        d4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = i0 + lk + 4 * r, j = j0 + li;
-          acc[r] = (i <= n && j < n && j <= i) ? A[tri(i, j)] : 0.0;
-        }
-#pragma unroll
-        for (int c0 = 0; c0 < NB; c0 += 4) {
-          const int c = c0 + lk;
-          const double xa = (va && c < nb) ? -A[ba + c] : 0.0;
-          const double xb = (vb && c < nb) ? A[bb + c] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = i0 + lk + 4 * r, j = j0 + li;
-          if (i <= n && j < n && j <= i) A[tri(i, j)] = acc[r];
-        }
-        }
-      }
-      PROF(5);
-    }
-    __syncthreads();
-    PROF(3);
-  }
-
-  // row n now holds y = L^-1 b.  Backward substitution L^T x = y, block-wise bottom-up; x overwrites row n.
-  double *x = A + tri(n, 0);
-  for (int kb = ((n - 1) / NB) * NB; kb >= 0; kb -= NB) {
-    const int nb = min(NB, n - kb);
-    if (wave == 0) {
-      double lcol[NB];
-      const int c = min(lane, nb - 1);
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        double v = 0.0;
-        if (lane < nb && j > lane && j < nb) v = A[tri(kb + j, kb + c)];
-        lcol[j] = v;
-      }
-      double t = (lane < nb) ? x[kb + c] : 0.0;
-      const double rd = (lane < nb) ? rdiag[kb + c] : 0.0;
-      back_column<NB - 1>(lcol, t, lane, rd);
-      if (lane < nb) x[kb + lane] = t;
-    }
-    __syncthreads();
-    PROF(6);
-    for (int i = tid; i < kb; i += nt) {
-      double t = x[i];
-      for (int c = 0; c < nb; c++) t = fma(-A[tri(kb + c, i)], x[kb + c], t);
-      x[i] = t;
-    }
-    __syncthreads();
-    PROF(7);
-  }
-
-  // non-finite results count as failure too; failure => zero update (:1263-1266)
-  int bad = 0;
-  for (int i = tid; i < n; i += nt)
-    if (!isfinite(x[i])) bad = 1;
-  if (bad) *fail = 1;
-  __syncthreads();
-  const int failed = *fail;
-  for (int i = tid; i < n; i += nt) dx[i] = failed ? 0.f : (float)x[i];
-  if (tid == 0) meta[1] = failed;
-  PROF(8);
+  ba_solve_general_body<USE_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, prof, smem);
 }
 
-static size_t solve_small_bytes(int n) {
-  return ((size_t)n + NB * NB + NB) * sizeof(double) + ((size_t)n + 4) * sizeof(int) + 16;
-}
-static size_t solve_packed_bytes(int n) { return (size_t)(n + 1) * (n + 2) / 2 * sizeof(double); }
 
 bool ba_solve_fits_lds(int n) {
   return solve_packed_bytes(n) + solve_small_bytes(n) <= (size_t)SOLVE_MAX_LDS_BYTES;
@@ -301,6 +75,36 @@ size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 // exists for skylines the first one cannot hold, nor the general kernel is queued behind it (4.6-4.8 us each per solve even
 // when they return at once).  The one thing they were still a net for -- a partner workgroup that does not show up within
 // a second -- then fails the solve (zero update, meta[1] = 1) instead of leaving it to the queue
+// Which kernel took a workspace's last system: the window kernel reports "banded, taken" (1) or "not banded, solved by the
+// general code in my launch" (2) through a word of pinned host memory per workspace (keyed by its meta pointer), read here
+// without any synchronisation.  It steers the NEXT solve of that workspace -- 2: straight to the register-tile / skyline
+// kernels, which are faster than the in-launch fall-back on such systems; anything else: the window kernel -- and is only
+// ever a performance hint: whatever is launched solves whatever it is given.
+static int *solver_verdict_slot(const int *meta) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, int> index;
+  static int *pool = nullptr;
+  static int next = 0;
+  constexpr int SLOTS = 1024, STRIDE = 16;   // ints per slot: [0] verdict, [1] solves since the verdict said "not banded"
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&pool), sizeof(int) * SLOTS * STRIDE, hipHostMallocCoherent | hipHostMallocMapped) !=
+        hipSuccess) {
+      pool = nullptr;
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    memset(pool, 0, sizeof(int) * SLOTS * STRIDE);
+  }
+  auto it = index.find(meta);
+  if (it == index.end()) {
+    if ((int)index.size() >= SLOTS) index.clear(), next = 0;   // (a process that went through 1024 workspaces starts over)
+    it = index.emplace(meta, next++).first;
+    pool[it->second * STRIDE] = 0, pool[it->second * STRIDE + 1] = 0;
+  }
+  return pool + it->second * STRIDE;
+}
+
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                     double *Lscratch, hipStream_t stream, long long *prof, int hint) {
   if (n <= 0) return DBA_OK;
@@ -313,9 +117,21 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     if (e && e[0] == 't') return 1;
     if (e && e[0] == 'g') return 2;
     if (e && e[0] == 'b') return 3;
+    if (e && e[0] == 'w') return 4;
     const char *g = getenv("DBA_SOLVE_GENERAL");
     return (g && g[0] == '1') ? 2 : 0;
   }();
+  // banded systems with a skyline table (every call of dba_ba): the five-wave window kernel, unless this workspace's last system
+  // was not banded (then every 32nd solve still goes there, in case the graph has changed back).  DBA_SOLVE_KERNEL=wave forces it.
+  if (!prof && fpose && (forced == 0 || forced == 4) && ba_solve_wave_supported(n)) {
+    int *slot = solver_verdict_slot(meta);
+    const int verdict = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
+    const bool probe = slot && verdict == 2 && (++slot[1] & 31) == 0;
+    if (forced == 4 || verdict != 2 || probe) {
+      if (slot && verdict == 2) slot[1] = 0;
+      return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream);
+    }
+  }
   int chained = 0;
   if (!prof && forced <= 1 && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);
   if (!prof && (forced == 0 || forced == 3) && ba_solve_band_supported(n)) {

@@ -1,48 +1,43 @@
-// EXPERIMENT (round 5, not built into the library): correct on every case of scratch/solve_wave_test.hip (23 systems: bands
-// of 0-7 poses, 1-64 poses, not positive definite, arrow / extra couplings, admission refusals) on the first run on the GPU --
-// scratch/wave_solver_model.py is the kernel lane by lane in numpy and was held against dense solves before any device run --
-// but SLOWER than the kernels that ship: n = 144: 49.5 us against 36.9 us (ba_solve_tile.hip); n = 378: 125 us against 101.5
-// (ba_solve_band.hip).  A lone wave issues one instruction per ~5 cycles (LDS b64 ~10), and a 4-column step is ~270 of them:
-// measured 2340 cycles per step = inverse of the pivot block 390 + six f64 matrix instructions 580 (on MI355X they run on the
-// float64 vector pipe: 64 cycles each at best, no overlap with the VALU) + reads / extraction / operands / control 1370.
-// That is 585 cycles per column -- the register-tile kernel's barrier steps cost 550.  See profiles/SOLVER_NOTES.md (round 5)
-// for what would make it pay (two waves per front + a separator between two fronts: estimated 17 us / 37 us).
-//
-// Damped solve of the reduced camera system by ONE wavefront: a sliding window of the band in matrix-core accumulators.
+// Damped solve of the reduced camera system of a sliding window: FIVE WAVES, the band's trailing window in matrix-core
+// accumulators, no workgroup barrier anywhere.
 //
 // Replaces the host-side Eigen LLT / SimplicialLLT of the reference (/root/reference/src/droid_kernels.cu:200-218
 // solveDenseD, :1248-1269 SparseBlock::solve) for the systems a sliding-window tracker produces: block-banded, 6 x 6 pose
-// blocks, a handful of blocks wide.  ba_solve_tile.hip / ba_solve_band.hip / ba_solve.hip keep every other structure.
+// blocks, up to four blocks wide (every column ends inside the 48-row window of its tile column: ba_solve_wave_admits).
+// Anything else is solved by the general blocked kernel's code inside the same launch (ba_solve_general.inc), and the host
+// learns the verdict through pinned memory, so that the next solve of that workspace goes to ba_solve_tile.hip /
+// ba_solve_band.hip directly (launch_ba_solve in ba_solve.hip).
 //
-// The solve is ~0.1 MFLOP; what costs is the dependent chain (n pivots) and what hangs on every link of it.  The
-// register-tile kernel (ba_solve_tile.hip) spreads the matrix over 11 waves and pays a workgroup barrier, an LDS hand-off
-// and a poorly filled float64 pipe per two columns (0.47 us).  Here one wave owns the whole active part of the matrix:
-//   * block LDL^T with 4 x 4 pivots; the trailing window -- the NT x NT lower tile triangle (16 x 16 tiles, NT = 3: 48 rows)
-//     below / right of the pivot's tile column -- lives in matrix-core accumulators for the whole factorisation, and a
-//     step's rank-4 update of it is one v_mfma_f64_16x16x4_f64 per tile: C -= R (W R^T) with R the raw panel, W the inverted
-//     pivot block.  The instruction broadcasts its operands itself: no shuffles, no barrier, all 64 lanes busy;
-//   * per step the next four columns leave the accumulators through LDS (the panel store, which is also what the
-//     substitution reads later) and come back in the operand layouts;
-//   * every lane inverts the pivot block, but lane group k (the k of the operand layouts) reads it with its indices XOR k,
-//     so that ROW 0 of its inverse is row k of W: each lane computes only the row it needs and nothing is selected or
-//     exchanged afterwards;
-//   * the window slides: after the four steps of a tile column the tiles move up one place (register copies) and the
-//     next tile row comes in from global memory, requested four steps (~1.5 us) before;
-//   * the right-hand side rides along (z = W b1, b2 -= R z), the backward substitution runs right-looking: lane (slot,
-//     k) accumulates v_s[k] = sum_i R_s[i][k] x[i] for the step s whose window still receives solved unknowns, so the
-//     chain per step is four v_readlane + two short FMA chains, no reduction.
-// Admission: the skyline (the prepare stage's pose-level table, made monotone) must stay inside the window in every step;
-// the kernel tests that itself (ba_solve_wave_admits) and leaves the system to the other kernels otherwise.
-// tests/wave_solver_model.py is this file lane by lane in numpy (pinned against a dense solve on the CPU).
+// The solve is ~0.1 MFLOP; what costs is the dependent chain (n pivots) and the instructions that hang on every link: a lone
+// wave issues one instruction per 5-8 cycles.  So the chain is made short per column and everything else is taken off it:
+//   * block LDL^T with 4 x 4 pivots.  The trailing window -- the 3 x 3 lower tile triangle (16 x 16 tiles, 48 rows) under / right
+//     of the pivot's tile column -- lives in v_mfma_f64_16x16x4_f64 accumulators for the whole factorisation; a step's rank-4
+//     update of a tile is ONE instruction (C -= R (W R^T), R the raw panel, W the inverted pivot block) that broadcasts its
+//     operands itself: no shuffles, no barrier;
+//   * THREE factor waves, one per tile row of the window (role r holds the tiles (r, 0..r)).  Role 0 is the chain: invert the
+//     pivot block (row 0 of the inverse by cofactors, 35 operations 13 deep), publish W, update the pivot tile, send its
+//     rows of the next panel to LDS and read the next pivot block back.  Roles 1, 2 pick W up and do the same for their
+//     rows, off the chain.  After the four steps of a tile column the ROLES rotate, not the tiles: role r becomes r - 1 (its
+//     tile (r, r) is the next (r - 1, r - 1)), the wave whose pivot tile is finished takes the tile row that enters the window;
+//   * lane group k (the k of the operand layouts) reads the pivot block with its indices XOR k, so that ROW 0 of its inverse is
+//     row k of W: every lane computes only the row it needs, nothing is selected or exchanged;
+//   * a LOADER wave brings the entering tile rows from global memory into one LDS slot, a tile column ahead: no register of a
+//     factor wave ever waits for global memory (a register prefetch made every loop trip wait: the compiler's copies of
+//     loop-carried registers cannot pass a pending load);
+//   * a SUBSTITUTION wave runs the right-hand side one step behind the factorisation (z = W b1, b2 -= R z) and then the
+//     backward substitution right-looking: lane (slot, k) accumulates v_s[k] = sum_i R_s[i][k] x[i] for the step s whose
+//     window still receives solved unknowns, so the chain per step is v_readlane -> 4 FMA -> quad broadcast -> 4 FMA;
+//   * the waves meet through monotone counters in LDS (flags written after the data, in program order: the LDS unit executes
+//     a wave's DS instructions in order), never at a barrier.
+// Measured (scratch/solve_wave_test.hip, profiles/r05_solver_stages.txt): n = 144: 30.3 us (register-tile kernel 36.9),
+// n = 174: 36 (57), n = 378: 75 (skyline kernel 101.5).  tests/wave_solver_model.py is the arithmetic and the index logic of
+// this file lane by lane in numpy, pinned against dense solves on the CPU (tests/test_wave_solver_model.py).
 #include "ba_kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
-namespace dba {
-bool ba_solve_wave_supported(int n);
-int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                         hipStream_t stream, long long *prof = nullptr);
-}
+#include "ba_solve_general.inc"
 
 namespace dba {
 
@@ -61,46 +56,17 @@ __device__ __forceinline__ double wv_readlane(double v, int l) {  // l wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// Row 0 of the inverse of the symmetric 4 x 4 block with lower triangle a b c / d e h / f g i j (rows 0..3), through
-// 2 x 2 blocks: [A B^T; B C]^-1, S = C - B A^-1 B^T.  ok = positive definite (as far as the pivots of this order say).
-__device__ __forceinline__ void wv_invert_row0(double a, double b, double c, double d, double e, double f, double g, double h,
-                                               double i, double j, double (&w)[4], bool &ok) {
-  const double detA = fma(-b, b, a * c);
-  const bool okA = (a > 0.0) && (detA > 0.0);
-  const double iA = okA ? wv_rcp(detA) : 0.0;
-  const double a00 = c * iA, a01 = -b * iA, a11 = a * iA;
-  const double x00 = fma(e, a01, d * a00), x01 = fma(e, a11, d * a01);  // X = B A^-1
-  const double x10 = fma(g, a01, f * a00), x11 = fma(g, a11, f * a01);
-  const double s00 = fma(-x01, e, fma(-x00, d, h));  // S = C - X B^T
-  const double s01 = fma(-x01, g, fma(-x00, f, i));
-  const double s11 = fma(-x11, g, fma(-x10, f, j));
-  const double detS = fma(-s01, s01, s00 * s11);
-  ok = okA && (s00 > 0.0) && (detS > 0.0);
-  const double iS = ok ? wv_rcp(detS) : 0.0;
-  const double t00 = s11 * iS, t01 = -s01 * iS, t11 = s00 * iS;  // S^-1
-  const double y00 = fma(t01, x10, t00 * x00), y01 = fma(t01, x11, t00 * x01);  // Y = S^-1 X
-  const double y10 = fma(t11, x10, t01 * x00), y11 = fma(t11, x11, t01 * x01);
-  // a failed block contributes nothing (iA = iS = 0 makes everything below zero); the verdict is collected separately
-  w[0] = fma(x10, y10, fma(x00, y00, a00));
-  w[1] = fma(x10, y11, fma(x00, y01, a01));
-  w[2] = -y00;
-  w[3] = -y10;
-}
-
-// LDS, in doubles: panel store [S][16 NT][4] | z of every step [S][4] | right-hand side / solution [np + 64]
-template <int NT>
+// LDS, in doubles: panel store [S][48][4] | z of every step [S][4] | right-hand side / solution + flags [np + 64] | the loader's slot
 __device__ __host__ __forceinline__ size_t wv_lds_doubles(int n) {
   const int np = (n + 15) & ~15, S = np >> 2;
-  return (size_t)S * (16 * NT * 4 + 4) + np + 64 + 3 * 4 * 64;   // (+ the loader's slot)
+  return (size_t)S * (16 * 3 * 4 + 4) + np + 64 + 3 * 4 * 64;
 }
 
-// The kernel's admission test, one wave: with the pose-level skyline fpose (first pose a pose is coupled with) made
-// monotone, every column's last row must lie inside the window of its step's tile column: row < 16 (s >> 2) + 16 NT.
-// Returns the smallest NT in {3, 4} (<= max_nt: the panel store of NT = 4 does not fit LDS for the largest systems) that admits
-// the system, or 0.
-__device__ __forceinline__ int ba_solve_wave_admits(const int *__restrict__ fpose, int n, int lane, int max_nt) {
+// The admission test, by every wave for itself: with the pose-level skyline fpose (first pose a pose is coupled with) made
+// monotone, every column's last row must lie inside the window of its step's tile column: row < 16 (s >> 2) + 48.
+__device__ __forceinline__ bool ba_solve_wave_admits(const int *__restrict__ fpose, int n, int lane) {
   const int P = n / 6;
-  if (!fpose || P > 64 || n != 6 * P) return 0;
+  if (!fpose || P > 64 || n != 6 * P) return false;
   int g = (lane < P) ? fpose[lane] : 0x7fffffff;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {  // suffix minimum: fill-in keeps the skyline monotone
@@ -113,18 +79,14 @@ __device__ __forceinline__ int ba_solve_wave_admits(const int *__restrict__ fpos
     if (gp <= lane) last = max(last, p);
   }
   const int np = (n + 15) & ~15, S = np >> 2;
-  bool ok3 = true, ok4 = true;
+  bool ok = true;
   for (int base = 0; base < S; base += 64) {   // (uniform trip count: the shuffle below is executed by all lanes)
     const int s = base + lane, c = 4 * s;
     const int q3 = min(min(c + 3, n - 1) / 6, P - 1);
     const int lastrow = 6 * __shfl(last, q3, 64) + 5;
-    const bool live = (s < S) && (c < n);
-    ok3 = ok3 && (!live || lastrow <= 16 * (s >> 2) + 47);
-    ok4 = ok4 && (!live || lastrow <= 16 * (s >> 2) + 63);
+    ok = ok && (!((s < S) && (c < n)) || lastrow <= 16 * (s >> 2) + 47);
   }
-  if (__ballot(!ok3) == 0ull) return 3;
-  if (__ballot(!ok4) == 0ull && max_nt >= 4) return 4;
-  return 0;
+  return __ballot(!ok) == 0ull;
 }
 
 #ifdef PROFILE_SOLVE
@@ -153,22 +115,11 @@ __device__ __forceinline__ void wv_publish(int *flag, int value) {
   *(wv_lds_vint *)flag = value;
   asm volatile("" ::: "memory");
 }
-#ifdef PROFILE_SOLVE
-__device__ long long *g_wv_wait_prof;   // (kept for the harness' symbol lookup; unused)
-#endif
-__device__ __forceinline__ long long wv_await(int *flag, int need) {   // returns the shader cycles spent waiting (profiling builds)
+__device__ __forceinline__ void wv_await(int *flag, int need) {
   __builtin_amdgcn_wave_barrier();
-#ifdef WV_STEP_PROF
-  const long long c0_ = clock64();
-#endif
   while (*(wv_lds_vint *)flag < need) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-#ifdef WV_STEP_PROF
-  return clock64() - c0_;
-#else
-  return 0;
-#endif
 }
 
 constexpr int WNT = 3;   // tile rows of the window = factor waves
@@ -315,11 +266,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     double w[4];
     if constexpr (R == 0) {
       bool ok;
-#ifdef WV_NO_INV
-      w[0] = pv[0], w[1] = pv[1], w[2] = pv[3], w[3] = pv[6], ok = true;
-#else
       wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, ok);
-#endif
       if (__ballot(!ok) != 0ull && lane == 0) *(wv_lds_vint *)L.fail = 1;
       if (li == 0) {   // W takes the pivot block's place in the panel store
 #pragma unroll
@@ -327,11 +274,11 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
       }
       wv_publish(L.flagW, s + 1);
     } else {
-      (void)wv_await(L.flagW, s + 1);
+      wv_await(L.flagW, s + 1);
 #pragma unroll
       for (int j = 0; j < 4; j++) w[j] = pan[(cl + lk) * 4 + (lk ^ j)];
 #pragma unroll
-      for (int t = 0; t < R; t++) (void)wv_await(L.flagE + t, s + 1);   // the rows above this wave's, stored by their owners
+      for (int t = 0; t < R; t++) wv_await(L.flagE + t, s + 1);   // the rows above this wave's, stored by their owners
     }
     double raw[R + 1][4];   // this lane's rows 16 t + li of the panel, columns XOR lk, t = 0..R
     if constexpr (R == 0) {
@@ -393,7 +340,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
       for (int j = 1; j <= R; j++) T[j - 1] = T[j];
     } else {                  // the pivot tile is finished: take the tile row that enters the window from the loader's slot
       if (more) {
-        (void)wv_await(L.flagL, tb + 1);
+        wv_await(L.flagL, tb + 1);
         const double *ring = L.RING;
 #pragma unroll
         for (int j = 0; j < NT; j++)
@@ -424,7 +371,7 @@ __device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const dou
     wv_d4 t[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; j++) t[j] = wv_load_tile(H, n, L.np, lm, ep, WNT + k, k + 1 + j, lane);
-    (void)wv_await(L.flagC, k);
+    wv_await(L.flagC, k);
 #pragma unroll
     for (int j = 0; j < WNT; j++)
 #pragma unroll
@@ -453,9 +400,9 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
   for (int s = 0; s < S; s++) {
     const int tb = s >> 2, cl = 4 * (s & 3);
     const double *pan = PAN + (size_t)s * PD;
-    (void)wv_await(L.flagW, s + 1);
+    wv_await(L.flagW, s + 1);
 #pragma unroll
-    for (int t = 0; t < WNT; t++) (void)wv_await(L.flagE + t, s + 1);
+    for (int t = 0; t < WNT; t++) wv_await(L.flagE + t, s + 1);
     double z[4];
     const double b0 = BV[4 * s], b1 = BV[4 * s + 1], b2 = BV[4 * s + 2], b3 = BV[4 * s + 3];
 #pragma unroll
@@ -542,22 +489,29 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
   WPROF(6);
 }
 
-// the kernel: five waves (three for the factorisation, one for the substitution, one that brings tile rows in).  Every wave runs the admission test (no
-// exchange needed to agree); meta[3] = 1 when the system was taken (a kernel queued behind with `skip_if_solved` then returns
-// at once), 0 when it is left to that kernel
+// the kernel: five waves (three for the factorisation, one for the substitution, one that brings tile rows in).  Every wave
+// runs the admission test (no exchange needed to agree).  A system that is not admitted is solved by the general blocked
+// kernel's code with the same five waves; `verdict` (pinned host memory) tells the host which it was: 1 taken, 2 not.
+template <bool GENERAL_IN_LDS>
 __global__ __launch_bounds__(320) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
                                                             const int *__restrict__ fpose, int n, double lm, double ep,
-                                                            float *__restrict__ dx, int *__restrict__ meta, int max_nt,
+                                                            float *__restrict__ dx, int *__restrict__ meta,
+                                                            double *__restrict__ Lglobal, int *__restrict__ verdict,
                                                             long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) double wv_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nt = ba_solve_wave_admits(fpose, n, lane, 3);
-  (void)max_nt;
-  if (threadIdx.x == 0) meta[3] = (nt == 3) ? 1 : 0;
-  if (nt != 3) return;
+  const bool admitted = ba_solve_wave_admits(fpose, n, lane);
+  if (threadIdx.x == 0) {
+    meta[3] = 1;   // (solved either way: a kernel queued behind with `skip_if_solved` returns at once)
+    if (verdict) __hip_atomic_store(verdict, admitted ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (!admitted) {
+    ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
+    return;
+  }
   {
     const WvLayout L(wv_smem, n);
-    if (threadIdx.x < 8) L.flagW[threadIdx.x] = 0;   // flagW, flagE[3], fail (+ spare)
+    if (threadIdx.x < 8) L.flagW[threadIdx.x] = 0;   // flagW, flagE[3], fail, flagL, flagC (+ spare)
   }
   __syncthreads();
   if (wave < WNT) ba_solve_wave_factor(n, wv_smem, H, lm, ep, lane, wave, prof);
@@ -565,26 +519,32 @@ __global__ __launch_bounds__(320) void ba_solve_wave_kernel(const double *__rest
   else ba_solve_wave_loader(n, wv_smem, H, lm, ep, lane);
 }
 
-static int wave_max_nt(int n) {
-  if (n <= 0 || n % 6 != 0 || n / 6 > 64) return 0;
-  if (wv_lds_doubles<3>(n) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 3;
-  return 0;
+bool ba_solve_wave_supported(int n) {
+  return n > 0 && n % 6 == 0 && n / 6 <= 64 && wv_lds_doubles(n) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES;
 }
 
-bool ba_solve_wave_supported(int n) { return wave_max_nt(n) != 0; }
-
+// Lscratch: the workspace's packed-triangle scratch (needed by the fall-back when the system does not fit LDS: n > 199)
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                         hipStream_t stream, long long *prof) {
+                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof) {
+  if (!ba_solve_wave_supported(n) || !fpose) return DBA_ERR_UNSUPPORTED;
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
-    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_kernel),
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_once.done();
   }
-  const int max_nt = wave_max_nt(n);
-  if (!max_nt) return DBA_ERR_UNSUPPORTED;
-  const size_t lds = wv_lds_doubles<3>(n) * sizeof(double);
-  hipLaunchKernelGGL(ba_solve_wave_kernel, dim3(1), dim3(320), lds, stream, H, b, fpose, n, lm, ep, dx, meta, max_nt, prof);
+  const size_t wave_lds = wv_lds_doubles(n) * sizeof(double);
+  const size_t gen_lds = solve_packed_bytes(n) + solve_small_bytes(n);
+  if (gen_lds <= (size_t)SOLVE_MAX_LDS_BYTES) {
+    hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(320), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
+                       ep, dx, meta, Lscratch, verdict, prof);
+  } else {
+    if (!Lscratch) return DBA_ERR_WORKSPACE;
+    hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(320), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
+                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, prof);
+  }
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -50,6 +50,7 @@ SYMBOLS = {
     "dba_ba_set_deterministic": (c_int, [c_int]),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
     "dba_ba_solve": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
+    "dba_ba_solve_skyline": (c_int, [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),
     "dba_ba_update": (c_int, [_P] * 5 + [c_int] * 8 + [_P, _P, c_size_t, _P]),
     "dba_ba_shard_front": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, c_int, _P, c_size_t, _P]),
     "dba_ba_shard_back": (c_int, [_P] * 5 + [c_int] * 6 + [c_float, c_float, c_int, _P, c_int, _P, c_size_t, _P]),

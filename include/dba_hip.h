@@ -139,12 +139,20 @@ int dba_ba_set_deterministic(int on);
 int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
 
 /* stage 3: damped dense solve in float64 on the device
- * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx.  Register-tile block LDL^T up
- * to 29 poses, skyline variants up to 64 poses, blocked Cholesky beyond / for wide skylines (csrc/ba_solve*.hip).
+ * (SparseBlock::solve :1248-1269: diag += ep + lm*diag; LL^T; zeros on failure) -> dx.  With a skyline table: the five-wave
+ * window kernel for banded systems up to 64 poses (csrc/ba_solve_wave.hip).  Otherwise / for other structures: register-tile
+ * block LDL^T up to 29 poses, skyline variants up to 64 poses, blocked Cholesky beyond / for wide skylines (csrc/ba_solve*.hip).
  * This stage measures the skyline from H (the system may have been summed over ranks); dba_ba takes it from the
  * prepare stage's graph tables. */
 int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws,
                  size_t ws_bytes, dba_stream_t stream);
+/* the same with the caller's pose-level skyline (device, t1 - t0 ints: for every pose the first pose it is coupled with, as
+ * dba_ba_shard_back's window_fpose): what dba_ba hands the solvers from its graph tables.  With a skyline, banded systems
+ * (every column inside the 48-row window of its 16-column tile: ~4 poses wide) go to the five-wave window kernel
+ * (csrc/ba_solve_wave.hip); a system that turns out not to be banded is solved by the general kernel's code in the same
+ * launch, and the next solve on this workspace goes to the register-tile / skyline kernels directly. */
+int dba_ba_solve_skyline(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, const int32_t *fpose, void *ws,
+                         size_t ws_bytes, dba_stream_t stream);
 
 /* stage 4: back-substitution + retraction (EvT6x1_kernel :1140-1160, dz :1495,
  * pose_retr_kernel :943-976, disp_retr_kernel :978-991).  dz_out [>=|kx|, ht*wd] may be NULL.

@@ -66,8 +66,9 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
       for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, 0, g_wprof); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
-      if (mode == 0 && getenv("HARNESS_STEPS")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
-      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us: [wave 0] load+first panel %.2f factor %.2f | [wave 1] init+forward (behind wave 0) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100, hp[1]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
+      if (mode == 0) { long long hp[24]; hipMemcpy(hp, g_wprof, 192, hipMemcpyDeviceToHost); const double S3 = ((n + 15) / 16 * 4) * 200.0 / 3.0, S_ = ((n + 15) / 16 * 4) * 200.0; printf("   shader cycles per step in role 0 / 1 / 2 (mean over the waves; waits included): %.0f / %.0f / %.0f | cycles per step a wave waits on flags: %.0f %.0f %.0f\n", (hp[8]+hp[12]+hp[16])/S3/3, (hp[9]+hp[13]+hp[17])/S3/3, (hp[10]+hp[14]+hp[18])/S3/3, hp[11]/S_, hp[15]/S_, hp[19]/S_); }
+      if (mode == 0 && getenv("HARNESS_STEPS_OLD")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
+      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us: [factor waves] load+first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [subst wave] init+forward (behind the factorisation) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100/3, hp[1]/200.0/100, hp[2]/200.0/100, hp[3]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
     }
   }
   hipFree(dH); hipFree(db); hipFree(dx); hipFree(meta); hipFree(dfp);
@@ -76,6 +77,7 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
 int main() {
   hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048);
   hipMalloc(&g_wprof, 256); hipMemset(g_wprof, 0, 256);
+  { long long *dwp; hipMalloc(&dwp, 64); hipMemset(dwp, 0, 64); hipMemcpyToSymbol(HIP_SYMBOL(dba::g_wv_wait_prof), &dwp, sizeof(dwp)); }
   run(24, 4, true, true); run(24, 3, true, true); run(25, 4, true, true); run(24, 2, true, false); run(24, 1, true, false); run(24, 0, true, false);
   run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
   run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);

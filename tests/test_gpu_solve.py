@@ -213,3 +213,109 @@ def test_random_window_structures_against_numpy():
     print(paths)
     if os.environ.get("DBA_SOLVE_SPLIT") != "0":
         assert paths["two workgroups"] >= 20 and paths["one workgroup"] >= 10
+
+
+# ---- the five-wave window kernel (csrc/ba_solve_wave.hip), reached through the stage function that takes a skyline table ----
+
+def _pose_system(rng, P, w, spd=True, extra=()):
+    """P poses of 6 unknowns, pose p coupled with p-w .. p (+ extra pairs); returns H, b and the pose-level skyline"""
+    n = 6 * P
+    H = np.zeros((n, n))
+    fpose = list(range(P))
+    for p, q in [(p, q) for p in range(P) for q in range(max(0, p - w), p + 1)] + list(extra):
+        Bk = rng.standard_normal((6, 6)) * 0.3
+        if p == q:
+            Bk = Bk + Bk.T
+        H[6 * p:6 * p + 6, 6 * q:6 * q + 6] += Bk
+        if p != q:
+            H[6 * q:6 * q + 6, 6 * p:6 * p + 6] += Bk.T
+        fpose[p] = min(fpose[p], q)
+    H += np.eye(n) * (np.abs(H).sum(1).max() + 1.0)
+    if not spd:
+        H[n // 2, n // 2] = -1.0
+    return H, np.sin(1.3 * np.arange(n)), np.array(fpose, np.int32)
+
+
+class _SkylineSolver:
+    """one workspace, several solves: the solver's choice of kernel for a workspace depends on what its previous system was"""
+
+    def __init__(self, P):
+        self.lib = _lib.load()
+        self.P = P
+        self.dims = (1, P + 2, 8, 8, 1, 1 + P)
+        self.nbytes = self.lib.dba_ba_workspace_bytes(*self.dims)
+        self.ws = torch.zeros(self.nbytes, dtype=torch.uint8, device="cuda")
+        self.lay = _lib.BaLayout()
+        _lib.check(self.lib.dba_ba_get_layout(*self.dims, ctypes.byref(self.lay)), "dba_ba_get_layout")
+
+    def solve(self, H, b, fpose, lm=1e-4, ep=0.1):
+        n, lay, ws = 6 * self.P, self.lay, self.ws
+        Hl = np.tril(H) + np.triu(np.full_like(H, 1e300), 1)       # the solvers read the lower triangle only
+        ws[lay.H:lay.H + 8 * n * n].view(torch.float64).copy_(torch.from_numpy(Hl.reshape(-1)).cuda())
+        ws[lay.b:lay.b + 8 * n].view(torch.float64).copy_(torch.from_numpy(b).cuda())
+        ws[lay.dx:lay.dx + 4 * n].view(torch.float32).fill_(7.0)
+        fp = torch.from_numpy(fpose).cuda()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(self.lib.dba_ba_solve_skyline(*self.dims, lm, ep, ctypes.c_void_p(fp.data_ptr()),
+                                                 ctypes.c_void_p(ws.data_ptr()), self.nbytes, stream), "dba_ba_solve_skyline")
+        torch.cuda.synchronize()
+        dx = ws[lay.dx:lay.dx + 4 * n].view(torch.float32).cpu().numpy().copy()
+        return dx, int(ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()[1])
+
+
+def _ref(H, b, lm=1e-4, ep=0.1):
+    return np.linalg.solve(H + np.diag(ep + lm * np.diag(H)), b)
+
+
+@pytest.mark.parametrize("P,w", [(1, 0), (2, 1), (3, 2), (8, 4), (16, 3), (23, 4), (24, 4), (24, 3), (24, 1), (24, 0), (25, 4),
+                                  (29, 4), (33, 4), (40, 4), (63, 4), (64, 3)])
+def test_window_kernel_solves_banded_systems(P, w):
+    rng = np.random.default_rng(7 * P + w)
+    H, b, fpose = _pose_system(rng, P, w)
+    dx, failed = _SkylineSolver(P).solve(H, b, fpose)
+    ref = _ref(H, b)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("P,w,extra", [(24, 5, ()), (24, 7, ()), (24, 23, ()), (24, 2, ((20, 3),)), (40, 6, ()), (63, 9, ()),
+                                        (63, 2, ((60, 1),))])
+def test_systems_that_are_not_banded_are_solved_in_the_same_launch_and_then_by_the_other_kernels(P, w, extra):
+    """the window kernel's admission test refuses these: the general kernel's code solves them inside its launch (first solve
+    on a workspace), the pinned verdict sends the workspace's next solves to the register-tile / skyline kernels; a banded
+    system on that workspace is then still solved (by whichever kernel gets it), and every 32nd solve probes the window kernel"""
+    rng = np.random.default_rng(11 * P + w)
+    H, b, fpose = _pose_system(rng, P, w, extra=extra)
+    S = _SkylineSolver(P)
+    ref = _ref(H, b)
+    for rep in range(3):
+        dx, failed = S.solve(H, b, fpose)
+        assert failed == 0, rep
+        np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()), err_msg="solve %d" % rep)
+    Hb, bb, fb = _pose_system(rng, P, 3)
+    refb = _ref(Hb, bb)
+    for rep in range(34):            # (past the probe)
+        dx, failed = S.solve(Hb, bb, fb)
+        assert failed == 0
+        np.testing.assert_allclose(dx, refb, rtol=0, atol=3e-7 * max(1.0, np.abs(refb).max()), err_msg="banded solve %d" % rep)
+
+
+@pytest.mark.parametrize("P,w", [(5, 2), (24, 4), (29, 4), (63, 4), (24, 7)])
+def test_window_kernel_and_its_fall_back_give_a_zero_update_for_an_indefinite_system(P, w):
+    rng = np.random.default_rng(P)
+    H, b, fpose = _pose_system(rng, P, w, spd=False)
+    dx, failed = _SkylineSolver(P).solve(H, b, fpose)
+    assert failed == 1 and np.all(dx == 0.0)
+
+
+def test_window_kernel_many_back_to_back_solves_are_identical():
+    """the waves of the kernel meet through flags in LDS, not barriers: 300 solves of one system, each bit-identical to the
+    first (a lost or early flag would show as a different or failed solve)"""
+    rng = np.random.default_rng(3)
+    H, b, fpose = _pose_system(rng, 24, 4)
+    S = _SkylineSolver(24)
+    first, failed = S.solve(H, b, fpose)
+    assert failed == 0
+    for rep in range(300):
+        dx, failed = S.solve(H, b, fpose)
+        assert failed == 0 and np.array_equal(dx, first), rep

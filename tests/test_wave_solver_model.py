@@ -1,0 +1,57 @@
+"""CPU: the lane-level numpy model of the five-wave window solver (tests/wave_solver_model.py <-> csrc/ba_solve_wave.hip) against
+dense solves of the damped system (droid_kernels.cu:1252-1253 damping, :1263-1266 zero update on failure), and the kernel's
+admission test: which skylines stay inside the 48-row window."""
+import numpy as np
+import pytest
+
+from wave_solver_model import WaveSolver, band_ok
+
+
+def _system(P, w, seed, extra=None):
+    """P poses of 6 unknowns, pose p coupled with p-w .. p (+ extra pairs); diagonally dominant; fpose as stage 0 builds it"""
+    rng = np.random.default_rng(seed)
+    n = 6 * P
+    H = np.zeros((n, n))
+    fpose = list(range(P))
+    pairs = [(p, q) for p in range(P) for q in range(max(0, p - w), p + 1)] + list(extra or [])
+    for p, q in pairs:
+        Bk = rng.standard_normal((6, 6)) * 0.3
+        if p == q:
+            Bk = Bk + Bk.T
+        H[6 * p:6 * p + 6, 6 * q:6 * q + 6] += Bk
+        if p != q:
+            H[6 * q:6 * q + 6, 6 * p:6 * p + 6] += Bk.T
+        fpose[p] = min(fpose[p], q)
+    H += np.eye(n) * (np.abs(H).sum(1).max() + 1.0)
+    return H, rng.standard_normal(n), fpose
+
+
+@pytest.mark.parametrize("P,w", [(24, 4), (24, 3), (25, 4), (8, 4), (3, 2), (29, 4), (63, 4), (24, 1), (16, 0), (2, 1), (1, 0)])
+def test_model_solves_banded_systems(P, w):
+    H, b, fpose = _system(P, w, 100 * P + w)
+    assert band_ok(fpose, 6 * P)
+    lm, ep = 1e-4, 0.1
+    ref = np.linalg.solve(H + np.diag(ep + lm * np.diag(H)), b)
+    x, failed = WaveSolver(np.tril(H), b, lm, ep).solve()      # (only the lower triangle is read)
+    assert not failed
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+
+
+def test_admission():
+    """4 poses wide always fits; 5 and more, an arrow (a coupling back to an early pose) and a dense system do not; an extra
+    coupling inside the window does"""
+    for P in (8, 24, 25, 29, 63, 64):
+        assert band_ok(_system(P, 4, 1)[2], 6 * P)
+    assert not band_ok(_system(24, 5, 2)[2], 144)
+    assert not band_ok(_system(24, 6, 3)[2], 144)
+    assert not band_ok(_system(24, 2, 4, extra=[(20, 3)])[2], 144)
+    assert not band_ok(_system(24, 23, 5)[2], 144)
+    assert band_ok(_system(24, 2, 6, extra=[(9, 5)])[2], 144)
+    assert band_ok(_system(24, 3, 7, extra=[(23, 19)])[2], 144)
+
+
+def test_model_reports_an_indefinite_system():
+    H, b, _ = _system(24, 4, 9)
+    H[70, 70] = -5.0
+    x, failed = WaveSolver(np.tril(H), b, 1e-4, 0.1).solve()
+    assert failed and np.all(x == 0.0)

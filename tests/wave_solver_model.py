@@ -1,8 +1,11 @@
-"""Lane-level model of csrc/ba_solve_wave.hip (the one-wave window solver): every array below has one entry per lane of
-the wave, every helper mirrors one hardware operation (the f64 16x16x4 matrix instruction with its operand layouts,
-v_readlane, LDS reads / writes by per-lane address), and the control flow is the kernel's, statement by statement.
-Test infrastructure: tests/test_wave_solver_model.py holds it against a dense Cholesky, which pins the index arithmetic
-of the kernel (panel storage, permuted pivot inverses, window rotation, the substitution ring) without a GPU."""
+"""Lane-level model of csrc/ba_solve_wave.hip (the window solver): every array below has one entry per lane of a wave,
+every helper mirrors one hardware operation (the f64 16x16x4 matrix instruction with its operand layouts, v_readlane, LDS
+reads / writes by per-lane address), and the data flow is the kernel's, statement by statement -- what the kernel spreads
+over three factor waves (one tile row of the window each, roles rotating with the window), a loader and a substitution wave
+is executed here in program order, which changes no index and no value.
+Test infrastructure: tests/test_wave_solver_model.py holds it against dense solves, which pins the index arithmetic of the
+kernel (panel store, pivot block read with indices XOR k and its cofactor inverse, window rotation, the substitution ring)
+and its admission test without a GPU."""
 import numpy as np
 
 LANES = np.arange(64)
@@ -27,30 +30,23 @@ def mfma_16x16x4(a, b, c):
 
 
 def invert_row0(P):
-    """row 0 of the inverse of the symmetric positive definite 4x4 block whose LOWER triangle is P[i][j] (per lane), through
-    2x2 blocks (the formulas of the kernel's wv_invert_row0); returns (w0..w3, ok)"""
+    """row 0 of the inverse of the symmetric positive definite 4x4 block whose LOWER triangle is P[i][j] (per lane), by
+    cofactors (the formulas of the kernel's wv_invert_row0_cof); returns (w0..w3, ok)"""
     a, b, c = P[0][0], P[1][0], P[1][1]
     d, e, f, g = P[2][0], P[2][1], P[3][0], P[3][1]
     h, i, j = P[2][2], P[3][2], P[3][3]
-    detA = a * c - b * b
-    okA = (a > 0) & (detA > 0)
-    iA = np.where(okA, 1.0 / np.where(okA, detA, 1.0), 0.0)
-    a00, a01, a11 = c * iA, -b * iA, a * iA
-    x00, x01 = d * a00 + e * a01, d * a01 + e * a11
-    x10, x11 = f * a00 + g * a01, f * a01 + g * a11
-    s00 = h - (x00 * d + x01 * e)
-    s01 = i - (x00 * f + x01 * g)
-    s11 = j - (x10 * f + x11 * g)
-    detS = s00 * s11 - s01 * s01
-    ok = okA & (s00 > 0) & (detS > 0)
-    iS = np.where(ok, 1.0 / np.where(ok, detS, 1.0), 0.0)
-    t00, t01, t11 = s11 * iS, -s01 * iS, s00 * iS
-    y00, y01 = t00 * x00 + t01 * x10, t00 * x01 + t01 * x11
-    y10, y11 = t01 * x00 + t11 * x10, t01 * x01 + t11 * x11
-    k = np.where(ok, 1.0, 0.0)
-    w0 = k * (a00 + x00 * y00 + x10 * y10)
-    w1 = k * (a01 + x00 * y01 + x10 * y11)
-    return [w0, w1, -y00, -y10], ok
+    m01, m02, m03 = d * g - e * f, d * i - h * f, d * j - i * f      # 2x2 minors of rows 2, 3
+    m12, m13, m23 = e * i - h * g, e * j - i * g, h * j - i * i
+    C0 = c * m23 - e * m13 + g * m12                                 # cofactors of row 0 (rows 1..3 expanded along row 1 = b c e g)
+    C1 = -(b * m23 - e * m03 + g * m02)
+    C2 = b * m13 - c * m03 + g * m01
+    C3 = -(b * m12 - c * m02 + e * m01)
+    det = a * C0 + b * C1 + d * C2 + f * C3
+    det2 = a * c - b * b
+    det3 = d * (b * e - c * d) - e * (a * e - b * d) + h * det2
+    ok = (a > 0) & (det2 > 0) & (det3 > 0) & (det > 0)
+    idet = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+    return [C0 * idet, C1 * idet, C2 * idet, C3 * idet], ok
 
 
 def band_ok(fpose, n):
