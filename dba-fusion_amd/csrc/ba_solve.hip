@@ -19,6 +19,7 @@
 // The backward substitution L^T x = y runs block-wise with the 12x12 triangle solved across lanes.
 #include "ba_kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -122,15 +123,17 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     return (g && g[0] == '1') ? 2 : 0;
   }();
   // banded systems with a skyline table (every call of dba_ba): the five-wave window kernel, unless this workspace's last system
-  // was not banded (then every 32nd solve still goes there, in case the graph has changed back).  DBA_SOLVE_KERNEL=wave forces it.
+  // was not banded (then every 1024th solve still goes there, in case the graph has changed back).  DBA_SOLVE_KERNEL=wave forces it.
   if (!prof && fpose && (forced == 0 || forced == 4) && ba_solve_wave_supported(n)) {
     int *slot = solver_verdict_slot(meta);
-    const int verdict = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
-    const bool probe = slot && verdict == 2 && (++slot[1] & 31) == 0;
-    if (forced == 4 || verdict != 2 || probe) {
-      if (slot && verdict == 2) slot[1] = 0;
-      return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream);
-    }
+    // (a workspace nobody has a verdict for yet -- the window shape changes with every keyframe -- starts from the verdict of
+    // the last workspace that had one: a tracker whose graphs are not banded does not pay the in-launch fall-back per keyframe)
+    static std::atomic<int> last_known{0};
+    int verdict = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
+    if (verdict) last_known.store(verdict, std::memory_order_relaxed);
+    else verdict = last_known.load(std::memory_order_relaxed);
+    const bool probe = slot && verdict == 2 && (++slot[1] & 1023) == 0;   // has the graph become banded again?
+    if (forced == 4 || verdict != 2 || probe) return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream);
   }
   int chained = 0;
   if (!prof && forced <= 1 && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);

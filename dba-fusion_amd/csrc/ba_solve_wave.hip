@@ -1,9 +1,10 @@
-// Damped solve of the reduced camera system of a sliding window: FIVE WAVES, the band's trailing window in matrix-core
+// Damped solve of the reduced camera system of a sliding window: FIVE (SIX) WAVES, the band's trailing window in matrix-core
 // accumulators, no workgroup barrier anywhere.
 //
 // Replaces the host-side Eigen LLT / SimplicialLLT of the reference (/root/reference/src/droid_kernels.cu:200-218
 // solveDenseD, :1248-1269 SparseBlock::solve) for the systems a sliding-window tracker produces: block-banded, 6 x 6 pose
-// blocks, up to four blocks wide (every column ends inside the 48-row window of its tile column: ba_solve_wave_admits).
+// blocks, up to four blocks wide with three factor waves (every column ends inside the 48-row window of its tile column:
+// ba_solve_wave_admits), up to ~seven with four (64 rows; systems up to 45 poses, whose taller panel store still fits LDS).
 // Anything else is solved by the general blocked kernel's code inside the same launch (ba_solve_general.inc), and the host
 // learns the verdict through pinned memory, so that the next solve of that workspace goes to ba_solve_tile.hip /
 // ba_solve_band.hip directly (launch_ba_solve in ba_solve.hip).
@@ -56,17 +57,19 @@ __device__ __forceinline__ double wv_readlane(double v, int l) {  // l wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// LDS, in doubles: panel store [S][48][4] | z of every step [S][4] | right-hand side / solution + flags [np + 64] | the loader's slot
-__device__ __host__ __forceinline__ size_t wv_lds_doubles(int n) {
+// LDS, in doubles: panel store [S][16 NT][4] | z of every step [S][4] | right-hand side / solution + flags [np + 64] | the loader's slot
+__device__ __host__ __forceinline__ size_t wv_lds_doubles(int n, int nt) {
   const int np = (n + 15) & ~15, S = np >> 2;
-  return (size_t)S * (16 * 3 * 4 + 4) + np + 64 + 3 * 4 * 64;
+  return (size_t)S * (16 * nt * 4 + 4) + np + 64 + (size_t)nt * 4 * 64;
 }
 
 // The admission test, by every wave for itself: with the pose-level skyline fpose (first pose a pose is coupled with) made
-// monotone, every column's last row must lie inside the window of its step's tile column: row < 16 (s >> 2) + 48.
-__device__ __forceinline__ bool ba_solve_wave_admits(const int *__restrict__ fpose, int n, int lane) {
+// monotone, every column's last row must lie inside the window of its step's tile column: row < 16 (s >> 2) + 16 NT.
+// Returns the smallest NT in {3, 4} (<= max_nt: the panel store of NT = 4 does not fit LDS for the largest systems) that admits
+// the system, or 0.
+__device__ __forceinline__ int ba_solve_wave_admits(const int *__restrict__ fpose, int n, int lane, int max_nt) {
   const int P = n / 6;
-  if (!fpose || P > 64 || n != 6 * P) return false;
+  if (!fpose || P > 64 || n != 6 * P) return 0;
   int g = (lane < P) ? fpose[lane] : 0x7fffffff;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {  // suffix minimum: fill-in keeps the skyline monotone
@@ -79,14 +82,18 @@ __device__ __forceinline__ bool ba_solve_wave_admits(const int *__restrict__ fpo
     if (gp <= lane) last = max(last, p);
   }
   const int np = (n + 15) & ~15, S = np >> 2;
-  bool ok = true;
+  bool ok3 = true, ok4 = true;
   for (int base = 0; base < S; base += 64) {   // (uniform trip count: the shuffle below is executed by all lanes)
     const int s = base + lane, c = 4 * s;
     const int q3 = min(min(c + 3, n - 1) / 6, P - 1);
     const int lastrow = 6 * __shfl(last, q3, 64) + 5;
-    ok = ok && (!((s < S) && (c < n)) || lastrow <= 16 * (s >> 2) + 47);
+    const bool live = (s < S) && (c < n);
+    ok3 = ok3 && (!live || lastrow <= 16 * (s >> 2) + 47);
+    ok4 = ok4 && (!live || lastrow <= 16 * (s >> 2) + 63);
   }
-  return __ballot(!ok) == 0ull;
+  if (max_nt >= 3 && __ballot(!ok3) == 0ull) return 3;
+  if (max_nt >= 4 && __ballot(!ok4) == 0ull) return 4;
+  return 0;
 }
 
 #ifdef PROFILE_SOLVE
@@ -122,8 +129,8 @@ __device__ __forceinline__ void wv_await(int *flag, int need) {
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int WNT = 3;   // tile rows of the window = factor waves
-
+// NT = tile rows of the window = factor waves: 3 (48 rows: bands up to 4 poses wide) or 4 (64 rows: up to ~7 poses)
+template <int WNT>
 struct WvLayout {   // LDS, in doubles
   static constexpr int PR = 16 * WNT;  // rows of a step's panel store (the window of its tile column)
   static constexpr int PD = PR * 4;    // doubles per step
@@ -136,7 +143,7 @@ struct WvLayout {   // LDS, in doubles
     np = (n + 15) & ~15, S = np >> 2;
     PAN = smem, ZST = PAN + (size_t)S * PD, BV = ZST + 4 * S;
     int *f = (int *)(BV + np + 60);
-    flagW = f, flagE = f + 1, fail = f + 1 + WNT, flagL = f + 2 + WNT, flagC = f + 3 + WNT;
+    flagW = f, flagE = f + 1, fail = f + 1 + WNT, flagL = f + 2 + WNT, flagC = f + 3 + WNT;   // (8 ints at most)
     RING = BV + np + 64;
   }
 };
@@ -207,14 +214,14 @@ __device__ __forceinline__ void wv_invert_row0_cof(double a, double b, double c,
 // tile is finished takes the tile row that enters the window -- brought into LDS by the loader wave, so that no register of a
 // factor wave ever waits for global memory (a prefetch into registers made every loop trip wait: the compiler's copies of the
 // loop-carried registers cannot pass a pending load).
+template <int NT>
 __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane,
                                      int wave, long long *__restrict__ prof) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  constexpr int NT = WNT;
-  const WvLayout L(smem, n);
-  constexpr int PD = WvLayout::PD;
+  const WvLayout<NT> L(smem, n);
+  constexpr int PD = WvLayout<NT>::PD;
   const int S = L.S, TB = S >> 2;
   double *const PAN = L.PAN;
   const int li = lane & 15, lk = lane >> 4;
@@ -356,7 +363,8 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   for (int tb = 0; tb < TB; tb++) {
     if (role == 0) run_column(tb, std::integral_constant<int, 0>{});
     else if (role == 1) run_column(tb, std::integral_constant<int, 1>{});
-    else run_column(tb, std::integral_constant<int, 2>{});
+    else if (role == 2 || NT == 3) run_column(tb, std::integral_constant<int, 2>{});
+    else run_column(tb, std::integral_constant<int, NT - 1>{});
     role = (role == 0) ? NT - 1 : role - 1;
   }
   WPROF(1 + wave);
@@ -364,8 +372,9 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 
 // ---- wave 4: the loader.  Tile row NT + k of the system (the tiles (NT + k, k + 1 .. k + NT): what the window gains when it
 // leaves tile column k) -> the one LDS slot, as soon as the previous occupant has been taken.
+template <int WNT>
 __device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane) {
-  const WvLayout L(smem, n);
+  const WvLayout<WNT> L(smem, n);
   const int TB = L.S >> 2;
   for (int k = 0; k + 1 < TB; k++) {   // (the rotation behind the last tile column brings nothing in)
     wv_d4 t[WNT];
@@ -383,13 +392,14 @@ __device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const dou
 // ---- wave 3: the right-hand side behind the factorisation (z = W b1, b2 -= R z), then the backward substitution,
 // right-looking: lane (slot, k) = (lane >> 2, lane & 3) accumulates v_s[k] = sum_i R_s[i][k] x[i] for the step s = slot
 // (mod 16) that still receives solved unknowns (a window spans at most 4 NT <= 16 steps); x1 = z - W v.
+template <int WNT>
 __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, float *__restrict__ dx, int *__restrict__ meta,
                                     double *__restrict__ smem, int lane, long long *__restrict__ prof) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  const WvLayout L(smem, n);
-  constexpr int PR = WvLayout::PR, PD = WvLayout::PD;
+  const WvLayout<WNT> L(smem, n);
+  constexpr int PR = WvLayout<WNT>::PR, PD = WvLayout<WNT>::PD;
   const int np = L.np, S = L.S;
   double *const PAN = L.PAN, *const ZST = L.ZST, *const BV = L.BV;
   for (int i = lane; i < np + 60; i += 64) {
@@ -489,44 +499,56 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
   WPROF(6);
 }
 
-// the kernel: five waves (three for the factorisation, one for the substitution, one that brings tile rows in).  Every wave
-// runs the admission test (no exchange needed to agree).  A system that is not admitted is solved by the general blocked
-// kernel's code with the same five waves; `verdict` (pinned host memory) tells the host which it was: 1 taken, 2 not.
+// the kernel: NT + 2 waves (NT for the factorisation, one for the substitution, one that brings tile rows in; launched with six,
+// the sixth leaves at once when the system fits the 48-row window).  Every wave runs the admission test (no exchange needed
+// to agree).  A system that is not admitted is solved by the general blocked kernel's code with the same waves; `verdict`
+// (pinned host memory) tells the host which it was: 1 taken, 2 not.
+template <int NT>
+__device__ __forceinline__ void ba_solve_wave_run(const double *__restrict__ H, const double *__restrict__ bvec, int n, double lm,
+                                                  double ep, float *__restrict__ dx, int *__restrict__ meta,
+                                                  double *__restrict__ smem, int lane, int wave, long long *__restrict__ prof) {
+  {
+    const WvLayout<NT> L(smem, n);
+    if (threadIdx.x < 8) L.flagW[threadIdx.x] = 0;   // flagW, flagE[NT], fail, flagL, flagC
+  }
+  __syncthreads();
+  if (wave < NT) ba_solve_wave_factor<NT>(n, smem, H, lm, ep, lane, wave, prof);
+  else if (wave == NT) ba_solve_wave_subst<NT>(bvec, n, dx, meta, smem, lane, prof);
+  else if (wave == NT + 1) ba_solve_wave_loader<NT>(n, smem, H, lm, ep, lane);
+}
+
 template <bool GENERAL_IN_LDS>
-__global__ __launch_bounds__(320) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
+__global__ __launch_bounds__(384) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
                                                             const int *__restrict__ fpose, int n, double lm, double ep,
                                                             float *__restrict__ dx, int *__restrict__ meta,
-                                                            double *__restrict__ Lglobal, int *__restrict__ verdict,
+                                                            double *__restrict__ Lglobal, int *__restrict__ verdict, int max_nt,
                                                             long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) double wv_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool admitted = ba_solve_wave_admits(fpose, n, lane);
+  const int nt = ba_solve_wave_admits(fpose, n, lane, max_nt);
   if (threadIdx.x == 0) {
     meta[3] = 1;   // (solved either way: a kernel queued behind with `skip_if_solved` returns at once)
-    if (verdict) __hip_atomic_store(verdict, admitted ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (verdict) __hip_atomic_store(verdict, nt ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (!admitted) {
-    ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
-    return;
-  }
-  {
-    const WvLayout L(wv_smem, n);
-    if (threadIdx.x < 8) L.flagW[threadIdx.x] = 0;   // flagW, flagE[3], fail, flagL, flagC (+ spare)
-  }
-  __syncthreads();
-  if (wave < WNT) ba_solve_wave_factor(n, wv_smem, H, lm, ep, lane, wave, prof);
-  else if (wave == WNT) ba_solve_wave_subst(bvec, n, dx, meta, wv_smem, lane, prof);
-  else ba_solve_wave_loader(n, wv_smem, H, lm, ep, lane);
+  if (nt == 3) ba_solve_wave_run<3>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, prof);
+  else if (nt == 4) ba_solve_wave_run<4>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, prof);
+  else ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
 }
 
-bool ba_solve_wave_supported(int n) {
-  return n > 0 && n % 6 == 0 && n / 6 <= 64 && wv_lds_doubles(n) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES;
+static int wave_max_nt(int n) {   // the tallest window whose panel store fits LDS for a system of n unknowns (0: none)
+  if (n <= 0 || n % 6 != 0 || n / 6 > 64) return 0;
+  if (wv_lds_doubles(n, 4) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 4;
+  if (wv_lds_doubles(n, 3) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 3;
+  return 0;
 }
+
+bool ba_solve_wave_supported(int n) { return wave_max_nt(n) != 0; }
 
 // Lscratch: the workspace's packed-triangle scratch (needed by the fall-back when the system does not fit LDS: n > 199)
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                          double *Lscratch, int *verdict, hipStream_t stream, long long *prof) {
-  if (!ba_solve_wave_supported(n) || !fpose) return DBA_ERR_UNSUPPORTED;
+  const int max_nt = wave_max_nt(n);
+  if (!max_nt || !fpose) return DBA_ERR_UNSUPPORTED;
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_kernel<true>),
@@ -535,15 +557,15 @@ int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_once.done();
   }
-  const size_t wave_lds = wv_lds_doubles(n) * sizeof(double);
+  const size_t wave_lds = wv_lds_doubles(n, max_nt) * sizeof(double);
   const size_t gen_lds = solve_packed_bytes(n) + solve_small_bytes(n);
   if (gen_lds <= (size_t)SOLVE_MAX_LDS_BYTES) {
-    hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(320), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
-                       ep, dx, meta, Lscratch, verdict, prof);
+    hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(384), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
+                       ep, dx, meta, Lscratch, verdict, max_nt, prof);
   } else {
     if (!Lscratch) return DBA_ERR_WORKSPACE;
-    hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(320), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
-                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, prof);
+    hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(384), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
+                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, max_nt, prof);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

@@ -7,7 +7,7 @@
 #define PROFILE_SOLVE 1
 namespace dba { long long *g_tile_prof; }
 #include "../dba-fusion_amd/csrc/ba_solve_tile.hip"
-#include "ba_solve_wave_experiment.hip"
+#include "../dba-fusion_amd/csrc/ba_solve_wave.hip"
 namespace dba { void set_last_error(const char*, hipError_t) {} }
 static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
   for (int j = 0; j < n; j++) {
@@ -20,6 +20,7 @@ static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std:
   x = b; return true;
 }
 static long long *g_wprof;
+static double *gscr;
 // P poses, pose p coupled with p-w..p (+ one extra pair), spd: make one diagonal entry negative otherwise
 int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
   const int n = 6 * P;
@@ -49,10 +50,10 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
   hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64); hipMalloc(&dfp, P*4);
   hipMemcpy(dH, Hl.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
   hipMemcpy(dfp, fpose.data(), P*4, hipMemcpyHostToDevice); hipMemset(meta, 0, 64); hipMemset(dx, 0xff, n*4);
-  int rc = dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, 0, nullptr);
+  int rc = dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr);
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess || rc) { printf("P=%d launch error %s rc=%d\n", P, hipGetErrorString(e), rc); return 1; }
   std::vector<float> x(n); int hm[8]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 32, hipMemcpyDeviceToHost);
-  if (!hm[3]) { printf("wave P=%2d w=%d extra=(%d,%d): NOT ADMITTED\n", P, w, ex_p, ex_q); return 0; }
+
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
   printf("wave P=%2d n=%3d w=%d extra=(%d,%d) spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", P, n, w, ex_p, ex_q, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
   if (getenv("HARNESS_DUMP")) { for (int i = 0; i < n; i++) if (fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6) printf("    x[%3d] dev % .6e ref % .6e\n", i, x[i], ok ? xr[i] : 0.0); }
@@ -63,12 +64,11 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
     for (int mode = 0; mode < 2; mode++) {
       if (mode == 1 && !dba::ba_solve_tile_supported(n)) continue;
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, 0, g_wprof); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, g_wprof); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
-      if (mode == 0) { long long hp[24]; hipMemcpy(hp, g_wprof, 192, hipMemcpyDeviceToHost); const double S3 = ((n + 15) / 16 * 4) * 200.0 / 3.0, S_ = ((n + 15) / 16 * 4) * 200.0; printf("   shader cycles per step in role 0 / 1 / 2 (mean over the waves; waits included): %.0f / %.0f / %.0f | cycles per step a wave waits on flags: %.0f %.0f %.0f\n", (hp[8]+hp[12]+hp[16])/S3/3, (hp[9]+hp[13]+hp[17])/S3/3, (hp[10]+hp[14]+hp[18])/S3/3, hp[11]/S_, hp[15]/S_, hp[19]/S_); }
       if (mode == 0 && getenv("HARNESS_STEPS_OLD")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
-      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us: [factor waves] load+first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [subst wave] init+forward (behind the factorisation) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100/3, hp[1]/200.0/100, hp[2]/200.0/100, hp[3]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
+      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us (wall clock per wave): [factor waves] load+first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [subst wave] init+forward (behind the factorisation) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100/3, hp[1]/200.0/100, hp[2]/200.0/100, hp[3]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
     }
   }
   hipFree(dH); hipFree(db); hipFree(dx); hipFree(meta); hipFree(dfp);
@@ -76,8 +76,7 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
 }
 int main() {
   hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048);
-  hipMalloc(&g_wprof, 256); hipMemset(g_wprof, 0, 256);
-  { long long *dwp; hipMalloc(&dwp, 64); hipMemset(dwp, 0, 64); hipMemcpyToSymbol(HIP_SYMBOL(dba::g_wv_wait_prof), &dwp, sizeof(dwp)); }
+  hipMalloc(&g_wprof, 256); hipMemset(g_wprof, 0, 256); hipMalloc(&gscr, 8 << 20);
   run(24, 4, true, true); run(24, 3, true, true); run(25, 4, true, true); run(24, 2, true, false); run(24, 1, true, false); run(24, 0, true, false);
   run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
   run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);

@@ -278,12 +278,28 @@ def test_window_kernel_solves_banded_systems(P, w):
     np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("P,w,extra", [(24, 5, ()), (24, 7, ()), (24, 23, ()), (24, 2, ((20, 3),)), (40, 6, ()), (63, 9, ()),
+@pytest.mark.parametrize("P,w", [(24, 5), (24, 6), (24, 7), (12, 7), (40, 6), (45, 5)])
+def test_window_kernel_with_four_factor_waves_takes_wider_bands(P, w):
+    """bands of 5-7 poses: the 64-row window (four factor waves), for systems whose taller panel store fits LDS (<= 45 poses)"""
+    rng = np.random.default_rng(13 * P + w)
+    H, b, fpose = _pose_system(rng, P, w)
+    S = _SkylineSolver(P)
+    dx, failed = S.solve(H, b, fpose)
+    ref = _ref(H, b)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+    first = dx
+    for rep in range(50):
+        dx, failed = S.solve(H, b, fpose)
+        assert failed == 0 and np.array_equal(dx, first), rep
+
+
+@pytest.mark.parametrize("P,w,extra", [(24, 9, ()), (24, 23, ()), (24, 2, ((20, 3),)), (50, 6, ()), (63, 9, ()),
                                         (63, 2, ((60, 1),))])
 def test_systems_that_are_not_banded_are_solved_in_the_same_launch_and_then_by_the_other_kernels(P, w, extra):
     """the window kernel's admission test refuses these: the general kernel's code solves them inside its launch (first solve
     on a workspace), the pinned verdict sends the workspace's next solves to the register-tile / skyline kernels; a banded
-    system on that workspace is then still solved (by whichever kernel gets it), and every 32nd solve probes the window kernel"""
+    system on that workspace is then still solved (by whichever kernel gets it), and every 1024th solve of the workspace probes the window kernel again"""
     rng = np.random.default_rng(11 * P + w)
     H, b, fpose = _pose_system(rng, P, w, extra=extra)
     S = _SkylineSolver(P)

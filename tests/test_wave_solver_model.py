@@ -4,6 +4,7 @@ admission test: which skylines stay inside the 48-row window."""
 import numpy as np
 import pytest
 
+import wave_solver_model as wsm
 from wave_solver_model import WaveSolver, band_ok
 
 
@@ -55,3 +56,20 @@ def test_model_reports_an_indefinite_system():
     H[70, 70] = -5.0
     x, failed = WaveSolver(np.tril(H), b, 1e-4, 0.1).solve()
     assert failed and np.all(x == 0.0)
+
+
+@pytest.mark.parametrize("P,w", [(24, 5), (24, 6), (24, 7), (12, 7), (40, 6)])
+def test_model_with_the_64_row_window(P, w):
+    """four factor waves / tile rows: bands the 48-row window refuses"""
+    H, b, fpose = _system(P, w, 31 * P + w)
+    assert not band_ok(fpose, 6 * P)
+    wsm.set_window(4)
+    try:
+        assert band_ok(fpose, 6 * P)
+        ref = np.linalg.solve(H + np.diag(0.1 + 1e-4 * np.diag(H)), b)
+        x, failed = WaveSolver(np.tril(H), b, 1e-4, 0.1).solve()
+        assert not failed
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+        assert not band_ok(_system(24, 9, 1)[2], 144)
+    finally:
+        wsm.set_window(3)

@@ -11,8 +11,14 @@ import numpy as np
 LANES = np.arange(64)
 LI = LANES & 15          # column of the C / D layout, row of the A layout, column of the B layout
 LK = LANES >> 4          # row group of the C / D layout, k of the A and B layouts
-NT = 3                   # tile rows of the window (16 rows each)
+NT = 3                   # tile rows of the window (16 rows each): 3 or 4 in the kernel (set_window)
 PAN_ROWS = 16 * NT
+
+
+def set_window(nt):
+    """the kernel's template parameter: 3 (48-row window) or 4 (64 rows, four factor waves)"""
+    global NT, PAN_ROWS
+    NT, PAN_ROWS = nt, 16 * nt
 
 
 def mfma_16x16x4(a, b, c):
@@ -109,7 +115,7 @@ class WaveSolver:
     def factor(self):
         S = self.S
         acc = {(ti, tj): self.load_tile(ti, tj) for ti in range(NT) for tj in range(ti + 1)}
-        nxt = [self.load_tile(3, 1), self.load_tile(3, 2), self.load_tile(3, 3)]
+        nxt = [self.load_tile(NT, 1 + j) for j in range(NT)]
         self.extract(0, acc)
         for s in range(S):
             tb, q = s >> 2, s & 3
@@ -149,9 +155,12 @@ class WaveSolver:
             self.ZST[s] = z
             # 7. the window moves on by one tile column
             if q == 3:
-                acc[(0, 0)], acc[(1, 0)], acc[(1, 1)] = acc[(1, 1)], acc[(2, 1)], acc[(2, 2)]
-                acc[(2, 0)], acc[(2, 1)], acc[(2, 2)] = nxt
-                nxt = [self.load_tile(tb + 4, tb + 2), self.load_tile(tb + 4, tb + 3), self.load_tile(tb + 4, tb + 4)]
+                for ti in range(NT - 1):
+                    for tj in range(ti + 1):
+                        acc[(ti, tj)] = acc[(ti + 1, tj + 1)]
+                for j in range(NT):
+                    acc[(NT - 1, j)] = nxt[j]
+                nxt = [self.load_tile(tb + 1 + NT, tb + 2 + j) for j in range(NT)]
             # 8. next step's panel
             if s + 1 < S:
                 self.extract(s + 1, acc)
