@@ -183,10 +183,11 @@ __device__ __forceinline__ wv_d4 wv_load_tile(const double *__restrict__ H, int 
 
 // Row 0 of the inverse of a symmetric positive definite 4 x 4 block (lower triangle a b c / d e h / f g i j) by cofactors:
 // the six 2 x 2 minors of rows 2, 3 serve the four 3 x 3 cofactors of row 0; det = sum_j A[0][j] C[0][j].  35 operations, 13
-// deep (the 2 x 2-block route: 42, 26 deep), on the chain of every step.  ok: the leading minors of orders 1, 2 and the
-// determinant are positive and so is the order-3 minor of rows / columns 0..2 (Sylvester).
+// deep (the 2 x 2-block route: 42, 26 deep), on the chain of every step.  pmin collects the smallest leading minor seen
+// (orders 1, 2, 3 and the determinant: all positive <=> positive definite, Sylvester); the verdict is drawn from it off the
+// chain, once per tile column.  A block that is not positive definite gives garbage here and a failed solve there.
 __device__ __forceinline__ void wv_invert_row0_cof(double a, double b, double c, double d, double e, double f, double g, double h,
-                                                   double i, double j, double (&w)[4], bool &ok) {
+                                                   double i, double j, double (&w)[4], double &pmin) {
   // rows: r0 = (a b d f), r1 = (b c e g), r2 = (d e h i), r3 = (f g i j)
   const double m01 = fma(d, g, -(e * f));   // |r2 r3| columns (0,1)
   const double m02 = fma(d, i, -(h * f));   // (0,2)
@@ -202,8 +203,8 @@ __device__ __forceinline__ void wv_invert_row0_cof(double a, double b, double c,
   const double det = fma(a, C0, fma(b, C1, fma(d, C2, f * C3)));
   const double det2 = fma(a, c, -(b * b));
   const double det3 = fma(d, fma(b, e, -(c * d)), fma(-e, fma(a, e, -(b * d)), h * det2));   // rows / columns 0..2
-  ok = (a > 0.0) && (det2 > 0.0) && (det3 > 0.0) && (det > 0.0);
-  const double id = ok ? wv_rcp(det) : 0.0;   // a failed block contributes nothing; the verdict is collected separately
+  pmin = fmin(fmin(pmin, a), fmin(det2, fmin(det3, det)));
+  const double id = wv_rcp(det);
   w[0] = C0 * id, w[1] = C1 * id, w[2] = C2 * id, w[3] = C3 * id;
 }
 
@@ -265,6 +266,20 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   wv_publish(L.flagE + wave, 1);
   WPROF(0);
 
+  double pmin = 1.0, wkeep[4] = {0.0, 0.0, 0.0, 0.0};
+  // role 0, after its matrix instruction has been issued: W takes the pivot block's place in the panel store, the others may go
+  auto publish_w = [&](int s, bool last_of_column) {
+    const int cl = 4 * (s & 3);
+    double *const pan = PAN + (size_t)s * PD;
+    if (last_of_column) {   // the verdict on this wave's four pivot blocks, before the step's W is announced
+      if (__ballot(!(pmin > 0.0)) != 0ull && lane == 0) *(wv_lds_vint *)L.fail = 1;
+    }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) pan[(cl + lk) * 4 + (lk ^ j)] = wkeep[j];
+    }
+    wv_publish(L.flagW, s + 1);
+  };
   // the part of a step every variant shares: W (computed or fetched), the operands; returns whether this tile row is touched
   auto operands = [&](int s, auto rc, double &av, auto &uv) {
     constexpr int R = decltype(rc)::value;
@@ -272,14 +287,9 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     double *const pan = PAN + (size_t)s * PD;
     double w[4];
     if constexpr (R == 0) {
-      bool ok;
-      wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, ok);
-      if (__ballot(!ok) != 0ull && lane == 0) *(wv_lds_vint *)L.fail = 1;
-      if (li == 0) {   // W takes the pivot block's place in the panel store
+      wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, pmin);
 #pragma unroll
-        for (int j = 0; j < 4; j++) pan[(cl + lk) * 4 + (lk ^ j)] = w[j];
-      }
-      wv_publish(L.flagW, s + 1);
+      for (int j = 0; j < 4; j++) wkeep[j] = w[j];   // (stored and published after the matrix instruction is under way)
     } else {
       wv_await(L.flagW, s + 1);
 #pragma unroll
@@ -319,6 +329,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 #pragma unroll
         for (int j = 0; j <= R; j++) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, uv[j], T[j], 0, 0, 0);
       }
+      if constexpr (R == 0) publish_w(s, false);
       extract(s + 1, R, T[0]);
       if constexpr (R == 0) {
         wv_order();
@@ -346,6 +357,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 #pragma unroll
       for (int j = 1; j <= R; j++) T[j - 1] = T[j];
     } else {                  // the pivot tile is finished: take the tile row that enters the window from the loader's slot
+      publish_w(s, true);
       if (more) {
         wv_await(L.flagL, tb + 1);
         const double *ring = L.RING;
