@@ -234,7 +234,9 @@ class ShardedWindow:
             alpha, motion_only):
         d = self._on(poses.device)
         eta2 = eta.reshape(-1, eta.shape[-2], eta.shape[-1])
-        eta_loc = eta2 if eta2.shape[0] == 1 else eta2.index_select(0, d["eta_rows"]).contiguous()
+        # (one rank: every row of the global damping is this rank's, in order -- nothing to select)
+        whole = self.world == 1 and eta2.shape[0] == len(self.eta_rows)
+        eta_loc = eta2 if (eta2.shape[0] == 1 or whole) else eta2.index_select(0, d["eta_rows"]).contiguous()
         n6 = 6 * (self.t1 - self.t0)
         # the whole call as ONE enqueued sequence of the library (stage 0, front / exchange / back per iteration, depth
         # all-gather): whenever the exchange is something the library can issue itself -- nothing (one rank), its own RCCL

@@ -627,13 +627,15 @@ def test_ba_solver_plan_of_a_64_pose_window_is_learnt_from_the_first_solve():
 
 
 def test_ba_general_size_solver_path_matches_too():
-    """Window-sized systems take the register-tile LDL^T (csrc/ba_solve_tile.hip); the general-size blocked
-    Cholesky (csrc/ba_solve.hip) stays reachable with DBA_SOLVE_GENERAL=1 and must pass the same parity cases."""
+    """Every solver kernel behind the same parity cases: DBA_SOLVE_KERNEL = general (blocked Cholesky, csrc/ba_solve.hip) |
+    band (skyline kernel, csrc/ba_solve_band.hip) | tile (register-tile LDL^T, csrc/ba_solve_tile.hip)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for kernel in ("general", "band"):  # the skyline kernel (csrc/ba_solve_band.hip) serves 30..64-pose windows by default
+    # (banded windows go to the five-wave window kernel by default, csrc/ba_solve_wave.hip; the register-tile, skyline and
+    # general kernels serve the other structures and must pass the same parity cases)
+    for kernel in ("general", "band", "tile"):
         env = dict(os.environ, DBA_SOLVE_KERNEL=kernel)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
                             os.path.join(here, "test_gpu_ba.py"), os.path.join(here, "test_gpu_solve.py"),
