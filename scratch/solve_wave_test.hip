@@ -7,7 +7,11 @@
 #define PROFILE_SOLVE 1
 namespace dba { long long *g_tile_prof; }
 #include "../dba-fusion_amd/csrc/ba_solve_tile.hip"
+#ifdef TWO_FRONTS   // the shelved eight-wave / two-front variant (profiles/SOLVER_NOTES.md): hipcc -DTWO_FRONTS -I../dba-fusion_amd/csrc
+#include "ba_solve_wave_two_fronts.hip"
+#else
 #include "../dba-fusion_amd/csrc/ba_solve_wave.hip"
+#endif
 namespace dba { void set_last_error(const char*, hipError_t) {} }
 static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
   for (int j = 0; j < n; j++) {
@@ -64,11 +68,13 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
     for (int mode = 0; mode < 2; mode++) {
       if (mode == 1 && !dba::ba_solve_tile_supported(n)) continue;
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, g_wprof); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
       if (mode == 0 && getenv("HARNESS_STEPS_OLD")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
-      if (mode == 0) { long long hp[8]; hipMemcpy(hp, g_wprof, 64, hipMemcpyDeviceToHost); printf("   wave stages us (wall clock per wave): [factor waves] load+first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [subst wave] init+forward (behind the factorisation) %.2f backward %.2f verdict+store %.2f\n", hp[0]/200.0/100/3, hp[1]/200.0/100, hp[2]/200.0/100, hp[3]/200.0/100, hp[4]/200.0/100, hp[5]/200.0/100, hp[6]/200.0/100); }
+      if (mode == 0) { for (int it = 0; it < 200; it++) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, g_wprof); (void)hipDeviceSynchronize(); long long hp[32]; hipMemcpy(hp, g_wprof, 256, hipMemcpyDeviceToHost); auto u = [&](int i) { return hp[i]/200.0/100; };
+        printf("   stages us (wall clock per wave; one front: top only): top factor load %.2f w0 %.2f w1 %.2f w2 %.2f | bottom factor load %.2f w0 %.2f w1 %.2f w2 %.2f | separator factor load %.2f w0 %.2f w1 %.2f w2 %.2f\n", u(0)/3, u(1), u(2), u(3), u(8)/3, u(9), u(10), u(11), u(12)/3, u(13), u(14), u(15));
+        printf("          top subst: init+forward %.2f separator (wait, forward, backward) %.2f backward %.2f wait for bottom + store %.2f | bottom subst: init+forward %.2f wait for the separator %.2f backward %.2f\n", u(4), u(5), u(7), u(6), u(20), u(21), u(22)); }
     }
   }
   hipFree(dH); hipFree(db); hipFree(dx); hipFree(meta); hipFree(dfp);
@@ -76,7 +82,7 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
 }
 int main() {
   hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048);
-  hipMalloc(&g_wprof, 256); hipMemset(g_wprof, 0, 256); hipMalloc(&gscr, 8 << 20);
+  (void)hipMalloc(&g_wprof, 256); (void)hipMemset(g_wprof, 0, 256); hipMalloc(&gscr, 8 << 20);
   run(24, 4, true, true); run(24, 3, true, true); run(25, 4, true, true); run(24, 2, true, false); run(24, 1, true, false); run(24, 0, true, false);
   run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
   run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);

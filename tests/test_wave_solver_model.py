@@ -73,3 +73,35 @@ def test_model_with_the_64_row_window(P, w):
         assert not band_ok(_system(24, 9, 1)[2], 144)
     finally:
         wsm.set_window(3)
+
+
+@pytest.mark.parametrize("P,w,nt", [(24, 4, 3), (24, 3, 3), (25, 4, 3), (29, 4, 3), (23, 2, 3), (16, 4, 3), (40, 4, 3), (63, 4, 3),
+                                     (24, 5, 4), (24, 6, 4), (40, 6, 4), (24, 1, 3), (12, 4, 3)])
+def test_model_two_fronts_around_a_separator(P, w, nt):
+    """the top and the bottom part eliminated independently (the bottom one in reverse order), the separator's system assembled
+    from what both leave of it, the three solutions stitched together"""
+    H, b, fpose = _system(P, w, 57 * P + w)
+    wsm.set_window(nt)
+    try:
+        plan = wsm.split_plan(fpose, 6 * P)
+        if P >= 16:
+            assert plan is not None
+        if plan is None:
+            pytest.skip("no separator for this system: one front")
+        a_t, sep, a_b = plan
+        assert a_t % 4 == 0 and a_b % 4 == 0 and sep % 4 == 0 and a_t + sep + a_b == 6 * P + ((6 * P) & 2)
+        ref = np.linalg.solve(H + np.diag(0.1 + 1e-4 * np.diag(H)), b)
+        x, failed = wsm.TwoFrontSolver(np.tril(H), b, 1e-4, 0.1, fpose).solve()
+        assert not failed
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    finally:
+        wsm.set_window(3)
+
+
+def test_split_plan_refuses_what_two_fronts_cannot_take():
+    assert wsm.split_plan(_system(4, 2, 1)[2], 24) is None                 # too small to be worth it
+    assert wsm.split_plan(_system(24, 2, 2, extra=[(20, 3)])[2], 144) is None   # an arrow: every separator is crossed
+    H, b, fpose = _system(24, 4, 3)
+    H[70, 70] = -5.0
+    x, failed = wsm.TwoFrontSolver(np.tril(H), b, 1e-4, 0.1, fpose).solve()
+    assert failed and np.all(x == 0.0)

@@ -72,21 +72,25 @@ def band_ok(fpose, n):
     return True
 
 
-class WaveSolver:
-    def __init__(self, H, b, lm, ep):
-        self.n = n = H.shape[0]
-        self.H, self.b, self.lm, self.ep = H, b, lm, ep
-        self.np_ = (n + 15) // 16 * 16
+class Instance:
+    """one (sub-)system the waves of the kernel work on: `elem(i, j)` = the damped local matrix (i >= j < nloc; identity padding
+    beyond nloc is added here), `rhs(i)`; `sel` = steps to eliminate (all of them for a complete solve)"""
+
+    def __init__(self, elem, rhs, nloc, sel=None):
+        self.elem, self.nloc = elem, nloc
+        self.np_ = (nloc + 15) // 16 * 16
         self.S = self.np_ // 4
-        self.PAN = np.full((self.S, PAN_ROWS, 4), np.nan)      # LDS: panel storage, NaN = never written
+        self.sel = self.S if sel is None else sel
+        self.PAN = np.full((self.S + 1, PAN_ROWS, 4), np.nan)      # LDS: panel storage, NaN = never written
         self.ZST = np.full((self.S, 4), np.nan)
         self.BV = np.zeros(self.np_ + 64)
-        self.BV[:n] = b
+        self.BV[:nloc] = [rhs(i) for i in range(nloc)]
         self.bad = np.zeros(64, bool)
+        self.acc = None
 
-    # ---- a tile of the damped, padded system in the C layout: reg r, lane -> (16 TI + (lane >> 4) + 4 r, 16 TJ + (lane & 15))
+    # ---- a tile in the C layout: reg r, lane -> (16 TI + (lane >> 4) + 4 r, 16 TJ + (lane & 15))
     def load_tile(self, TI, TJ):
-        n, np_ = self.n, self.np_
+        nloc, np_ = self.nloc, self.np_
         t = np.zeros((4, 64))
         for r in range(4):
             row, col = 16 * TI + LK + 4 * r, 16 * TJ + LI
@@ -94,12 +98,10 @@ class WaveSolver:
                 i, j = row[l], col[l]
                 if i >= np_ or j >= np_:
                     v = 0.0
-                elif i >= n or j >= n:
+                elif i >= nloc or j >= nloc:
                     v = 1.0 if i == j else 0.0
                 else:
-                    v = self.H[max(i, j), min(i, j)]
-                    if i == j:
-                        v += self.ep + self.lm * v
+                    v = self.elem(max(i, j), min(i, j))
                 t[r, l] = v
         return t
 
@@ -113,11 +115,11 @@ class WaveSolver:
                 self.PAN[s_next, rows[m], (LI & 3)[m]] = acc[(t, 0)][r][m]
 
     def factor(self):
-        S = self.S
+        """the first `sel` steps of the elimination, the right-hand side riding along"""
         acc = {(ti, tj): self.load_tile(ti, tj) for ti in range(NT) for tj in range(ti + 1)}
         nxt = [self.load_tile(NT, 1 + j) for j in range(NT)]
         self.extract(0, acc)
-        for s in range(S):
+        for s in range(self.sel):
             tb, q = s >> 2, s & 3
             cl, c = 4 * q, 4 * s
             pan = self.PAN[s]
@@ -161,33 +163,132 @@ class WaveSolver:
                 for j in range(NT):
                     acc[(NT - 1, j)] = nxt[j]
                 nxt = [self.load_tile(tb + 1 + NT, tb + 2 + j) for j in range(NT)]
-            # 8. next step's panel
-            if s + 1 < S:
+            # 8. next step's panel (the kernel stops at the last eliminated step; one more here is harmless)
+            if s + 1 < self.S:
                 self.extract(s + 1, acc)
+        self.acc = acc
 
-    def substitute(self):
-        S = self.S
+    def dump(self, a, sep):
+        """after a partial elimination (a = 4 sel): the lower triangle of the block [a, a + sep)^2 out of the window's tiles
+        (tile (ti, tj) of the window sits at tile row / column (a >> 4) + ti / tj of the local system)"""
+        tb = a >> 4
+        D = np.full((sep, sep), np.nan)
+        for (ti, tj), t in self.acc.items():
+            for r in range(4):
+                row, col = 16 * (tb + ti) + LK + 4 * r, 16 * (tb + tj) + LI
+                for l in range(64):
+                    i, j = row[l] - a, col[l] - a
+                    if 0 <= j <= i < sep:
+                        D[i, j] = t[r, l]
+        assert not np.isnan(D[np.tril_indices(sep)]).any()
+        return D
+
+    def substitute(self, given=None):
+        """backward substitution over all steps; `given`: the unknowns behind the eliminated part (local 4 sel ...), solved
+        elsewhere -- their steps only hand their values on"""
+        Sx = self.S if given is None else self.sel + (len(given) + 3) // 4
         slot, k = LANES >> 2, LANES & 3
         v = np.zeros(64)
         x = np.zeros(self.np_ + 64)
-        for sp in range(S - 1, -1, -1):
-            tbp, clp, cp = sp >> 2, 4 * (sp & 3), 4 * sp
-            vk = np.array([v[4 * (sp & 15) + m] for m in range(4)])          # v_readlane
-            Wf = self.PAN[sp, clp:clp + 4, :]
-            x1 = self.ZST[sp] - Wf @ vk
-            x[cp:cp + 4] = x1
+        if given is not None:
+            x[4 * self.sel:4 * self.sel + len(given)] = given
+        for sp in range(Sx - 1, -1, -1):
+            clp, cp = 4 * (sp & 3), 4 * sp
+            if sp < self.sel:
+                vk = np.array([v[4 * (sp & 15) + m] for m in range(4)])          # v_readlane
+                Wf = self.PAN[sp, clp:clp + 4, :]
+                x1 = self.ZST[sp] - Wf @ vk
+                x[cp:cp + 4] = x1
+            else:
+                x1 = x[cp:cp + 4].copy()
             d = (sp - 1 - slot) & 15
             s = sp - 1 - d
             lrow = cp - 16 * (s >> 2)
-            valid = (s >= 0) & (lrow + 3 <= PAN_ROWS - 1)
+            valid = (s >= 0) & (s < self.sel) & (lrow + 3 <= PAN_ROWS - 1)
             for l in range(64):
                 if valid[l]:
                     v[l] += self.PAN[s[l], lrow[l]:lrow[l] + 4, k[l]] @ x1
             v[slot == (sp & 15)] = 0.0
-        return x[:self.n]
+        return x
+
+
+class WaveSolver:
+    """the whole system on one front (what the kernel does when it finds no separator)"""
+
+    def __init__(self, H, b, lm, ep):
+        self.n = n = H.shape[0]
+        self.inst = Instance(lambda i, j: H[i, j] + ((ep + lm * H[i, j]) if i == j else 0.0), lambda i: b[i], n)
 
     def solve(self):
-        self.factor()
-        x = self.substitute()
-        failed = self.bad.any() or not np.isfinite(x).all()
+        self.inst.factor()
+        x = self.inst.substitute()[:self.n]
+        failed = self.inst.bad.any() or not np.isfinite(x).all()
         return (np.zeros(self.n) if failed else x), failed
+
+
+# ---- two fronts around a separator: the model of scratch/ba_solve_wave_two_fronts.hip (built, correct, slower than one front:
+# profiles/SOLVER_NOTES.md); kept because the instance form above is also how the product kernel's arithmetic is pinned
+def split_plan(fpose, n):
+    """the kernel's decision (ba_solve_wave_split): the system padded to n4 = n + (n & 2) unknowns (identity behind the last one),
+    top part [0, a_t) | separator [a_t, a_t + sep) | bottom part [a_t + sep, n4).  The smallest separator (a multiple of 4) such
+    that no column of the top part reaches the bottom part, both blocks [a, a + sep) lie inside the window that is left when
+    a front stops, and the bottom part -- eliminated in REVERSE order -- passes the window test too.  None: one front."""
+    P = len(fpose)
+    g = np.minimum.accumulate(np.asarray(fpose)[::-1])[::-1]
+    last = np.array([max(p for p in range(P) if g[p] <= q) for q in range(P)])
+    n4 = n + (n & 2)
+    for sep in range(4, PAN_ROWS - 12 + 1, 4):
+        a_t = ((n4 - sep) // 2) & ~3
+        a_b = n4 - sep - a_t
+        if a_t < 16 or a_b < 16:
+            return None
+        if 6 * last[(a_t - 1) // 6] + 5 >= a_t + sep:                    # a top column reaches past the separator
+            continue
+        if 4 * ((a_t // 4) % 4) + sep > PAN_ROWS or 4 * ((a_b // 4) % 4) + sep > PAN_ROWS:
+            continue
+        ok = True
+        for s in range(a_b // 4):                                         # the bottom part's own window test, reversed order
+            omin = n4 - 1 - (4 * s + 3)
+            first = 6 * g[omin // 6] if omin < n else omin
+            if (n4 - 1 - first) > 16 * (s >> 2) + PAN_ROWS - 1:
+                ok = False
+        if ok:
+            return a_t, sep, a_b
+    return None
+
+
+class TwoFrontSolver:
+    def __init__(self, H, b, lm, ep, fpose):
+        self.n, self.H, self.b, self.lm, self.ep = H.shape[0], H, b, lm, ep
+        self.plan = split_plan(fpose, self.n)
+
+    def _elem(self, o_r, o_c):          # damped, padded system in ORIGINAL indices, o_r >= o_c
+        n = self.n
+        if o_r >= n:
+            return 1.0 if o_r == o_c else 0.0
+        v = self.H[o_r, o_c]
+        return v + (self.ep + self.lm * v) if o_r == o_c else v
+
+    def solve(self):
+        n, n4 = self.n, self.n + (self.n & 2)
+        a_t, sep, a_b = self.plan
+        rhs = lambda o: self.b[o] if o < n else 0.0                      # noqa: E731
+        top = Instance(lambda i, j: self._elem(i, j), rhs, a_t + sep, sel=a_t // 4)
+        # bottom: local i' <-> original n4 - 1 - i' (lower triangle of the reversed matrix = upper of the original = its mirror)
+        bot = Instance(lambda i, j: self._elem(n4 - 1 - j, n4 - 1 - i), lambda i: rhs(n4 - 1 - i), a_b + sep, sel=a_b // 4)
+        top.factor()
+        bot.factor()
+        Dt, Db = top.dump(a_t, sep), bot.dump(a_b, sep)
+        # separator: both dumps hold the damped original block plus their own front's update
+        def selem(i, j):
+            return Dt[i, j] + Db[sep - 1 - j, sep - 1 - i] - self._elem(a_t + i, a_t + j)
+        def srhs(i):
+            return top.BV[a_t + i] + bot.BV[a_b + sep - 1 - i] - rhs(a_t + i)
+        mid = Instance(selem, srhs, sep)
+        mid.factor()
+        xs = mid.substitute()[:sep]
+        xt = top.substitute(given=xs)[:a_t]
+        xb = bot.substitute(given=xs[::-1])[:a_b]
+        x = np.concatenate([xt, xs, xb[::-1]])[:n]
+        failed = top.bad.any() or bot.bad.any() or mid.bad.any() or not np.isfinite(x).all()
+        return (np.zeros(n) if failed else x), failed
