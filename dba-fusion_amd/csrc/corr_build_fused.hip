@@ -41,6 +41,10 @@
 //   * target map in blocks of 8 channels (a half wave's fragment load = 512 contiguous bytes): no change;
 //   * staggered start of the two co-resident workgroups, 4-deep fragment prefetch: no change.
 // Halving the fragment traffic needs a 128-pixel tile (132 KB of LDS, one workgroup per CU).
+// Operands (round 5): where 16-byte pieces of the maps are aligned (map width a multiple of 8) the strip-walking form reads
+// the caller's [n][C][h][w] maps as they lie (NATIVE below) -- the two fmap_pixel_major_kernel launches (20 us each per 32
+// edges at 64x64) and their scratch traffic are gone; the kernel itself pays ~1 % for the 32-byte pieces a tiled strip's
+// channel slice consists of (16.9 against 17.6 us per edge end to end; DBA_BUILD_OPERANDS=copy|bnative for the A/B run).
 // Shapes: w2 <= 128, C % 16 == 0, 4 levels, h2 >> 3 >= 1, w2 >> 3 >= 1; anything else takes the unfused path of
 // corr_build.hip + corr_shear_kernel.
 #include <hip/hip_runtime.h>
@@ -80,7 +84,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // reach HBM; consumed before them it only waits for the previous strip's, which have had a whole multiplication to drain.
 // The stores then drain while the next strip is multiplied.  One workgroup per CU (103 KB of LDS, up to 256 registers
 // per lane).
-template <int NT, bool LOOP>
+// NATIVE / NATIVE_B (LOOP form only): A / Bm are the caller's feature maps as they lie, [n][C][h][w] -- no k-block-major copies
+// are made first (a launch and 2 x the map's bytes of traffic less per map and build).  The source operand's 16 KB per strip
+// are read as 16-byte pieces (8 consecutive pixels of one channel, which both pixel orders of the planes keep adjacent), 4
+// channels per thread (threads 0..255), scaled (/ 4: corr.py:67-68) and transposed in registers into the LDS fragment layout's
+// [pixel][4 channels] units; the wave's target fragments -- read once per walk -- go through 2 KB of LDS per wave
+// ([pixel][16 channels], written by halves, read back as fragments).
+template <int NT, bool LOOP, bool NATIVE = false, bool NATIVE_B = NATIVE>
 __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_build_fused_kernel(
     const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm, FusedLevels L, int C, int h1, int w1, int h2, int w2,
     int HW1p, float inv_w1, int strips_per_wg, const int *__restrict__ oslots, int tiled
@@ -130,15 +140,41 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   constexpr int KSL = 8;                           // k-steps of the LOOP form (C = 128)
   half8 bres[LOOP ? KSL : 1][NT];                  // LOOP: the wave's target fragments, resident
   half8 apre[2];                                   // LOOP: this thread's two 16-byte pieces of the next source operand
+  half8 anat[4];                                   // NATIVE: 8 pixels x 4 channels of the next source operand (threads 0..255)
   auto request_a = [&](int strip) {
     const _Float16 *Ae = A + (size_t)e * HW1 * C;
+    if constexpr (NATIVE) {   // thread = (channel group of 4, pixel group of 8: half a tile row, or 8 pixels of the linear order)
+      if (tid < 256) {
+        const int kg = tid >> 3, pg = tid & 7;
+        int yy, xx;
+        sh_pixel_yx(min(strip * 64 + 8 * pg, HW1 - 8), w1, inv_w1, tiled != 0, yy, xx);
+        const _Float16 *src = Ae + (size_t)(4 * kg) * HW1 + yy * w1 + xx;
+#pragma unroll
+        for (int c = 0; c < 4; c++) anat[c] = *reinterpret_cast<const half8 *>(src + (size_t)c * HW1);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int idx = tid + 512 * u, kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
       apre[u] = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(strip * 64 + px, HW1 - 1)) * 16 + hf * 8);
     }
   };
-  auto stage_a = [&](_Float16 *dst) {  // this thread's two pieces -> LDS, fragment layout (see the non-LOOP staging below)
+  auto stage_a = [&](_Float16 *dst) {  // this thread's pieces -> LDS, fragment layout (see the non-LOOP staging below)
+    if constexpr (NATIVE) {
+      if (tid < 256) {
+        const int kg = tid >> 3, pg = tid & 7, kbk = kg >> 2, qq = kg & 1, hf = (kg >> 1) & 1, px = 8 * pg;
+        _Float16 *d = dst + (((((kbk * 2 + qq) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {   // pixel j: its four channels
+          half4 o;
+#pragma unroll
+          for (int c = 0; c < 4; c++) o[c] = anat[c][j];
+          *reinterpret_cast<half4 *>(d + 4 * j) = o * (_Float16)0.25f;   // (corr.py:67-68: both maps / 4, one rounding to half)
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int idx = tid + 512 * u, kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
@@ -152,11 +188,35 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   };
   if constexpr (LOOP) {
     const int ty = min(ty0 + wave, h2 - 1);
+    if constexpr (NATIVE_B) {
+      // k-step ks: 16 channels x 64 targets of row ty = 128 pieces of 8 targets x 1 channel, two per lane
+      const _Float16 *Be = Bm + (size_t)e * HW2 * C + (size_t)ty * w2;
+      const int kq = lane >> 3, tx0 = min(8 * (lane & 7), w2 - 8);
+      half8 raw[KSL][2];
+#pragma unroll
+      for (int ks = 0; ks < KSL; ks++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          raw[ks][u] = *reinterpret_cast<const half8 *>(Be + (size_t)(16 * ks + kq + 8 * u) * HW2 + tx0);
+      _Float16 *scr = T + wave * (64 * 16);   // (the tile's LDS: nothing lives there before the first strip)
+#pragma unroll
+      for (int ks = 0; ks < KSL; ks++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) scr[(8 * (lane & 7) + j) * 16 + kq + 8 * u] = raw[ks][u][j] * (_Float16)0.25f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NT; t++) bres[ks][t] = *reinterpret_cast<const half8 *>(scr + (t * 32 + l31) * 16 + kh);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const _Float16 *bpt = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + t * 32 + l31, HW2 - 1) * 16 + kh;
 #pragma unroll
       for (int ks = 0; ks < KSL; ks++) bres[ks][t] = *reinterpret_cast<const half8 *>(bpt + (size_t)ks * 16 * HW2);
+    }
     }
     // (pinned: left to itself the compiler sinks these loads into the strip loop and re-reads the fragments per strip)
 #pragma unroll
@@ -597,10 +657,28 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
   const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the source pixels in 4 x 16 tiles: the plane's pixel order (common.h)
-  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
-  hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
+  // DBA_BUILD_KERNEL=classic|loop forces one form where both apply (tests, A/B runs); read once per process
+  static const int force = [] {
+    const char *e = getenv("DBA_BUILD_KERNEL");
+    return !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  // the strip walk for every map up to 64 wide at C = 128 (since the row-end quads are stored by the whole wave it also
+  // wins where strips span row ends: 55x55 13.3 against 14.3 us/edge)
+  const bool loop_form = (w2 <= 64 && C == 128 && force != 1);
+  // ... and, where 8-byte pieces of the maps are aligned, straight from the caller's [n][C][h][w] maps
+  // (DBA_BUILD_OPERANDS=copy keeps the k-block-major copies: A/B runs)
+  static const int native_mode = [] {   // 0: copies of both maps, 1: both maps as they lie, 2: the target map only
+    const char *e = getenv("DBA_BUILD_OPERANDS");
+    return !e ? 1 : (e[0] == 'c' ? 0 : (e[0] == 'b' ? 2 : 1));
+  }();
+  const bool native_b = loop_form && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
+  const bool native = native_b && native_mode == 1 && (HW1 % 8 == 0) && (w1 % 8 == 0);
+  if (!native)
+    hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                       static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
+  if (!native_b)
+    hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                       static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
   const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
@@ -611,6 +689,10 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<4, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused_kernel<2, true, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
@@ -623,14 +705,7 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
 #else
 #define FB_PROF_ARG
 #endif
-  // DBA_BUILD_KERNEL=classic|loop forces one form where both apply (tests, A/B runs); read once per process
-  static const int force = [] {
-    const char *e = getenv("DBA_BUILD_KERNEL");
-    return !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'l' ? 2 : 0));
-  }();
-  // the strip walk for every map up to 64 wide at C = 128 (since the row-end quads are stored by the whole wave it also
-  // wins where strips span row ends: 55x55 13.3 against 14.3 us/edge)
-  if (w2 <= 64 && C == 128 && force != 1) {
+  if (loop_form) {
     // strips per workgroup: as many as leave >= ~512 workgroups (two rounds of the 256 CUs), at most 16
     const int nstrips = HW1p / 64;
     const long long rows = (long long)grid.y * n;
@@ -639,8 +714,17 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     if (force == 2 && spw < 2) spw = 2;
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
-    hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
-                       inv_w1, spw, out_slots, tiled FB_PROF_ARG);
+    if (native)
+      hipLaunchKernelGGL((corr_build_fused_kernel<2, true, true>), lgrid, dim3(512), lds, s, static_cast<const _Float16 *>(fmap1),
+                         static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
+                         tiled FB_PROF_ARG);
+    else if (native_b)
+      hipLaunchKernelGGL((corr_build_fused_kernel<2, true, false, true>), lgrid, dim3(512), lds, s, A,
+                         static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
+                         tiled FB_PROF_ARG);
+    else
+      hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
+                         inv_w1, spw, out_slots, tiled FB_PROF_ARG);
   } else if (w2 <= 64) {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
     hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,

@@ -122,13 +122,15 @@ def test_lookup_non_finite_coords_do_not_fault(layout, lookup_kernel):
                                    (1, 16, 48, 64), (1, 16, 18, 71), (2, 16, 20, 44), (1, 16, 9, 128), (1, 16, 16, 16), (1, 16, 12, 128),
                                    (1, 16, 24, 107), (2, 128, 28, 107), (1, 32, 8, 120),
                                    (2, 16, 8, 8), (1, 16, 9, 10), (1, 32, 11, 13), (1, 16, 8, 65), (1, 16, 33, 36),
-                                   (1, 128, 55, 55), (2, 128, 18, 44), (3, 128, 9, 10), (1, 128, 11, 13), (5, 128, 8, 8)])
+                                   (1, 128, 55, 55), (2, 128, 18, 44), (3, 128, 9, 10), (1, 128, 11, 13), (5, 128, 8, 8),
+                                   (2, 128, 24, 40), (1, 128, 20, 32), (3, 128, 8, 16), (1, 128, 30, 56), (2, 128, 12, 48)])
 def test_fused_sheared_build_equals_unfused_pipeline(shape):
     """one-pass MFMA build (GEMM + pooling + shear) == GEMM kernel + 3 pooling passes + shear passes, bit for bit, for
     64-wide maps, maps whose strips span row ends (107, 55, 71, 44 wide), heights that are not multiples of 8 (28,
     55, 18, 20, 9: partial target tiles and the floor sizes of avg_pool2d), the widest supported map (128), the
     smallest ones (8 x 8, 9 x 10, 11 x 13: the store loops' column counters wrap more than once per line there),
-    widths just past a tile size (65, 36), and C = 128 on irregular maps (the strip-walking form with row-end quads)"""
+    widths just past a tile size (65, 36), C = 128 on irregular maps (the strip-walking form with row-end quads), and C = 128
+    on maps whose width is a multiple of 8 (operands read straight from the [n, C, h, w] maps: linear and tiled pixel order)"""
     from dbaf_amd.corr import CorrBlock
     n, C, h, w = shape
     rng = np.random.default_rng(12)
