@@ -187,6 +187,11 @@ def main():
         wt = wt.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
         return ii_n, jj_n, tg, wt
 
+    def caller_graph_fused(m=None):
+        """the same tensors from droid_backends.gather_edges: one launch for the ten of caller_graph (edit 4)"""
+        return droid_backends.gather_edges(tgt_inac, wgt_inac, ii_inac, jj_inac, m_idx if m is None else m, tgt_act, wgt_act,
+                                           ii_act, jj_act)
+
     C = 128
     fmaps = t(syn.make_fmaps(W.B, C, h, w, args.seed + 1000))
 
@@ -244,7 +249,9 @@ def main():
     # graph_mode: "fresh" = the BA gets the tensors caller_graph() just built (the reference's call pattern; the headline),
     #             "same"  = the same caller statements run, but the BA gets the standing tensors (object identity is the only
     #                       difference: what a fresh graph costs THIS library), "none" = no caller statements (rounds 1-4),
-    #             "bool"  = fresh, with the literal boolean mask of :243 (synchronises the host)
+    #             "bool"  = fresh, with the literal boolean mask of :243 (synchronises the host),
+    #             "gather" = fresh, built by droid_backends.gather_edges (one launch instead of the statements' ten: a fourth
+    #                       call-site edit, reported next to the headline, not as it)
     fresh_default = "fresh" if shard is None else "none"
 
     def step(i, corr_of=lambda i: corrs[i % ncopies], lookup=None, time_ba=False, pooled=False, graph=None,
@@ -275,7 +282,7 @@ def main():
             c = corr_of(i)(coords1, timing=(ev[4 * i], ev[4 * i + 1]))
         keep[i % ncopies] = c
         if graph_mode != "none" and n_loc > 0:
-            g = caller_graph(m_bool if graph_mode == "bool" else None)
+            g = caller_graph_fused() if graph_mode == "gather" else caller_graph(m_bool if graph_mode == "bool" else None)
             if graph_mode != "same":
                 ii_, jj_, target_, weight_ = g
         if time_ba:
@@ -335,7 +342,7 @@ def main():
     pooled_us = (time.perf_counter() - tp) / max(args.steps, 1) * 1e6
     mode_us = {}
     if shard is None and n_loc > 0:
-        for gm in ("same", "none", "fresh", "bool"):
+        for gm in ("same", "none", "fresh", "bool", "gather"):
             for i in range(min(args.warmup, 3)):
                 step(i, graph_mode=gm)
             torch.cuda.synchronize()
@@ -798,6 +805,8 @@ def main():
                         "step_same_tensor_objects_us": round(mode_us["same"], 1) if mode_us else None,
                         "step_without_caller_tensor_ops_us": round(mode_us["none"], 1) if mode_us else None,
                         "step_bool_mask_sync_us": round(mode_us["bool"], 1) if mode_us else None,
+                        # the caller's ten statements replaced by droid_backends.gather_edges (one launch): a fourth call-site edit
+                        "step_gather_edges_us": round(mode_us["gather"], 1) if mode_us else None,
                         "fresh_vs_same_objects": round(mode_us["fresh"] / mode_us["same"], 4) if mode_us else None,
                         "reprojection": "fused into the lookup launch" if fused else "own launch",
                         "gn_iter_per_s": round(2.0 * updates_per_s, 3),

@@ -198,6 +198,26 @@ int dba_ba_poll_eta_error(int *eta_rows, int *num_kx) {
   return 1;
 }
 
+int dba_ba_gather_edges(const float *target_inac, const float *weight_inac, const int64_t *ii_inac, const int64_t *jj_inac,
+                        int n_inac, const int64_t *sel, int n_sel, const float *target_act, const float *weight_act,
+                        const int64_t *ii_act, const int64_t *jj_act, int n_act, int ht, int wd, float *targets_out,
+                        float *weights_out, int64_t *ii_out, int64_t *jj_out, dba_stream_t stream) {
+  if (n_sel < 0 || n_act < 0 || n_inac < 0 || ht <= 0 || wd <= 0) return DBA_ERR_ARG;
+  if (!sel && n_sel > n_inac) return DBA_ERR_ARG;
+  const int n = n_sel + n_act;
+  if (n == 0) return DBA_OK;
+  if (!targets_out || !weights_out || !ii_out || !jj_out) return DBA_ERR_ARG;
+  if (n_sel > 0 && (!target_inac || !weight_inac || !ii_inac || !jj_inac || n_inac == 0)) return DBA_ERR_ARG;
+  if (n_act > 0 && (!target_act || !weight_act || !ii_act || !jj_act)) return DBA_ERR_ARG;
+  const int HW = ht * wd;
+  hipLaunchKernelGGL(ba_gather_edges_kernel, dim3((HW + 255) / 256, n, 2), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2 *>(target_inac), reinterpret_cast<const float2 *>(weight_inac), ii_inac, jj_inac,
+                     sel, n_sel, n_inac, reinterpret_cast<const float2 *>(target_act), reinterpret_cast<const float2 *>(weight_act),
+                     ii_act, jj_act, HW, targets_out, weights_out, ii_out, jj_out);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
 int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);

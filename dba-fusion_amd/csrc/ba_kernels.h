@@ -96,6 +96,10 @@ __global__ void ba_update_kernel(float *poses, const float *poses_src, float *di
                                  float *dx_out, BaTables T, BaBuffers W, float disp_floor);
 __global__ void ba_copy_dx_kernel(const double *src, float *dst, int n);
 __global__ void ba_copy_f32_kernel(const float *src, float *dst, int n);
+__global__ void ba_gather_edges_kernel(const float2 *tgt_inac, const float2 *wgt_inac, const int64_t *ii_inac, const int64_t *jj_inac,
+                                       const int64_t *sel, int n_sel, int n_inac, const float2 *tgt_act, const float2 *wgt_act,
+                                       const int64_t *ii_act, const int64_t *jj_act, int HW, float *tgt_out, float *wgt_out,
+                                       int64_t *ii_out, int64_t *jj_out);
 
 // damped float64 Cholesky solve of H x = b, one workgroup
 // fpose: optional [n/6] skyline of the system at pose granularity (see BaTables); null = measure it from H

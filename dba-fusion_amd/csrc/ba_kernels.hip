@@ -1623,6 +1623,37 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
   if (dz_out) dz_out[mk] = dz;
 }
 
+// The caller's edge tensors for one BA call, in ONE launch: covisible_graph.py:242-247 + :332-333 concatenate the selected
+// inactive edges and the active ones (ii, jj, target, weight: four index-gathers + four cats) and bring target / weight from
+// [n, h, w, 2] to the planar [n, 2, h, w] the binding takes (two permute + contiguous copies): ten launches of ~3.8 us each on a
+// 96-edge window, for 12 MB of traffic.  Output edge o < n_sel is inactive edge sel[o] (sel null: o), the others are the active
+// edges in order.  grid (pixel chunks of 256, edge, target | weight).
+__global__ __launch_bounds__(256) void ba_gather_edges_kernel(const float2 *__restrict__ tgt_inac, const float2 *__restrict__ wgt_inac,
+                                                              const int64_t *__restrict__ ii_inac, const int64_t *__restrict__ jj_inac,
+                                                              const int64_t *__restrict__ sel, int n_sel, int n_inac,
+                                                              const float2 *__restrict__ tgt_act, const float2 *__restrict__ wgt_act,
+                                                              const int64_t *__restrict__ ii_act, const int64_t *__restrict__ jj_act,
+                                                              int HW, float *__restrict__ tgt_out, float *__restrict__ wgt_out,
+                                                              int64_t *__restrict__ ii_out, int64_t *__restrict__ jj_out) {
+  const int o = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  const bool inac = o < n_sel;
+  // (an index outside the inactive list reads edge 0 and is reported by the host wrapper's range check of `sel` only when the
+  // caller asks for it: torch's own gather would fault here)
+  int64_t src = inac ? (sel ? sel[o] : (int64_t)o) : (int64_t)(o - n_sel);
+  if (inac) src = (src < 0) ? src + n_inac : src;   // (torch's negative indices)
+  if (inac && (src < 0 || src >= n_inac)) src = 0;
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    ii_out[o] = inac ? ii_inac[src] : ii_act[src];
+    jj_out[o] = inac ? jj_inac[src] : jj_act[src];
+  }
+  if (k >= HW) return;
+  const float2 *in = blockIdx.z ? (inac ? wgt_inac : wgt_act) : (inac ? tgt_inac : tgt_act);
+  float *out = blockIdx.z ? wgt_out : tgt_out;
+  const float2 v = in[(size_t)src * HW + k];
+  out[((size_t)o * 2 + 0) * HW + k] = v.x;
+  out[((size_t)o * 2 + 1) * HW + k] = v.y;
+}
+
 __global__ void ba_copy_dx_kernel(const double *__restrict__ src, float *__restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];

@@ -163,6 +163,59 @@ std::vector<torch::Tensor> ba_clamped(torch::Tensor poses, torch::Tensor disps, 
                  disp_floor);
 }
 
+// The edge tensors of one BA call as the reference's caller assembles them (dbaf/covisible_graph.py:242-247, :332-333) in one
+// launch: not a reference binding, see droid_backends.gather_edges
+std::vector<torch::Tensor> gather_edges(torch::Tensor target_inac, torch::Tensor weight_inac, torch::Tensor ii_inac,
+                                        torch::Tensor jj_inac, c10::optional<torch::Tensor> sel, torch::Tensor target,
+                                        torch::Tensor weight, torch::Tensor ii, torch::Tensor jj) {
+  CHECK_INPUT(target_inac);
+  CHECK_INPUT(weight_inac);
+  CHECK_INPUT(ii_inac);
+  CHECK_INPUT(jj_inac);
+  CHECK_INPUT(target);
+  CHECK_INPUT(weight);
+  CHECK_INPUT(ii);
+  CHECK_INPUT(jj);
+  TORCH_CHECK(target.dim() >= 4 && target.size(-1) == 2, "gather_edges: target must be [..., ht, wd, 2]");
+  const int ht = (int)target.size(-3), wd = (int)target.size(-2);
+  auto four = [&](const torch::Tensor &x, const char *name) {
+    TORCH_CHECK(x.dim() >= 4 && x.size(-1) == 2 && x.size(-3) == ht && x.size(-2) == wd && x.scalar_type() == torch::kFloat32,
+                "gather_edges: ", name, " must be float32 [..., ", ht, ", ", wd, ", 2]");
+    return x.reshape({-1, ht, wd, 2});
+  };
+  const torch::Tensor ta = four(target, "target"), wa = four(weight, "weight"), ti = four(target_inac, "target_inac"),
+                      wi = four(weight_inac, "weight_inac");
+  auto idx = [&](const torch::Tensor &x, const char *name) {
+    TORCH_CHECK(x.scalar_type() == torch::kInt64, "gather_edges: ", name, " must be int64");
+    return x.reshape({-1});
+  };
+  const torch::Tensor iia = idx(ii, "ii"), jja = idx(jj, "jj"), iii = idx(ii_inac, "ii_inac"), jji = idx(jj_inac, "jj_inac");
+  const int n_act = (int)ta.size(0), n_inac = (int)ti.size(0);
+  TORCH_CHECK(wa.size(0) == n_act && iia.size(0) == n_act && jja.size(0) == n_act,
+              "gather_edges: target, weight, ii, jj disagree on the number of active edges");
+  TORCH_CHECK(wi.size(0) == n_inac && iii.size(0) == n_inac && jji.size(0) == n_inac,
+              "gather_edges: target_inac, weight_inac, ii_inac, jj_inac disagree on the number of inactive edges");
+  torch::Tensor s;
+  int n_sel = n_inac;
+  if (sel.has_value()) {
+    s = sel->reshape({-1});
+    CHECK_DEVICE(s);
+    if (s.scalar_type() == torch::kBool) s = s.nonzero().reshape({-1});   // (synchronises the host, like `x[mask]` itself)
+    TORCH_CHECK(s.scalar_type() == torch::kInt64, "gather_edges: sel must be int64 indices or a boolean mask");
+    s = s.contiguous();
+    n_sel = (int)s.size(0);
+  }
+  const int n = n_sel + n_act;
+  torch::Tensor tg = torch::empty({n, 2, ht, wd}, target.options()), wt = torch::empty({n, 2, ht, wd}, target.options());
+  torch::Tensor ii_n = torch::empty({n}, ii.options()), jj_n = torch::empty({n}, ii.options());
+  check(dba_ba_gather_edges(ti.data_ptr<float>(), wi.data_ptr<float>(), iii.data_ptr<int64_t>(), jji.data_ptr<int64_t>(), n_inac,
+                            sel.has_value() ? s.data_ptr<int64_t>() : nullptr, n_sel, ta.data_ptr<float>(), wa.data_ptr<float>(),
+                            iia.data_ptr<int64_t>(), jja.data_ptr<int64_t>(), n_act, ht, wd, tg.data_ptr<float>(),
+                            wt.data_ptr<float>(), ii_n.data_ptr<int64_t>(), jj_n.data_ptr<int64_t>(), stream_of(target)),
+        "dba_ba_gather_edges");
+  return {ii_n, jj_n, tg, wt};
+}
+
 // frame_distance (src/droid.cpp:181-197)
 torch::Tensor frame_distance(torch::Tensor poses, torch::Tensor disps, torch::Tensor intrinsics, torch::Tensor ii,
                              torch::Tensor jj, const float beta) {
@@ -387,6 +440,9 @@ PYBIND11_MODULE(_droid_backends_C, m) {
   // bundle adjustment kernels (src/droid.cpp:299-302)
   m.def("ba", &ba, "bundle adjustment");
   m.def("ba_clamped", &ba_clamped, "bundle adjustment + the caller's clamp of the inverse depths");
+  m.def("gather_edges", &gather_edges, "the caller's edge tensors for one ba call (cat of inactive + active, planar target / weight)",
+        pybind11::arg("target_inac"), pybind11::arg("weight_inac"), pybind11::arg("ii_inac"), pybind11::arg("jj_inac"),
+        pybind11::arg("sel"), pybind11::arg("target"), pybind11::arg("weight"), pybind11::arg("ii"), pybind11::arg("jj"));
   m.def("check_async_errors", &raise_pending_eta_error, "raises what an earlier asynchronous call found wrong on the device");
   m.def("frame_distance", &frame_distance, "frame_distance");
   m.def("projmap", &projmap, "projmap");

@@ -20,7 +20,8 @@ from dbaf_amd import _lib
 from dbaf_amd._lib import DBA_F16, DBA_F32
 
 __all__ = ["ba", "ba_extend", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
-           "altcorr_backward", "corr_index_forward", "corr_index_backward", "BACore"]
+           "altcorr_backward", "corr_index_forward", "corr_index_backward", "BACore", "ba_clamped", "gather_edges",
+           "check_async_errors"]
 
 # The compiled adapter (csrc_ext/droid_backends_ext.cpp -> _droid_backends_C.so, `make ext`): the pybind11 module a
 # maintainer would build in place of the reference's src/droid.cpp -- every binding of droid.cpp:297-316 over the same C ABI.
@@ -221,6 +222,53 @@ def ba_clamped(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, 
         raise RuntimeError("ba_clamped: disp_floor must be positive")
     return _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
                motion_only, float(disp_floor))
+
+
+def gather_edges(target_inac, weight_inac, ii_inac, jj_inac, sel, target, weight, ii, jj):
+    """The edge tensors of one BA call as CovisibleGraph.update(use_inactive=True) assembles them
+    (dbaf/covisible_graph.py:242-247: `torch.cat([self.ii_inac[m], self.ii], 0)`, the same for jj, target, weight; :332-333:
+    `target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()`, the same for weight) in ONE launch instead of ten.
+    target_inac, weight_inac [1, n_inac, ht, wd, 2] (or without the leading 1), ii_inac, jj_inac [n_inac]; sel: int64 indices of
+    the inactive edges to take (None: all; a boolean mask is converted with torch's own nonzero, i.e. with its host
+    synchronisation); target, weight [1, n, ht, wd, 2], ii, jj [n]: the active edges.
+    Returns (ii, jj, target, weight) with target, weight [n_sel + n, 2, ht, wd]: the arguments of `ba`.  Not a reference
+    binding: an integration replaces the six statements above by this call."""
+    lib = _lib.load()
+    ht, wd = int(target.shape[-3]), int(target.shape[-2])
+    dev = target.device
+    if not target.is_cuda:
+        raise RuntimeError("gather_edges (MI355X): tensors must be HIP device tensors; no CPU path")
+
+    def five(x, name):
+        if x.shape[-1] != 2 or tuple(x.shape[-3:-1]) != (ht, wd):
+            raise RuntimeError("gather_edges: %s must be [..., %d, %d, 2], got %s" % (name, ht, wd, tuple(x.shape)))
+        return _check(x.reshape(-1, ht, wd, 2), name, torch.float32)
+
+    ta, wa = five(target, "target"), five(weight, "weight")
+    ti, wi = five(target_inac, "target_inac"), five(weight_inac, "weight_inac")
+    iia, jja = _check(ii.reshape(-1), "ii", torch.int64), _check(jj.reshape(-1), "jj", torch.int64)
+    iii, jji = _check(ii_inac.reshape(-1), "ii_inac", torch.int64), _check(jj_inac.reshape(-1), "jj_inac", torch.int64)
+    n_act, n_inac = int(ta.shape[0]), int(ti.shape[0])
+    if wa.shape[0] != n_act or iia.shape[0] != n_act or jja.shape[0] != n_act:
+        raise RuntimeError("gather_edges: target, weight, ii, jj disagree on the number of active edges")
+    if wi.shape[0] != n_inac or iii.shape[0] != n_inac or jji.shape[0] != n_inac:
+        raise RuntimeError("gather_edges: target_inac, weight_inac, ii_inac, jj_inac disagree on the number of inactive edges")
+    if sel is None:
+        n_sel = n_inac
+    else:
+        if sel.dtype == torch.bool:
+            sel = sel.reshape(-1).nonzero().reshape(-1)      # (synchronises the host, like `x[mask]` itself)
+        sel = _check(sel.reshape(-1), "sel", torch.int64)
+        n_sel = int(sel.shape[0])
+    n = n_sel + n_act
+    tg = torch.empty(n, 2, ht, wd, dtype=torch.float32, device=dev)
+    wt = torch.empty(n, 2, ht, wd, dtype=torch.float32, device=dev)
+    ii_n = torch.empty(n, dtype=torch.int64, device=dev)
+    jj_n = torch.empty(n, dtype=torch.int64, device=dev)
+    _lib.check(lib.dba_ba_gather_edges(_ptr(ti), _ptr(wi), _ptr(iii), _ptr(jji), n_inac, _ptr(sel), n_sel, _ptr(ta), _ptr(wa),
+                                       _ptr(iia), _ptr(jja), n_act, ht, wd, _ptr(tg), _ptr(wt), _ptr(ii_n), _ptr(jj_n),
+                                       _stream()), "dba_ba_gather_edges")
+    return ii_n, jj_n, tg, wt
 
 
 def _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,

@@ -92,6 +92,16 @@ int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws
  * Host memory only: no synchronisation.  The adapters poll at the top of every ba call and raise for the earlier one. */
 int dba_ba_poll_eta_error(int *eta_rows, int *num_kx);
 
+/* The edge tensors of one BA call as the reference's caller assembles them (dbaf/covisible_graph.py:242-247: torch.cat of the
+ * selected inactive edges' and the active edges' ii / jj / target / weight; :332-333: target, weight from [n, ht, wd, 2] to the
+ * planar [n, 2, ht, wd] of the binding droid.cpp:301) in one launch instead of ten.  target_* / weight_*: [n_*, ht, wd, 2]
+ * float32; sel: n_sel indices into the inactive list (int64, device; null: its first n_sel edges); outputs: targets_out,
+ * weights_out [n_sel + n_act, 2, ht, wd], ii_out, jj_out [n_sel + n_act] -- the arguments of dba_ba / droid_backends.ba. */
+int dba_ba_gather_edges(const float *target_inac, const float *weight_inac, const int64_t *ii_inac, const int64_t *jj_inac,
+                        int n_inac, const int64_t *sel, int n_sel, const float *target_act, const float *weight_act,
+                        const int64_t *ii_act, const int64_t *jj_act, int n_act, int ht, int wd, float *targets_out,
+                        float *weights_out, int64_t *ii_out, int64_t *jj_out, dba_stream_t stream);
+
 /* stage 1: fused per-source-frame linearisation (projective_transform_kernel :220-468 +
  * accum_kernel :899-919 + C/w/Q assembly :1474-1478); also clears H, b.  alpha = 0.05 for
  * droid_backends.ba (:1474), 0.001 for BACore::hessian (:1872). */

@@ -133,3 +133,48 @@ def test_compiled_error_behaviour():
         core.init(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
                   W.t0, W.t1, 2, W.lm, W.ep, False)
         core.hessian(torch.zeros(6, 6, device="cuda", dtype=torch.float64), torch.zeros(6, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("sel_kind", ["index", "none", "mask", "negative"])
+def test_gather_edges_equals_the_callers_statements(sel_kind):
+    """droid_backends.gather_edges (both adapters) == covisible_graph.py:242-247 + :332-333 statement by statement, bit for bit"""
+    db, C = _both()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    h, w, n_in, n_act = 12, 20, 7, 5
+    dev = "cuda"
+    tgt_inac = torch.randn(1, n_in, h, w, 2, generator=g).to(dev)
+    wgt_inac = torch.rand(1, n_in, h, w, 2, generator=g).to(dev)
+    ii_inac = torch.randint(0, 9, (n_in,), generator=g).to(dev)
+    jj_inac = torch.randint(0, 9, (n_in,), generator=g).to(dev)
+    tgt = torch.randn(1, n_act, h, w, 2, generator=g).to(dev)
+    wgt = torch.rand(1, n_act, h, w, 2, generator=g).to(dev)
+    ii = torch.randint(0, 9, (n_act,), generator=g).to(dev)
+    jj = torch.randint(0, 9, (n_act,), generator=g).to(dev)
+    if sel_kind == "index":
+        m = torch.tensor([5, 0, 3], device=dev)
+    elif sel_kind == "negative":
+        m = torch.tensor([-1, 2, -7], device=dev)
+    elif sel_kind == "mask":
+        m = (ii_inac >= 3) & (jj_inac >= 2)            # covisible_graph.py:240
+    else:
+        m = None
+    mm = slice(None) if m is None else m
+    ii_r = torch.cat([ii_inac[mm], ii], 0)
+    jj_r = torch.cat([jj_inac[mm], jj], 0)
+    tg_r = torch.cat([tgt_inac[:, mm], tgt], 1).view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
+    wt_r = torch.cat([wgt_inac[:, mm], wgt], 1).view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
+    for mod in (db, C):
+        ii_n, jj_n, tg, wt = mod.gather_edges(tgt_inac, wgt_inac, ii_inac, jj_inac, m, tgt, wgt, ii, jj)
+        assert torch.equal(ii_n, ii_r) and torch.equal(jj_n, jj_r)
+        assert tg.shape == tg_r.shape and torch.equal(tg.view(torch.int32), tg_r.view(torch.int32))
+        assert torch.equal(wt.view(torch.int32), wt_r.view(torch.int32))
+    # no inactive edges selected / no active edges
+    e = torch.empty(0, dtype=torch.int64, device=dev)
+    ii_n, jj_n, tg, wt = db.gather_edges(tgt_inac, wgt_inac, ii_inac, jj_inac, e, tgt, wgt, ii, jj)
+    assert torch.equal(ii_n, ii) and torch.equal(tg, tgt.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous())
+    ii_n, jj_n, tg, wt = db.gather_edges(tgt_inac, wgt_inac, ii_inac, jj_inac, None, tgt[:, :0], wgt[:, :0], ii[:0], jj[:0])
+    assert torch.equal(jj_n, jj_inac) and torch.equal(wt, wgt_inac.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous())
+    with pytest.raises(RuntimeError):
+        db.gather_edges(tgt_inac, wgt_inac, ii_inac, jj_inac, None, tgt, wgt[:, :2], ii, jj)
+    with pytest.raises(RuntimeError):
+        db.gather_edges(tgt_inac.cpu(), wgt_inac, ii_inac, jj_inac, None, tgt, wgt, ii, jj)
