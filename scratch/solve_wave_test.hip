@@ -73,8 +73,12 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
       printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
       if (mode == 0 && getenv("HARNESS_STEPS_OLD")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
       if (mode == 0) { for (int it = 0; it < 200; it++) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, g_wprof); (void)hipDeviceSynchronize(); long long hp[32]; hipMemcpy(hp, g_wprof, 256, hipMemcpyDeviceToHost); auto u = [&](int i) { return hp[i]/200.0/100; };
+#ifdef TWO_FRONTS
         printf("   stages us (wall clock per wave; one front: top only): top factor load %.2f w0 %.2f w1 %.2f w2 %.2f | bottom factor load %.2f w0 %.2f w1 %.2f w2 %.2f | separator factor load %.2f w0 %.2f w1 %.2f w2 %.2f\n", u(0)/3, u(1), u(2), u(3), u(8)/3, u(9), u(10), u(11), u(12)/3, u(13), u(14), u(15));
         printf("          top subst: init+forward %.2f separator (wait, forward, backward) %.2f backward %.2f wait for bottom + store %.2f | bottom subst: init+forward %.2f wait for the separator %.2f backward %.2f\n", u(4), u(5), u(7), u(6), u(20), u(21), u(22)); }
+#else
+        printf("   stages us (wall clock per wave): [factor waves] load + first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [substitution wave] init + forward (behind the factorisation) %.2f backward %.2f verdict + store %.2f\n", u(0)/3, u(1), u(2), u(3), u(4), u(5), u(6)); }
+#endif
     }
   }
   hipFree(dH); hipFree(db); hipFree(dx); hipFree(meta); hipFree(dfp);

@@ -635,20 +635,18 @@ def test_ba_general_size_solver_path_matches_too():
     here = os.path.dirname(os.path.abspath(__file__))
     # (banded windows go to the five-wave window kernel by default, csrc/ba_solve_wave.hip; the register-tile, skyline and
     # general kernels serve the other structures and must pass the same parity cases)
-    for kernel in ("general", "band", "tile"):
-        env = dict(os.environ, DBA_SOLVE_KERNEL=kernel)
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
-                            os.path.join(here, "test_gpu_ba.py"), os.path.join(here, "test_gpu_solve.py"),
-                            "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd"], env=env,
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, kernel + r.stdout[-2000:] + r.stderr[-2000:]
-    # ... and the register-tile kernel with one elimination front only (two fronts are the default on banded systems)
-    env = dict(os.environ, DBA_SOLVE_TWIST="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
-                        os.path.join(here, "test_gpu_ba.py"), os.path.join(here, "test_gpu_solve.py"),
-                        "-k", "matches_oracle or cholesky_failure or host_cholesky or non_spd or two_front or failing_pivot"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, "one front" + r.stdout[-2000:] + r.stderr[-2000:]
+    # ... and the register-tile kernel with one elimination front only (two fronts are the default on banded systems).
+    # (the four processes share the device: side by side they take as long as one)
+    base = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_ba.py"),
+            os.path.join(here, "test_gpu_solve.py"), "-k"]
+    sel = "matches_oracle or cholesky_failure or host_cholesky or non_spd"
+    runs = [(k, dict(os.environ, DBA_SOLVE_KERNEL=k), sel) for k in ("general", "band", "tile")]
+    runs.append(("one front", dict(os.environ, DBA_SOLVE_TWIST="0"), sel + " or two_front or failing_pivot"))
+    procs = [(name, subprocess.Popen(base + [k], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+             for name, env, k in runs]
+    for name, pr in procs:
+        out, _ = pr.communicate(timeout=900)
+        assert pr.returncode == 0, name + out[-3000:]
 
 
 def _random_graph(rng, num_kf, n_edges, t0, long_range):

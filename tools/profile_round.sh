@@ -5,7 +5,7 @@
 set -u
 TAG=${1:-r03}
 WIN=${2:-25_96}
-KERN=${3:-corr_lookup_sheared}
+KERN=${3:-corr_lookup_rowtile}
 SFX=""; [ "$WIN" != "25_96" ] && SFX="_$WIN"
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
@@ -13,8 +13,8 @@ rm -rf $OUT/${TAG}_trace$SFX $OUT/${TAG}_pmc$SFX   # gpurun merges into an exist
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--window $WIN --steps 60 --warmup 12"
-python $REPO/bench.py $ARGS > $OUT/${TAG}_bench$SFX.json 2> $OUT/${TAG}_bench$SFX.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace$SFX -- python $REPO/bench.py $ARGS --no-cpu-baseline --no-extras > $OUT/${TAG}_trace$SFX.log 2>&1
+timeout 600 python $REPO/bench.py $ARGS > $OUT/${TAG}_bench$SFX.json 2> $OUT/${TAG}_bench$SFX.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace$SFX -- python $REPO/bench.py $ARGS --no-cpu-baseline --no-extras > $OUT/${TAG}_trace$SFX.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_pmc$SFX -o pmc_$(echo $set | cut -c1-5) -- python $REPO/bench.py --window $WIN --steps 6 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
