@@ -63,9 +63,9 @@ python $REPO/scratch/hbm_ceiling.py > $OUT/${TAG}_hbm_ceiling.txt 2>&1
 [ -x $REPO/scratch/bin/lds_rates ] && $REPO/scratch/bin/lds_rates > $OUT/${TAG}_lds_rates.txt 2>&1
 [ -x $REPO/scratch/bin/f64_latency ] && $REPO/scratch/bin/f64_latency > $OUT/${TAG}_f64_latency.txt 2>&1
 # (window solver: per-wave stage times + the matrix instruction's latency; then the register-tile / skyline kernels' stages)
-{ [ -x $REPO/scratch/bin/solve_wave_test ] && timeout 120 $REPO/scratch/bin/solve_wave_test 2>&1 | grep -A3 "P=24 n=144 w=4 extra=(-1,-1) spd=1\|P=29 n=174\|P=63 n=378 w=4 extra=(-1,-1) spd=1\|P=40 n=240\|n=144 w=5"
-  [ -x $REPO/scratch/bin/solve_wave_two_fronts ] && echo "--- shelved two-front variant (scratch/ba_solve_wave_two_fronts.hip)" && timeout 120 $REPO/scratch/bin/solve_wave_two_fronts 2>&1 | grep -A4 "P=24 n=144 w=4 extra=(-1,-1) spd=1\|P=40 n=240"
-  [ -x $REPO/scratch/bin/mfma_f64_lat ] && echo "--- scratch/mfma_f64_lat.hip" && timeout 60 $REPO/scratch/bin/mfma_f64_lat 2>&1 | tail -12
+{ [ -x $REPO/scratch/bin/solve_wave_test ] && timeout 120 $REPO/scratch/bin/solve_wave_test 2>&1 | grep -A3 "P=24 n=144 w=4 extra=(-1,-1) spd=1\|P=29 n=174\|P=63 n=378 w=4 extra=(-1,-1) spd=1\|P=40 n=240\|n=144 w=5" | grep -v "^--\|P=64 n=384"
+  [ -x $REPO/scratch/bin/solve_wave_two_fronts ] && echo "--- shelved two-front variant (scratch/ba_solve_wave_two_fronts.hip)" && timeout 120 $REPO/scratch/bin/solve_wave_two_fronts 2>&1 | grep -A4 "P=24 n=144 w=4 extra=(-1,-1) spd=1\|P=40 n=240" | grep -v "^--\|P=64 n=384"
+  [ -x $REPO/scratch/bin/mfma_f64_lat ] && echo "--- scratch/mfma_f64_lat.hip" && timeout 60 $REPO/scratch/bin/mfma_f64_lat 2>&1 | grep "cycles per link"
   [ -x $REPO/scratch/bin/solve_prof ] && echo "--- register-tile / skyline kernels (scratch/solve_tile_test.hip)" && (HARNESS_BAND=1 timeout 120 $REPO/scratch/bin/solve_prof; timeout 120 $REPO/scratch/bin/solve_prof) 2>&1 | grep -A3 "n=144 band= 24 spd=1\|n=186\|n=378 band= 36"
 } > $OUT/${TAG}_solver_stages.txt
 timeout 120 python $REPO/scratch/build_ab.py $TAG > $OUT/${TAG}_build_shapes.txt 2>&1

@@ -13,7 +13,6 @@ rm -rf $OUT/${TAG}_trace$SFX $OUT/${TAG}_pmc$SFX   # gpurun merges into an exist
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--window $WIN --steps 60 --warmup 12"
-timeout 600 python $REPO/bench.py $ARGS > $OUT/${TAG}_bench$SFX.json 2> $OUT/${TAG}_bench$SFX.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace$SFX -- python $REPO/bench.py $ARGS --no-cpu-baseline --no-extras > $OUT/${TAG}_trace$SFX.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/${TAG}_pmc$SFX -o pmc_$(echo $set | cut -c1-5) -- python $REPO/bench.py --window $WIN --steps 6 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
@@ -41,4 +40,8 @@ json.dump({"kernel": "$KERN", "workload": "$WIN", "copies": 3, "kernel_source_sh
           open("$OUT/${TAG}_pmc_lookup$SFX.json", "w"), indent=1)
 print(open("$OUT/${TAG}_pmc_lookup$SFX.json").read())
 PY
+# the bench line last: it reads the traffic per launch from the round's PMC file under profiles/ (copied there on this box;
+# the builder commits the same file from gpurun_out/)
+cp $OUT/${TAG}_pmc_lookup$SFX.json $REPO/profiles/${TAG}_pmc_lookup$SFX.json
+timeout 600 python $REPO/bench.py $ARGS > $OUT/${TAG}_bench$SFX.json 2> $OUT/${TAG}_bench$SFX.err
 cat $OUT/${TAG}_bench$SFX.json
