@@ -30,9 +30,17 @@
 //     window still receives solved unknowns, so the chain per step is v_readlane -> 4 FMA -> quad broadcast -> 4 FMA;
 //   * the waves meet through monotone counters in LDS (flags written after the data, in program order: the LDS unit executes
 //     a wave's DS instructions in order), never at a barrier.
-// Measured (scratch/solve_wave_test.hip, profiles/r05_solver_stages.txt): n = 144: 30.3 us (register-tile kernel 36.9),
-// n = 174: 36 (57), n = 378: 75 (skyline kernel 101.5).  tests/wave_solver_model.py is the arithmetic and the index logic of
-// this file lane by lane in numpy, pinned against dense solves on the CPU (tests/test_wave_solver_model.py).
+//   * instruction issue is the budget of every wave here, so what the chain wave and the substitution wave do per step was cut by
+//     hand: per-lane addresses are formed once per tile column and the step inside the column sits in the instructions' offset
+//     fields (19 address instructions per step gone from the chain, ~10 from the substitution); a wave that waits for several
+//     flags reads them with ONE 16-byte LDS access instead of one round trip after the other, and polls without sleeping (the
+//     chain passes through such a wake-up once per tile column); the positive-definiteness minors are computed while the next
+//     pivot block's LDS reads are in flight; the substitution's readlane values feed the FMAs from scalar registers (inline asm:
+//     the compiler copied each into a vector register first).  n = 144: 29.5 -> 25.2 us, n = 378: 72.9 -> 62.1 us.
+// Measured (scratch/solve_wave_test.hip, profiles/r05_solver_stages.txt): n = 144: 25.2 us (register-tile kernel 37.0),
+// n = 174: 30.0 (59.5), n = 240: 39.9, n = 378: 62.1 (skyline kernel 101.5-106), 64-row window: 26.7.
+// tests/wave_solver_model.py is the arithmetic and the index logic of this file lane by lane in numpy, pinned against dense
+// solves on the CPU (tests/test_wave_solver_model.py).
 #include "ba_kernels.h"
 
 #include <algorithm>
@@ -128,6 +136,25 @@ __device__ __forceinline__ void wv_await(int *flag, int need) {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
+// N consecutive flags (flag is 16-byte aligned) all >= need: ONE LDS read per look instead of N round trips one after the other
+typedef int wv_i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile wv_i4 wv_lds_vint4;
+template <int N>
+__device__ __forceinline__ void wv_await_all(int *flag, int need) {
+  static_assert(N >= 1 && N <= 5, "flagW and up to four flagE");
+  __builtin_amdgcn_wave_barrier();
+  for (;;) {
+    const wv_i4 v = *(wv_lds_vint4 *)flag;
+    int m = v.x;
+    if (N > 1) m = min(m, v.y);
+    if (N > 2) m = min(m, v.z);
+    if (N > 3) m = min(m, v.w);
+    if (N > 4) m = min(m, *(wv_lds_vint *)(flag + 4));
+    if (m >= need) break;   // (polling without a sleep: these waves have their SIMD to themselves, and the chain passes through
+  }                         // the wake-up of role 1 once per tile column and of the substitution wave at the end)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // NT = tile rows of the window = factor waves: 3 (48 rows: bands up to 4 poses wide) or 4 (64 rows: up to ~7 poses)
 template <int WNT>
@@ -183,11 +210,10 @@ __device__ __forceinline__ wv_d4 wv_load_tile(const double *__restrict__ H, int 
 
 // Row 0 of the inverse of a symmetric positive definite 4 x 4 block (lower triangle a b c / d e h / f g i j) by cofactors:
 // the six 2 x 2 minors of rows 2, 3 serve the four 3 x 3 cofactors of row 0; det = sum_j A[0][j] C[0][j].  35 operations, 13
-// deep (the 2 x 2-block route: 42, 26 deep), on the chain of every step.  pmin collects the smallest leading minor seen
-// (orders 1, 2, 3 and the determinant: all positive <=> positive definite, Sylvester); the verdict is drawn from it off the
-// chain, once per tile column.  A block that is not positive definite gives garbage here and a failed solve there.
+// deep (the 2 x 2-block route: 42, 26 deep), on the chain of every step.  A block that is not positive definite gives garbage
+// here and a failed solve there: wv_pd_minors.
 __device__ __forceinline__ void wv_invert_row0_cof(double a, double b, double c, double d, double e, double f, double g, double h,
-                                                   double i, double j, double (&w)[4], double &pmin) {
+                                                   double i, double j, double (&w)[4], double &det) {
   // rows: r0 = (a b d f), r1 = (b c e g), r2 = (d e h i), r3 = (f g i j)
   const double m01 = fma(d, g, -(e * f));   // |r2 r3| columns (0,1)
   const double m02 = fma(d, i, -(h * f));   // (0,2)
@@ -200,12 +226,17 @@ __device__ __forceinline__ void wv_invert_row0_cof(double a, double b, double c,
   const double C1 = -fma(b, m23, fma(-e, m03, g * m02));
   const double C2 = fma(b, m13, fma(-c, m03, g * m01));
   const double C3 = -fma(b, m12, fma(-c, m02, e * m01));
-  const double det = fma(a, C0, fma(b, C1, fma(d, C2, f * C3)));
+  det = fma(a, C0, fma(b, C1, fma(d, C2, f * C3)));
+  const double id = wv_rcp(det);
+  w[0] = C0 * id, w[1] = C1 * id, w[2] = C2 * id, w[3] = C3 * id;
+}
+// pmin collects the smallest leading minor seen (orders 1, 2, 3 and the determinant: all positive <=> positive definite,
+// Sylvester); the verdict is drawn from it once per tile column.  Not on the chain: the role-0 wave computes it while the next
+// pivot block's LDS reads are in flight.
+__device__ __forceinline__ void wv_pd_minors(double a, double b, double c, double d, double e, double h, double det, double &pmin) {
   const double det2 = fma(a, c, -(b * b));
   const double det3 = fma(d, fma(b, e, -(c * d)), fma(-e, fma(a, e, -(b * d)), h * det2));   // rows / columns 0..2
   pmin = fmin(fmin(pmin, a), fmin(det2, fmin(det3, det)));
-  const double id = wv_rcp(det);
-  w[0] = C0 * id, w[1] = C1 * id, w[2] = C2 * id, w[3] = C3 * id;
 }
 
 // ---- waves 0..2: the factorisation.  Wave w starts as the owner of tile row w of the window (role r = w: tiles (r, 0..r)
@@ -250,6 +281,34 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     for (int j = 0; j < 4; j++) raw0n[j] = PAN[(size_t)sn * PD + li * 4 + (j ^ lk)];
   };
 
+  // The same accesses inside a tile column whose first step's panel lies at `col`: the per-lane part of every address is
+  // formed ONCE per column, the step inside the column (a compile-time q) goes into the instructions' offset fields -- a lone
+  // wave pays 5-8 cycles for every address it computes, and the chain wave formed ~19 per step.
+  struct ColPtr {
+    const double *pe[10], *pr[4];
+    double *xw[4];
+  };
+  auto col_ptrs = [&](double *col, ColPtr &C) {
+#pragma unroll
+    for (int e = 0; e < 10; e++) C.pe[e] = col + px[e];
+#pragma unroll
+    for (int j = 0; j < 4; j++) C.pr[j] = col + li * 4 + (j ^ lk), C.xw[j] = col + lk * 4 + (lk ^ j);
+  };
+  auto read_pivot_c = [&](const ColPtr &C, auto qc) {
+    constexpr int q = decltype(qc)::value;
+#pragma unroll
+    for (int e = 0; e < 10; e++) pv[e] = C.pe[e][q * (PD + 16)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) raw0n[j] = C.pr[j][q * PD];
+  };
+  auto extract_c = [&](double *xe, auto qc, const wv_d4 &c) {   // xe = col + (16 t + lk) * 4 + (li & 3)
+    constexpr int q = decltype(qc)::value;
+    if ((li >> 2) == q) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) xe[q * PD + 16 * r] = c[r];
+    }
+  };
+
   wv_d4 T[NT];
 #pragma unroll
   for (int j = 0; j < NT; j++) T[j] = wv_d4{0.0, 0.0, 0.0, 0.0};
@@ -266,7 +325,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   wv_publish(L.flagE + wave, 1);
   WPROF(0);
 
-  double pmin = 1.0, wkeep[4] = {0.0, 0.0, 0.0, 0.0};
+  double pmin = 1.0, wkeep[4] = {0.0, 0.0, 0.0, 0.0}, detk = 1.0;
   // role 0, after its matrix instruction has been issued: W takes the pivot block's place in the panel store, the others may go
   auto publish_w = [&](int s, bool last_of_column) {
     const int cl = 4 * (s & 3);
@@ -280,6 +339,14 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     }
     wv_publish(L.flagW, s + 1);
   };
+  auto publish_w_c = [&](const ColPtr &C, int s, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) C.xw[j][q * (PD + 16)] = wkeep[j];
+    }
+    wv_publish(L.flagW, s + 1);
+  };
   // the part of a step every variant shares: W (computed or fetched), the operands; returns whether this tile row is touched
   auto operands = [&](int s, auto rc, double &av, auto &uv) {
     constexpr int R = decltype(rc)::value;
@@ -287,15 +354,13 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     double *const pan = PAN + (size_t)s * PD;
     double w[4];
     if constexpr (R == 0) {
-      wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, pmin);
+      wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, detk);
 #pragma unroll
       for (int j = 0; j < 4; j++) wkeep[j] = w[j];   // (stored and published after the matrix instruction is under way)
     } else {
-      wv_await(L.flagW, s + 1);
+      wv_await_all<R + 1>(L.flagW, s + 1);   // W, and the rows above this wave's, stored by their owners (flagW, flagE[0 .. R-1])
 #pragma unroll
       for (int j = 0; j < 4; j++) w[j] = pan[(cl + lk) * 4 + (lk ^ j)];
-#pragma unroll
-      for (int t = 0; t < R; t++) wv_await(L.flagE + t, s + 1);   // the rows above this wave's, stored by their owners
     }
     double raw[R + 1][4];   // this lane's rows 16 t + li of the panel, columns XOR lk, t = 0..R
     if constexpr (R == 0) {
@@ -307,36 +372,48 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 #pragma unroll
         for (int j = 0; j < 4; j++) raw[t][j] = pan[(16 * t + li) * 4 + (j ^ lk)];
     }
-    {
-      const bool live = li > cl + 3;  // rows of tile 0 at or above the pivot are eliminated: they take no part
-#pragma unroll
-      for (int j = 0; j < 4; j++) raw[0][j] = live ? raw[0][j] : 0.0;
-    }
     av = -raw[R][0];
 #pragma unroll
     for (int t = 0; t <= R; t++) uv[t] = fma(w[3], raw[t][3], fma(w[2], raw[t][2], fma(w[1], raw[t][1], w[0] * raw[t][0])));
+    {
+      const bool live = li > cl + 3;  // rows of tile 0 at or above the pivot are eliminated: they take no part
+      uv[0] = live ? uv[0] : 0.0;
+      if constexpr (R == 0) av = live ? av : 0.0;
+    }
     // (lane (li, lk) holds R[16 R + li][lk] in raw[R][0]: the ballot sees every entry of this tile row's panel)
     return (R == 0) || (__ballot(raw[R][0] != 0.0) != 0ull);
   };
   // steps 4 tb .. 4 tb + 3 in role R; afterwards the wave is role R - 1 (R >= 1) or NT - 1 (R = 0)
   auto run_column = [&](int tb, auto rc) {
     constexpr int R = decltype(rc)::value;
-    for (int q = 0; q < 3; q++) {
+    double *const col = PAN + (size_t)(4 * tb) * PD;
+    double *const xe = col + (16 * R + lk) * 4 + (li & 3);
+    ColPtr C;
+    if constexpr (R == 0) col_ptrs(col, C);
+    auto mid = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
       const int s = 4 * tb + q;
       double av, uv[R + 1];
+      double ma = pv[0], mb = pv[1], mc = pv[2], md = pv[3], me = pv[4], mh = pv[5];   // (role 0: for the minors, below)
       const bool any = operands(s, rc, av, uv);
       if (any) {
 #pragma unroll
         for (int j = 0; j <= R; j++) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, uv[j], T[j], 0, 0, 0);
       }
-      if constexpr (R == 0) publish_w(s, false);
-      extract(s + 1, R, T[0]);
+      if constexpr (R == 0) publish_w_c(C, s, qc);
+      extract_c(xe, std::integral_constant<int, q + 1>{}, T[0]);
       if constexpr (R == 0) {
         wv_order();
-        read_pivot(s + 1);
+        read_pivot_c(C, std::integral_constant<int, q + 1>{});
+        // while those reads are under way: was this step's pivot block positive definite?
+        asm volatile("" : "+v"(ma), "+v"(mb), "+v"(mc), "+v"(md), "+v"(me), "+v"(mh));
+        wv_pd_minors(ma, mb, mc, md, me, mh, detk, pmin);
       }
       wv_publish(L.flagE + R, s + 2);
-    }
+    };
+    mid(std::integral_constant<int, 0>{});
+    mid(std::integral_constant<int, 1>{});
+    mid(std::integral_constant<int, 2>{});
     const int s = 4 * tb + 3;
     const bool more = s + 1 < S;
     double av, uv[R + 1];
@@ -357,6 +434,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 #pragma unroll
       for (int j = 1; j <= R; j++) T[j - 1] = T[j];
     } else {                  // the pivot tile is finished: take the tile row that enters the window from the loader's slot
+      wv_pd_minors(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], detk, pmin);
       publish_w(s, true);
       if (more) {
         wv_await(L.flagL, tb + 1);
@@ -422,9 +500,7 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
   for (int s = 0; s < S; s++) {
     const int tb = s >> 2, cl = 4 * (s & 3);
     const double *pan = PAN + (size_t)s * PD;
-    wv_await(L.flagW, s + 1);
-#pragma unroll
-    for (int t = 0; t < WNT; t++) wv_await(L.flagE + t, s + 1);
+    wv_await_all<WNT + 1>(L.flagW, s + 1);   // (flagW, flagE[0 .. WNT-1]: adjacent)
     double z[4];
     const double b0 = BV[4 * s], b1 = BV[4 * s + 1], b2 = BV[4 * s + 2], b3 = BV[4 * s + 3];
 #pragma unroll
@@ -453,19 +529,29 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     const int slot = lane >> 2, kk = lane & 3;
     double v = 0.0;
     struct Ops { wv_d2 w01, w23; double z, r[4]; bool valid; };
-    auto fetch = [&](int sp, Ops &o) {   // everything step sp reads that does not hang on the chain
-      const int spc = max(sp, 0);
-      const double *wr = PAN + (size_t)spc * PD + 16 * (spc & 3) + 4 * kk;   // row k of W (in the pivot block's place)
-      o.w01 = *(const wv_d2 *)wr, o.w23 = *(const wv_d2 *)(wr + 2);
-      o.z = ZST[4 * spc + kk];
-      const int dd = (spc - 1 - slot) & 15, sq = spc - 1 - dd;
-      const int lrow = 4 * spc - 16 * (sq >> 2);
-      o.valid = (sq >= 0) && (lrow + 3 <= PR - 1);
-      const double *rp = PAN + (size_t)max(sq, 0) * PD + min(lrow, PR - 4) * 4 + kk;
+    // Addresses.  The steps are walked a tile column (four steps, q = 3..0) at a time, so that what depends on the step inside
+    // the column sits in the instructions' offset fields and the per-lane part is formed once per column (row k of W:
+    // wc + q (PD + 16); z: zc + 4 q; the solved unknowns: xc + 4 q).  The panel rows a lane's accumulator takes
+    // (R_s[lrow .. lrow + 3][k] of its pending step s) move by a fixed stride from step to step: with u = sp - 1 - slot,
+    //   index = slot PD + 16 (slot & 3) + k + 16 + 16 u + 16 (PD - 16) (u >> 4),  valid <=> u >= 0 and (u & 15) <= dmax(slot)
+    // (tests/test_wave_solver_model.py holds the closed form against the direct one), so rp just steps down by 16 doubles, by
+    // 16 (PD - 15) when the lane's slot is the step's own (u & 15 wraps) -- ~7 instead of ~17 address instructions per step.
+    const int dmax = PR / 4 - 2 - (slot & 3);
+    int u = S - 2 - slot;                                  // for the step fetched next (S - 1 first)
+    const double *rp = PAN + (slot * PD + 16 * (slot & 3) + kk + 16) + 16 * u + 16 * (PD - 16) * (u >> 4);
+    const double *const rsafe = PAN + kk;
+    auto fetch = [&](const double *wc, const double *zc, int sp, auto qc, Ops &o) {   // everything step sp = 4 c + q reads off the chain
+      constexpr int q = decltype(qc)::value;
+      o.w01 = *(const wv_d2 *)(wc + q * (PD + 16)), o.w23 = *(const wv_d2 *)(wc + q * (PD + 16) + 2);
+      o.z = zc[4 * q];
+      o.valid = (u >= 0) && ((u & 15) <= dmax);
+      const double *ra = o.valid ? rp : rsafe;
 #pragma unroll
-      for (int m = 0; m < 4; m++) o.r[m] = rp[4 * m];
-    };
-    auto pin = [&](Ops &o) {   // keeps the prefetch where it was issued
+      for (int m = 0; m < 4; m++) o.r[m] = ra[4 * m];
+      // ... and the lane's state for the step below this one
+      u -= 1;
+      rp -= (slot == ((sp - 1) & 15)) ? 16 * (PD - 15) : 16;
+      // (keeps the prefetch where it was issued)
       asm volatile("" : "+v"(o.w01), "+v"(o.w23), "+v"(o.z));
 #pragma unroll
       for (int k = 0; k < 4; k++) asm volatile("" : "+v"(o.r[k]));
@@ -476,27 +562,46 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), m * 0x55, 0xf, 0xf, false);
       return __hiloint2double(hi, lo);
     };
-    auto solve_step = [&](int sp, const Ops &o) {
+    auto solve_step = [&](double *xc, int sp, auto qc, const Ops &o) {
+      constexpr int q = decltype(qc)::value;
       const int l0 = 4 * (sp & 15);
       const double v0 = wv_readlane(v, l0), v1 = wv_readlane(v, l0 + 1), v2 = wv_readlane(v, l0 + 2), v3 = wv_readlane(v, l0 + 3);
-      const double xk = fma(-o.w23.y, v3, fma(-o.w23.x, v2, fma(-o.w01.y, v1, fma(-o.w01.x, v0, o.z))));   // x1[kk]
-      if (lane < 4) BV[4 * sp + lane] = xk;
+      // x1[kk] = z - W[k][:] v: the four v stay in scalar registers (left to itself the compiler copies each into a vector
+      // register first: 8 moves per step on a chain that is bound by instruction issue)
+      auto fnma_vs = [](double w, double sv, double acc) {
+        double r;
+        asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(w), "s"(sv), "v"(acc));
+        return r;
+      };
+      const double xk = fnma_vs(o.w23.y, v3, fnma_vs(o.w23.x, v2, fnma_vs(o.w01.y, v1, fnma_vs(o.w01.x, v0, o.z))));
+      if (lane < 4) xc[4 * q] = xk;
       const double x0 = quad(xk, std::integral_constant<int, 0>{}), x1 = quad(xk, std::integral_constant<int, 1>{}),
                    x2 = quad(xk, std::integral_constant<int, 2>{}), x3 = quad(xk, std::integral_constant<int, 3>{});
       const double upd = fma(o.r[3], x3, fma(o.r[2], x2, fma(o.r[1], x1, o.r[0] * x0)));
       v = o.valid ? v + upd : v;
       v = (slot == (sp & 15)) ? 0.0 : v;
     };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
+    auto wcol = [&](int c) { return PAN + (size_t)(4 * c) * PD + 4 * kk; };   // row k of W of the column's first step
     Ops oa, ob;
-    fetch(S - 1, oa);
-    for (int sp = S - 1; sp >= 0; sp -= 2) {   // two steps per trip, each one's operands requested a step ahead
-      fetch(sp - 1, ob);
-      pin(ob);
-      solve_step(sp, oa);
-      if (sp - 1 < 0) break;
-      fetch(sp - 2, oa);
-      pin(oa);
-      solve_step(sp - 1, ob);
+    const int TBs = S >> 2;   // (S is a multiple of 4: np is a multiple of 16)
+    const double *wc = wcol(TBs - 1), *zc = ZST + 16 * (TBs - 1) + kk;
+    fetch(wc, zc, S - 1, Q3{}, oa);
+    for (int c = TBs - 1; c >= 0; c--) {   // each step's operands requested a step ahead
+      const int s0 = 4 * c, cn = max(c - 1, 0);
+      double *const xc = BV + 16 * c + lane;
+      fetch(wc, zc, s0 + 2, Q2{}, ob);
+      solve_step(xc, s0 + 3, Q3{}, oa);
+      fetch(wc, zc, s0 + 1, Q1{}, oa);
+      solve_step(xc, s0 + 2, Q2{}, ob);
+      fetch(wc, zc, s0, Q0{}, ob);
+      solve_step(xc, s0 + 1, Q1{}, oa);
+      wc = wcol(cn), zc = ZST + 16 * cn + kk;
+      fetch(wc, zc, s0 - 1, Q3{}, oa);     // (column c - 1; below the first column: a harmless re-read of column 0)
+      solve_step(xc, s0, Q0{}, ob);
     }
   }
   wv_order();

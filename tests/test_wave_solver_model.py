@@ -105,3 +105,25 @@ def test_split_plan_refuses_what_two_fronts_cannot_take():
     H[70, 70] = -5.0
     x, failed = wsm.TwoFrontSolver(np.tril(H), b, 1e-4, 0.1, fpose).solve()
     assert failed and np.all(x == 0.0)
+
+
+@pytest.mark.parametrize("PR", [48, 64])
+def test_backward_address_recurrence(PR):
+    """the closed form the kernel's backward substitution steps its panel-row address with (csrc/ba_solve_wave.hip: u = sp - 1 -
+    slot) against the direct index of the lane's pending step, for every lane and step"""
+    PD = PR * 4
+    slot, kk = np.arange(64) >> 2, np.arange(64) & 3
+    C = slot * PD + 16 * (slot & 3) + kk + 16
+    dmax = PR // 4 - 2 - (slot & 3)
+    for S in (4, 8, 12, 36, 96):
+        u = S - 2 - slot
+        idx_inc = C + 16 * u + 16 * (PD - 16) * (u >> 4)
+        for sp in range(S - 1, -1, -1):
+            dd = (sp - 1 - slot) & 15
+            sq = sp - 1 - dd
+            lrow = 4 * sp - 16 * (sq >> 2)
+            valid = (sq >= 0) & (lrow + 3 <= PR - 1)
+            assert np.array_equal(valid, (u >= 0) & ((u & 15) <= dmax))
+            assert np.array_equal((sq * PD + lrow * 4 + kk)[valid], idx_inc[valid])
+            u = u - 1                                                     # the kernel's step: rp -= 16 or 16 (PD - 15)
+            idx_inc = idx_inc - np.where(slot == ((sp - 1) & 15), 16 * (PD - 15), 16)
