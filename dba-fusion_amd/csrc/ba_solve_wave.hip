@@ -444,6 +444,12 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 #pragma unroll
           for (int r = 0; r < 4; r++) T[j][r] = ring[(j * 4 + r) * 64 + lane];
         extract(s + 1, NT - 1, T[0]);
+        // flagE[NT - 1] changes hands here, from the wave that held the last tile row through this column to this one.  That
+        // wave runs off the chain, behind: its own last announcement (row NT - 1 of panel s, value s + 1) must be out before
+        // this one -- otherwise the readers take panel s's row for stored when it is not, and the counter steps back when the
+        // late store lands.  (This wave is off the chain from here on: the wait costs nothing.)  Found in round 5 when the
+        // chain got faster: one wrong solve in ~40 cold starts, scratch/solve_stress.py / solve_cold.py.
+        wv_await(L.flagE + (NT - 1), s + 1);
         wv_publish(L.flagE + (NT - 1), s + 2);   // (orders the reads of the slot before ...)
         wv_publish(L.flagC, tb + 1);             // ... the slot is free again)
       }

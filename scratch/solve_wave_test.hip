@@ -87,6 +87,7 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
 int main() {
   hipMalloc(&dba::g_tile_prof, 2048 + (1 << 20)); hipMemset(dba::g_tile_prof, 0, 2048);
   (void)hipMalloc(&g_wprof, 256); (void)hipMemset(g_wprof, 0, 256); hipMalloc(&gscr, 8 << 20);
+  if (getenv("HARNESS_ONLY")) { int P = 40, w = 4; sscanf(getenv("HARNESS_ONLY"), "%d %d", &P, &w); return run(P, w, true, false); }   // one cold solve and out
   run(24, 4, true, true); run(24, 3, true, true); run(25, 4, true, true); run(24, 2, true, false); run(24, 1, true, false); run(24, 0, true, false);
   run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
   run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);
