@@ -8,6 +8,8 @@
 // tiles summed out of LDS), the single substitution wave finishes the two forward passes 7 us behind the factorisation and its
 // interleaved backward pass takes 10 us, and eight waves instead of six cost the one-front path itself 15 us at n = 378.
 // A ten-wave form (own substitution and loader waves per front) has 168 VGPRs per wave: the allocator spilled in every path.
+// NOTE: this copy predates two things the product file has: the instruction diet (29.5 -> 25.1 us) and the fix of the hand-over
+// race on flagE[NT - 1] (the ring taker must wait for the old holder's last announcement; profiles/SOLVER_NOTES.md).
 //
 // Damped solve of the reduced camera system of a sliding window: FIVE (SIX) WAVES, the band's trailing window in matrix-core
 // accumulators, no workgroup barrier anywhere.
