@@ -470,11 +470,12 @@ int dba_ba_shard_back(float *poses, float *disps, const int64_t *ii, const int64
 // prepared = 1: the index tables in `ws` are those of this graph already (a previous dba_ba / dba_ba_prepare with the
 // same ii, jj, sizes, t0, t1 and Schur form on this workspace): stage 0 is skipped.  prepared = 2: stage 0 decides that
 // itself, on the device, by comparing the edge list with the key it left in the workspace (dba_ba_prepare_keyed).
-static int ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
-                  const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
-                  const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
-                  float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
-                  dba_stream_t stream, int prepared, int solver_hint, float disp_floor = 0.f) {
+extern "C++" {
+int dba::ba_run_loop(float *poses, float *disps, const float *intrinsics, const float *disps_sens, const float *targets,
+                const float *weights, const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm, float ep,
+                float alpha, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream,
+                int prepared, int solver_hint, float disp_floor, const int32_t *window_fpose, const BaExchange *exchange) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -482,7 +483,6 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
     rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
   }
-  const float alpha = 0.05f;  // droid_kernels.cu:1474
   // Back-substitution + retraction of iteration k are folded into the linearisation of iteration k + 1 (one launch less
   // per iteration; DBA_BA_FUSE_UPDATE=0 keeps them apart): the poses the next launch reads stay untouched, the retracted
   // window travels through two workspace copies, and only the last iteration's update is a launch of its own, which
@@ -493,20 +493,25 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
   for (int itr = 0; itr < iterations; itr++) {
     float *pose_dst = plan.W.poses_tmp + (size_t)(itr & 1) * 7 * B;
     const int upd = pending ? (motion_only ? 1 : 3) : 0;
-    rc = ba_linearize_stage(pose_src, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, nullptr, N, B,
+    rc = ba_linearize_stage(pose_src, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, jj, frame_owned, N, B,
                             ht, wd, t0, t1, alpha, upd, pending ? pose_dst : nullptr, disps, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
     if (pending) pose_src = pose_dst;
-    rc = ba_reduce_stage(ii, jj, nullptr, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
+    rc = ba_reduce_stage(ii, jj, frame_owned, N, B, ht, wd, t0, t1, motion_only, 1, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
-    rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, true, nullptr, solver_hint);
+    if (exchange && exchange->fn && plan.P > 0) {   // the ranks' partial [H | gap | b] become the window's
+      const size_t n6 = (size_t)6 * plan.P;
+      rc = exchange->fn(exchange->ctx, plan.W.H, (size_t)(plan.W.b - plan.W.H) + n6, (hipStream_t)stream);
+      if (rc != DBA_OK) return rc;
+    }
+    rc = ba_solve_stage(N, B, ht, wd, t0, t1, lm, ep, ws, ws_bytes, stream, window_fpose == nullptr, window_fpose, solver_hint);
     if (rc != DBA_OK) return rc;
     const bool last = (itr == iterations - 1);
     if (fuse && !last) {
       pending = true;
       continue;
     }
-    rc = ba_update_launch(poses, disps, jj, nullptr, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
+    rc = ba_update_launch(poses, disps, jj, frame_owned, N, B, ht, wd, t0, t1, 1, motion_only ? 0 : 1,
                           last ? dz_out : nullptr, last ? dx_out : nullptr, ws, ws_bytes, stream,
                           pose_src == poses ? nullptr : pose_src, last ? disp_floor : 0.f);
     if (rc != DBA_OK) return rc;
@@ -514,6 +519,17 @@ static int ba_run(float *poses, float *disps, const float *intrinsics, const flo
     pending = false;
   }
   return DBA_OK;
+}
+}  // extern "C++"
+
+static int ba_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+                  const float *targets, const float *weights, const float *eta, int eta_rows, const int64_t *ii,
+                  const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
+                  float ep, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes,
+                  dba_stream_t stream, int prepared, int solver_hint, float disp_floor = 0.f) {
+  return ba_run_loop(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, nullptr, N, B, ht, wd, t0,
+                     t1, iterations, lm, ep, 0.05f /* droid_kernels.cu:1474 */, motion_only, dx_out, dz_out, ws, ws_bytes, stream,
+                     prepared, solver_hint, disp_floor, nullptr, nullptr);
 }
 
 int dba_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,

@@ -101,6 +101,21 @@ __global__ void ba_gather_edges_kernel(const float2 *tgt_inac, const float2 *wgt
                                        const int64_t *ii_act, const int64_t *jj_act, int HW, float *tgt_out, float *wgt_out,
                                        int64_t *ii_out, int64_t *jj_out);
 
+// The Gauss-Newton loop of dba_ba (ba_host.hip), shared with the sharded sequence (ba_sharded_host.hip): frame_owned restricts
+// stages 1 / 2 / 4 to the rank's source frames, window_fpose is the COMPLETE graph's pose-level skyline for the redundant solve,
+// and `exchange` (may be null) runs between the reduction and the solve of every iteration on the summed-to-be [H | gap | b]
+// range of the workspace.  The back-substitution + retraction of iteration k ride in the linearisation of iteration k + 1 in
+// both uses (a rank only moves the depths of frames it owns; the poses' update is redundant on every rank).
+struct BaExchange {
+  int (*fn)(void *ctx, double *hb, size_t hb_len, hipStream_t stream);
+  void *ctx;
+};
+int ba_run_loop(float *poses, float *disps, const float *intrinsics, const float *disps_sens, const float *targets,
+                const float *weights, const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
+                const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm, float ep,
+                float alpha, int motion_only, float *dx_out, float *dz_out, void *ws, size_t ws_bytes, dba_stream_t stream,
+                int prepared, int solver_hint, float disp_floor, const int32_t *window_fpose, const BaExchange *exchange);
+
 // damped float64 Cholesky solve of H x = b, one workgroup
 // fpose: optional [n/6] skyline of the system at pose granularity (see BaTables); null = measure it from H
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,

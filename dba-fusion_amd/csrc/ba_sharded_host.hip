@@ -144,49 +144,45 @@ int dba_ba_sharded_run(float *poses, float *disps, const float *intrinsics, cons
   if (!x || x->world < 1 || x->rank < 0 || x->rank >= x->world) return DBA_ERR_ARG;
   if (x->world > 1 && !x->comm && !x->peer_regions) return DBA_ERR_ARG;   // somebody has to carry the sums
   if (x->peer_regions && (!x->peer_status || !x->peer_epoch)) return DBA_ERR_ARG;
-  dba_ba_layout lay;
-  int rc = dba_ba_get_layout(N, B, ht, wd, t0, t1, &lay);
-  if (rc != DBA_OK) return rc;
-  const size_t n6 = (size_t)6 * lay.P;
-  // [H | alignment gap | b] is one float64 range of the workspace (the gap is zero: dba_ba_workspace_init / the caller)
-  if (lay.b < lay.H + 8 * n6 * n6 || (lay.b - lay.H) % 8) return DBA_ERR_WORKSPACE;
-  double *hb = reinterpret_cast<double *>(static_cast<char *>(ws) + lay.H);
-  const size_t hb_len = (lay.b - lay.H) / 8 + n6;
   if (x->band_len && (!x->band_idx || !x->band_buf)) return DBA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (prepared != 1) {
-    rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
-    if (rc != DBA_OK) return rc;
-  }
-  for (int itr = 0; itr < iterations; itr++) {
-    rc = dba_ba_shard_front(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, frame_owned, N, B,
-                            ht, wd, t0, t1, alpha, motion_only, ws, ws_bytes, stream);
-    if (rc != DBA_OK) return rc;
-    if ((x->comm || x->peer_regions) && n6 > 0) {   // (also with one rank: the collective then runs over a world of one)
-      double *buf = hb;
-      size_t cnt = hb_len;
-      if (x->band_len) {   // large windows: only the skyline band travels (gather -> sum -> scatter)
-        cnt = x->band_len, buf = x->band_buf;
-        hipLaunchKernelGGL(band_take_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, hb, x->band_idx, cnt, buf);
-        DBA_LAUNCH_CHECK();
-      }
-      if (x->peer_regions) {
-        *x->peer_epoch += 1;
-        rc = dba_peer_allreduce_f64(buf, cnt, x->peer_regions, x->rank, x->world, *x->peer_epoch, x->peer_max_doubles,
-                                    x->peer_status, stream);
-      } else {
-        rc = dba_comm_allreduce_f64(x->comm, buf, cnt, stream);
-      }
-      if (rc != DBA_OK) return rc;
-      if (x->band_len) {
-        hipLaunchKernelGGL(band_put_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, hb, x->band_idx, cnt, buf);
-        DBA_LAUNCH_CHECK();
-      }
+  // The Gauss-Newton loop is dba_ba's own (ba_run_loop: the back-substitution + retraction of iteration k ride in the
+  // linearisation of iteration k + 1 here too -- a rank only moves the depths of the frames it owns, the update of the poses
+  // is redundant on every rank), with the sum over the ranks between the reduction and the solve.  One rank sums nothing.
+  struct Ctx {
+    const dba_shard_exchange *x;
+  } ctx{x};
+  BaExchange ex;
+  ex.ctx = &ctx;
+  ex.fn = [](void *c, double *hb, size_t hb_len, hipStream_t st) -> int {
+    const dba_shard_exchange *x = static_cast<Ctx *>(c)->x;
+    double *buf = hb;
+    size_t cnt = hb_len;
+    if (x->band_len) {   // large windows: only the skyline band travels (gather -> sum -> scatter)
+      cnt = x->band_len, buf = x->band_buf;
+      hipLaunchKernelGGL(band_take_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, hb, x->band_idx, cnt, buf);
+      DBA_LAUNCH_CHECK();
     }
-    rc = dba_ba_shard_back(poses, disps, ii, jj, frame_owned, N, B, ht, wd, t0, t1, lm, ep, motion_only ? 0 : 1, window_fpose,
-                           solver_hint, ws, ws_bytes, stream);
+    int rc;
+    if (x->peer_regions) {
+      *x->peer_epoch += 1;
+      rc = dba_peer_allreduce_f64(buf, cnt, x->peer_regions, x->rank, x->world, *x->peer_epoch, x->peer_max_doubles,
+                                  x->peer_status, (dba_stream_t)st);
+    } else {
+      rc = dba_comm_allreduce_f64(x->comm, buf, cnt, (dba_stream_t)st);
+    }
     if (rc != DBA_OK) return rc;
-  }
+    if (x->band_len) {
+      hipLaunchKernelGGL(band_put_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, hb, x->band_idx, cnt, buf);
+      DBA_LAUNCH_CHECK();
+    }
+    return DBA_OK;
+  };
+  const bool sums = x->world > 1 && (x->comm || x->peer_regions);
+  int rc = ba_run_loop(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, frame_owned, N, B, ht, wd,
+                       t0, t1, iterations, lm, ep, alpha, motion_only, nullptr, nullptr, ws, ws_bytes, stream,
+                       (prepared == 1 || prepared == 2) ? prepared : 0, solver_hint, 0.f, window_fpose, sums ? &ex : nullptr);
+  if (rc != DBA_OK) return rc;
   // the replicas of the depth maps are made coherent ONCE per call: every rank sends the rows it owns
   // (only with a communicator: the peer-read exchange carries the reduced system alone, its caller gathers the depths)
   if (!motion_only && iterations > 0 && x->kmax > 0 && x->comm) {

@@ -227,9 +227,13 @@ typedef struct {
   float *send, *recv;
 } dba_shard_exchange;
 
-/* stage 0 (prepared = 0 | 1 | 2 as in dba_ba_run), then `iterations` x { dba_ba_shard_front -> sum of [H | b] over the ranks
- * -> dba_ba_shard_back }, then the all-gather of the owned depth maps: everything enqueued on `stream`, nothing waits on the
- * host.  The alignment gap between H and b in the workspace must be zero (it is summed along). */
+/* stage 0 (prepared = 0 | 1 | 2 as in dba_ba_run), then dba_ba's own Gauss-Newton loop on the rank's edges -- `iterations` x
+ * { linearisation (which carries the previous iteration's back-substitution + retraction, as in dba_ba: a rank moves the
+ * depths of the frames it owns, the poses' update is redundant on every rank), Schur reduction, sum of [H | b] over the
+ * ranks, solve with the complete graph's skyline }, the last update --, then the all-gather of the owned depth maps:
+ * everything enqueued on `stream`, nothing waits on the host.  The same states as the staged sequence
+ * dba_ba_shard_front / sum / dba_ba_shard_back, bit for bit.  With world = 1 nothing is summed.  The alignment gap between H
+ * and b in the workspace must be zero (it is summed along). */
 int dba_ba_sharded_run(float *poses, float *disps, const float *intrinsics, const float *disps_sens, const float *targets,
                        const float *weights, const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj,
                        const uint8_t *frame_owned, int N, int B, int ht, int wd, int t0, int t1, int iterations, float lm,
