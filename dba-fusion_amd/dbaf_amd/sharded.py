@@ -108,8 +108,19 @@ class _Comms:
             idb = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
             comm = ctypes.c_void_p()
             with torch.cuda.device(device):
-                _lib.check(lib.dba_comm_create(ctypes.cast(idb, ctypes.c_void_p), world, rank, ctypes.byref(comm)),
-                           "dba_comm_create")
+                rc = lib.dba_comm_create(ctypes.cast(idb, ctypes.c_void_p), world, rank, ctypes.byref(comm))
+            # every rank must take the same route: if the communicator could not be made on ANY of them, all keep the staged
+            # path (the collectives of torch.distributed between stage calls)
+            ok = torch.tensor([1 if (rc == 0 and comm.value) else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if rc == 0 and comm.value:
+                    lib.dba_comm_destroy(comm)
+                import warnings
+                warnings.warn("dbaf_amd.sharded: the library's own RCCL communicator could not be created on every rank (%s); "
+                              "the sharded BA keeps the staged path" % (_lib.load().dba_last_error().decode() if rc else "another rank failed"))
+                cls._by_group[key] = ent = (None,)
+                return None
             cls._by_group[key] = ent = (comm,)
         return ent[0]
 
