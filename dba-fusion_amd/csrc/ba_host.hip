@@ -218,6 +218,15 @@ int dba_ba_gather_edges(const float *target_inac, const float *weight_inac, cons
   return DBA_OK;
 }
 
+int dba_ba_solver_verdict(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (!ba_solve_wave_supported(6 * plan.P)) return 2;
+  const int *slot = solver_verdict_slot(plan.T.meta);
+  return slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
+}
+
 int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
@@ -232,8 +241,18 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
   return dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, 0, 0, ws, ws_bytes, stream);
 }
 
+// judge_band: the solves that follow use THIS graph's skyline (dba_ba; not the sharded sequence, whose ranks see their own edges
+// only, and not BACore, whose system is solved on the host): stage 0 then also tells the host whether the window solver takes it
+static int ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
+                            int check, void *ws, size_t ws_bytes, dba_stream_t stream, bool judge_band);
+
 int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
                          int check, void *ws, size_t ws_bytes, dba_stream_t stream) {
+  return ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, check, ws, ws_bytes, stream, false);
+}
+
+static int ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
+                            int check, void *ws, size_t ws_bytes, dba_stream_t stream, bool judge_band) {
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
@@ -249,9 +268,11 @@ int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_prepare_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
+  const int max_nt = judge_band ? ba_solve_wave_max_nt(6 * plan.P) : 0;
+  int *band_verdict = max_nt ? solver_verdict_slot(plan.T.meta) : nullptr;
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
                      (int)scan_ints, ba_schur_frame_form(N, plan.P) ? 1 : 0, check ? 1 : 0, eta_rows,
-                     eta_rows > 1 ? eta_status() : nullptr, plan.T);
+                     eta_rows > 1 ? eta_status() : nullptr, plan.T, band_verdict, max_nt);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -480,7 +501,8 @@ int dba::ba_run_loop(float *poses, float *disps, const float *intrinsics, const 
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   if (prepared != 1) {
-    rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
+    rc = ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream,
+                          window_fpose == nullptr);
     if (rc != DBA_OK) return rc;
   }
   // Back-substitution + retraction of iteration k are folded into the linearisation of iteration k + 1 (one launch less

@@ -69,8 +69,10 @@ constexpr int GKEY_MAGIC = 0x6b657935;   // first word of a valid graph key
 // check != 0: leave at once when the workspace's key says the tables are those of this very graph
 // eta_rows > 1: must equal |kx| (droid_kernels.cu:1476 broadcasts eta over the rows of C); a mismatch is reported through
 // `status` (pinned host memory, may be null): [0] = 1, [1] = eta_rows, [2] = |kx|
+// band_verdict (pinned host memory, may be null): when the tables are rebuilt, 1 / 2 = the window solver will / will not admit
+// the reduced system of this graph (its admission test on the new skyline; max_nt as launch_ba_solve_wave passes it)
 __global__ void ba_prepare_kernel(const int64_t *ii, const int64_t *jj, int N, int B, int t0, int t1, int scan_ints,
-                                  int ftable, int check, int eta_rows, int *status, BaTables T);
+                                  int ftable, int check, int eta_rows, int *status, BaTables T, int *band_verdict, int max_nt);
 // which Schur kernel a window gets (ba_host.hip): the per-source-frame form on windows whose frames couple many rows
 bool ba_schur_frame_form(int N, int P);
 template <int PPL, bool MF, int EW>
@@ -131,6 +133,10 @@ int launch_ba_solve_tile(const double *H, const double *b, int n, double lm, dou
 // five-wave window solver for banded systems (ba_solve_wave.hip); needs the pose-level skyline table; a system it does not
 // admit is solved by the general kernel's code in the same launch, *verdict (pinned host memory, may be null) = 1 admitted / 2 not
 bool ba_solve_wave_supported(int n);
+int ba_solve_wave_max_nt(int n);   // the tallest window (3 | 4 tile rows) whose panel store fits LDS for n unknowns, 0: none
+// the word of pinned host memory that carries "banded (1) / not banded (2)" for the workspace whose meta block this is
+// (launch_ba_solve reads it without synchronising; the window kernel and, on a graph change, stage 0 write it); null: no pool
+int *solver_verdict_slot(const int *meta);
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                          double *Lscratch, int *verdict, hipStream_t stream, long long *prof = nullptr);
 size_t ba_solve_scratch_doubles(int n);

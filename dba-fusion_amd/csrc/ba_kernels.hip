@@ -22,6 +22,7 @@
 //     sums order-independent), and solved on the device (ba_solve*.hip);
 //   * back-substitution + retraction of an iteration ride in the next iteration's linearisation.
 #include "ba_kernels.h"
+#include "ba_solve_admit.h"
 
 #include <cstdio>
 #include <cstring>
@@ -47,7 +48,8 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restrict__ ii,
                                                           const int64_t *__restrict__ jj, int N, int B,
                                                           int t0, int t1, int scan_ints, int ftable, int check,
-                                                          int eta_rows, int *__restrict__ status, BaTables T) {
+                                                          int eta_rows, int *__restrict__ status, BaTables T,
+                                                          int *__restrict__ band_verdict, int max_nt) {
   extern __shared__ int sm[];
   int *flag = sm;
   int *cnt = sm + B;
@@ -288,6 +290,13 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   }
   __syncthreads();
   for (int pp = tid; pp < P; pp += nt) T.fpose[pp] = fps[pp];
+  // the new graph's verdict for the host's choice of solver: known here, one whole solve before the window kernel itself
+  // would report it (launch_ba_solve reads the word without synchronising; a graph that changes from update to update would
+  // otherwise be judged by the previous graph's solve, or by a probe every 1024 solves)
+  if (band_verdict && wave == 0) {
+    const int admitted = ba_solve_wave_admits(fps, 6 * P, lane, max_nt);
+    if (lane == 0) __hip_atomic_store(band_verdict, admitted ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // the key of what was just built (every thread passed the comparison's barrier above before anything is overwritten; an
   // edge id that does not fit 32 bits never compares equal, so such a graph is simply rebuilt every time)
   for (int n = tid; n < N; n += nt) T.gkey[8 + n] = (int)ii[n], T.gkey[8 + N + n] = (int)jj[n];

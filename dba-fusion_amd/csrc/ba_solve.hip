@@ -76,12 +76,15 @@ size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 // exists for skylines the first one cannot hold, nor the general kernel is queued behind it (4.6-4.8 us each per solve even
 // when they return at once).  The one thing they were still a net for -- a partner workgroup that does not show up within
 // a second -- then fails the solve (zero update, meta[1] = 1) instead of leaving it to the queue
+// (Round 5, later: stage 0 of dba_ba runs the window kernel's admission test itself whenever it rebuilds a graph's tables and
+// writes the same word -- ba_kernels.hip::ba_prepare_kernel --, so a changed graph is judged before its first solve is over;
+// the window kernel's own report and the rare probes below remain for callers that solve without stage 0.)
 // Which kernel took a workspace's last system: the window kernel reports "banded, taken" (1) or "not banded, solved by the
 // general code in my launch" (2) through a word of pinned host memory per workspace (keyed by its meta pointer), read here
 // without any synchronisation.  It steers the NEXT solve of that workspace -- 2: straight to the register-tile / skyline
 // kernels, which are faster than the in-launch fall-back on such systems; anything else: the window kernel -- and is only
 // ever a performance hint: whatever is launched solves whatever it is given.
-static int *solver_verdict_slot(const int *meta) {
+int *solver_verdict_slot(const int *meta) {
   static std::mutex mu;
   static std::unordered_map<const void *, int> index;
   static int *pool = nullptr;

@@ -46,6 +46,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "ba_solve_admit.h"
 #include "ba_solve_general.inc"
 
 namespace dba {
@@ -69,39 +70,6 @@ __device__ __forceinline__ double wv_readlane(double v, int l) {  // l wave-unif
 __device__ __host__ __forceinline__ size_t wv_lds_doubles(int n, int nt) {
   const int np = (n + 15) & ~15, S = np >> 2;
   return (size_t)S * (16 * nt * 4 + 4) + np + 64 + (size_t)nt * 4 * 64;
-}
-
-// The admission test, by every wave for itself: with the pose-level skyline fpose (first pose a pose is coupled with) made
-// monotone, every column's last row must lie inside the window of its step's tile column: row < 16 (s >> 2) + 16 NT.
-// Returns the smallest NT in {3, 4} (<= max_nt: the panel store of NT = 4 does not fit LDS for the largest systems) that admits
-// the system, or 0.
-__device__ __forceinline__ int ba_solve_wave_admits(const int *__restrict__ fpose, int n, int lane, int max_nt) {
-  const int P = n / 6;
-  if (!fpose || P > 64 || n != 6 * P) return 0;
-  int g = (lane < P) ? fpose[lane] : 0x7fffffff;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {  // suffix minimum: fill-in keeps the skyline monotone
-    const int o = __shfl_down(g, off, 64);
-    if (lane + off < 64) g = min(g, o);
-  }
-  int last = lane;  // last(q) = the last pose p with g[p] <= q (g is non-decreasing)
-  for (int p = 0; p < P; p++) {
-    const int gp = __builtin_amdgcn_readlane(g, p);
-    if (gp <= lane) last = max(last, p);
-  }
-  const int np = (n + 15) & ~15, S = np >> 2;
-  bool ok3 = true, ok4 = true;
-  for (int base = 0; base < S; base += 64) {   // (uniform trip count: the shuffle below is executed by all lanes)
-    const int s = base + lane, c = 4 * s;
-    const int q3 = min(min(c + 3, n - 1) / 6, P - 1);
-    const int lastrow = 6 * __shfl(last, q3, 64) + 5;
-    const bool live = (s < S) && (c < n);
-    ok3 = ok3 && (!live || lastrow <= 16 * (s >> 2) + 47);
-    ok4 = ok4 && (!live || lastrow <= 16 * (s >> 2) + 63);
-  }
-  if (max_nt >= 3 && __ballot(!ok3) == 0ull) return 3;
-  if (max_nt >= 4 && __ballot(!ok4) == 0ull) return 4;
-  return 0;
 }
 
 #ifdef PROFILE_SOLVE
@@ -658,19 +626,19 @@ __global__ __launch_bounds__(384) void ba_solve_wave_kernel(const double *__rest
   else ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
 }
 
-static int wave_max_nt(int n) {   // the tallest window whose panel store fits LDS for a system of n unknowns (0: none)
+int ba_solve_wave_max_nt(int n) {   // the tallest window whose panel store fits LDS for a system of n unknowns (0: none)
   if (n <= 0 || n % 6 != 0 || n / 6 > 64) return 0;
   if (wv_lds_doubles(n, 4) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 4;
   if (wv_lds_doubles(n, 3) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 3;
   return 0;
 }
 
-bool ba_solve_wave_supported(int n) { return wave_max_nt(n) != 0; }
+bool ba_solve_wave_supported(int n) { return ba_solve_wave_max_nt(n) != 0; }
 
 // Lscratch: the workspace's packed-triangle scratch (needed by the fall-back when the system does not fit LDS: n > 199)
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                          double *Lscratch, int *verdict, hipStream_t stream, long long *prof) {
-  const int max_nt = wave_max_nt(n);
+  const int max_nt = ba_solve_wave_max_nt(n);
   if (!max_nt || !fpose) return DBA_ERR_UNSUPPORTED;
   static DeviceOnce attr_once;
   if (attr_once.needed()) {

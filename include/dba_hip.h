@@ -86,6 +86,13 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
  * recorded in pinned host memory and reported by dba_ba_poll_eta_error (the kernels then reuse the last eta row). */
 int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
                          int check, void *ws, size_t ws_bytes, dba_stream_t stream);
+/* diagnostic: what the library currently believes about the reduced camera system of this workspace's graph -- 1: banded enough
+ * for the window solver (csrc/ba_solve_wave.hip), 2: not (the register-tile / skyline / general kernels serve it), 0: nothing
+ * known yet; negative: error.  Host memory only, no synchronisation: the value is written by stage 0 when it rebuilds a graph's
+ * tables inside dba_ba / dba_ba_run and by the window solver itself, and steers where the NEXT solves of the workspace are sent
+ * (only ever a hint: every kernel solves whatever it is given).  Replaces the host-side choice of Eigen::LLT / SimplicialLLT
+ * by matrix size in /root/reference/src/droid_kernels.cu:200-218,1248-1269. */
+int dba_ba_solver_verdict(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes);
 /* marks a freshly allocated workspace as "no graph prepared" (clears meta and the key header; asynchronous on `stream`) */
 int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
 /* 1 (and the two counts) if a stage 0 that has COMPLETED since the last poll saw eta_rows != |kx|, else 0; clears the record.

@@ -752,3 +752,57 @@ def test_ba_extend_exports_the_system_and_matches_ba_with_a_zero_prior():
         Hf[np.diag_indices_from(Hf)] += W.ep + W.lm * np.diag(Hf)
         np.testing.assert_allclose(dx3.cpu().numpy(), np.linalg.solve(Hf, vn).reshape(P, 6), rtol=1e-4, atol=1e-7)
         assert dz3 is not None and torch.isfinite(dz3).all()
+
+
+def test_stage0_tells_the_host_which_solver_the_new_graph_gets():
+    """when stage 0 rebuilds a graph's tables it runs the window solver's admission test on the new skyline and writes the
+    verdict where launch_ba_solve reads it (pinned host memory, no synchronisation): a workspace whose graph changes from banded
+    to far-reaching and back is sent to the right solver from the NEXT call on, not after the window kernel has found out by
+    solving (or a probe every 1024 solves); the states are the oracle's either way"""
+    import ctypes
+    import droid_backends
+    from dbaf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    num_kf, n_edges, h, w = 12, 40, 16, 24
+
+    def graph(long_range):
+        ii, jj = [], []
+        for k in range(n_edges):
+            i = int(rng.integers(0, num_kf))
+            j = int(rng.integers(0, num_kf)) if (long_range and k % 3 == 0) else int(np.clip(i + rng.integers(-2, 3), 0, num_kf - 1))
+            if i == j:
+                j = (i + 1) % num_kf
+            ii.append(i), jj.append(j)
+        if long_range:
+            ii += [1, num_kf - 1]
+            jj += [num_kf - 1, 1]          # couples the ends of the window: no band
+            del ii[:2], jj[:2]
+        return np.array(ii, np.int64), np.array(jj, np.int64)
+
+    verdicts = []
+    for long_range in (False, True, False):
+        ii, jj = graph(long_range)
+        W = syn.make_window(ii, jj, num_kf, h, w, seed=3, target_noise=0.2)
+        d = to_dev(W)
+        for rep in range(2):
+            droid_backends.ba(d["poses"].clone(), d["disps"].clone(), d["intrinsics"], d["disps_sens"], d["target"], d["weight"],
+                              d["eta"], d["ii"], d["jj"], W.t0, W.t1, 2, W.lm, W.ep, False)
+        torch.cuda.synchronize()
+        dims = (W.N, W.B, W.h, W.w, W.t0, W.t1)
+        key = [k for k in droid_backends._BA_WS.ws if k[-1] == dims]
+        assert key, "the adapter keeps one workspace per window shape"
+        ws, nbytes = droid_backends._BA_WS.ws[key[0]]
+        verdicts.append(lib.dba_ba_solver_verdict(*dims, ctypes.c_void_p(ws.data_ptr()), nbytes))
+        # ... and the result is the oracle's whichever kernel solved
+        # (a small random window: bound like the other small fixtures -- 2 x the fp32-faithful oracle's own deviation)
+        orc = _oracle()
+        args = (W.poses, W.disps, W.intrinsics, W.disps_sens, W.target, W.weight, W.eta, W.ii, W.jj, W.t0, W.t1, 2,
+                W.lm, W.ep, False, 0.05)
+        r32, r64 = orc.ba(*args, np.float32), orc.ba(*args, np.float64)
+        p, dd = d["poses"].clone(), d["disps"].clone()
+        droid_backends.ba(p, dd, d["intrinsics"], d["disps_sens"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"],
+                          W.t0, W.t1, 2, W.lm, W.ep, False)
+        check_state(p.cpu().numpy(), dd.cpu().numpy(), r64["poses"], r64["disps"], W.disps, ref32_disps=r32["disps"],
+                    ref32_poses=r32["poses"], d_rtol=2e-3, frac=0.95, ref32_factor=6.0)   # (the bounds of test_ba_random_graphs_match_oracle)
+    assert verdicts == [1, 2, 1], verdicts
