@@ -78,7 +78,7 @@ def _run(TB, handover_wait, seed, bias):
     rng = random.Random(seed)
     log = []
     waves = _waves(TB, handover_wait, log)
-    flags, written, violations = {}, set(), []
+    flags, written, taken, violations = {}, set(), set(), []
     pending = [next(g, None) for g in waves]
     slow = rng.randrange(NT)
     weights = [1.0 / bias if w == slow else 1.0 for w in range(NT)] + [1.0, 1.0]
@@ -89,10 +89,15 @@ def _run(TB, handover_wait, seed, bias):
         i = rng.choices(runnable, [weights[k] for k in runnable])[0]
         kind = pending[i][0]
         if kind == "write":
-            written.add(pending[i][1])
+            item = pending[i][1]
+            # the loader's ring is ONE slot: tile row k may only land there when row k - 1 has been taken out
+            if item[0] == "ring" and item[1] > 0 and ("ring", item[1] - 1) not in taken:
+                violations.append(("slot overwritten before it was read", i, item))
+            written.add(item)
         elif kind == "read":
             if pending[i][1] not in written:
                 violations.append(("read before write", i, pending[i][1]))
+            taken.add(pending[i][1])
         elif kind == "publish":
             if pending[i][2] <= flags.get(pending[i][1], 0):
                 violations.append(("counter steps back", i, pending[i][1], flags.get(pending[i][1], 0), pending[i][2]))
