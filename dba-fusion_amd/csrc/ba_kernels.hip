@@ -612,7 +612,7 @@ __device__ unsigned long long g_lin_span[2 * 8192];
 // (one pixel per lane: four workgroups per CU, i.e. every workgroup of a 25-keyframe window resident at once, is worth
 // keeping: the register budget is held at 128)
 template <int PPL, bool MF, int EW>
-__global__ __launch_bounds__(256, (PPL == 1 ? 4 : 1)) void ba_linearize_kernel(
+__global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_linearize_kernel(
     const float *__restrict__ poses, const float *__restrict__ disps, const float *__restrict__ intrinsics,
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
     const float *__restrict__ weights, const float *__restrict__ eta, int eta_rows,
