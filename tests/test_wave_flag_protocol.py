@@ -13,10 +13,7 @@ import random
 
 import pytest
 
-NT = 3
-
-
-def _waves(TB, handover_wait, log):
+def _waves(TB, handover_wait, log, NT=3):
     S = 4 * TB
 
     def factor(w):
@@ -73,11 +70,11 @@ def _waves(TB, handover_wait, log):
     return [factor(w) for w in range(NT)] + [subst(), loader()]
 
 
-def _run(TB, handover_wait, seed, bias):
+def _run(TB, handover_wait, seed, bias, NT=3):
     """random scheduler; bias > 1 lets one factor wave run that much more often (the wave that falls behind on the device)"""
     rng = random.Random(seed)
     log = []
-    waves = _waves(TB, handover_wait, log)
+    waves = _waves(TB, handover_wait, log, NT)
     flags, written, taken, violations = {}, set(), set(), []
     pending = [next(g, None) for g in waves]
     slow = rng.randrange(NT)
@@ -107,16 +104,18 @@ def _run(TB, handover_wait, seed, bias):
     return violations
 
 
-@pytest.mark.parametrize("TB", [2, 3, 9])
-def test_shipped_protocol_never_reads_what_is_not_written(TB):
+@pytest.mark.parametrize("TB,NT", [(2, 3), (3, 3), (9, 3), (9, 4), (3, 4)])
+def test_shipped_protocol_never_reads_what_is_not_written(TB, NT):
+    """48-row window (three factor waves) and 64-row window (four)"""
     for seed in range(300):
         for bias in (1.0, 4.0, 20.0):
-            assert _run(TB, True, seed, bias) == [], (TB, seed, bias)
+            assert _run(TB, True, seed, bias, NT) == [], (TB, NT, seed, bias)
 
 
 def test_the_round5_handover_race_is_what_the_wait_closes():
     """without the ring taker's wait for flagE[NT - 1] the last tile row's counter is announced over the laggard's head: rows are
     read before they are written and the counter steps back -- found by schedules that let one factor wave fall behind"""
-    bad = [v for seed in range(300) for v in _run(9, False, seed, 20.0)]
-    assert any(v[0] == "read before write" and v[2][0] == "panel" and v[2][2] == NT - 1 for v in bad)
-    assert any(v[0] == "counter steps back" and v[2] == ("E", NT - 1) for v in bad)
+    for NT in (3, 4):
+        bad = [v for seed in range(300) for v in _run(9, False, seed, 20.0, NT)]
+        assert any(v[0] == "read before write" and v[2][0] == "panel" and v[2][2] == NT - 1 for v in bad)
+        assert any(v[0] == "counter steps back" and v[2] == ("E", NT - 1) for v in bad)
