@@ -11,8 +11,12 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) include/dba_hip.h
 
-all: lib ext oracle
+all: lib ext oracle testbin
 lib: $(PKG)/lib/libdba_hip.so
+# test infrastructure: one cold start of the solvers per process (tests/test_gpu_solve_cold.py); host C++, loads the library by dlopen
+testbin: tests/native/solve_cold
+tests/native/solve_cold: tests/native/solve_cold.cpp
+	g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $< -o $@ -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,/opt/rocm/lib
 ext: $(PKG)/droid_backends/_droid_backends_C.so
 oracle:
 	$(MAKE) -C oracle -s
@@ -44,6 +48,6 @@ $(PKG)/droid_backends/_droid_backends_C.so: $(PKG)/csrc_ext/droid_backends_ext.c
 	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,$(TORCH_LIB)
 
 clean:
-	rm -rf build $(PKG)/lib/libdba_hip.so $(PKG)/droid_backends/_droid_backends_C.so
+	rm -rf build $(PKG)/lib/libdba_hip.so $(PKG)/droid_backends/_droid_backends_C.so tests/native/solve_cold
 	$(MAKE) -C oracle clean
-.PHONY: all lib ext oracle clean
+.PHONY: all lib ext oracle testbin clean

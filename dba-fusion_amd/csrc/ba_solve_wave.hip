@@ -51,6 +51,8 @@
 
 namespace dba {
 
+constexpr int WV_THREADS = 448;   // up to five factor waves, the substitution wave, the loader
+
 typedef double wv_d4 __attribute__((ext_vector_type(4)));
 typedef double wv_d2 __attribute__((ext_vector_type(2)));
 
@@ -66,10 +68,25 @@ __device__ __forceinline__ double wv_readlane(double v, int l) {  // l wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// LDS, in doubles: panel store [S][16 NT][4] | z of every step [S][4] | right-hand side / solution + flags [np + 64] | the loader's slot
-__device__ __host__ __forceinline__ size_t wv_lds_doubles(int n, int nt) {
+// LDS, in doubles: panel store [K][16 NT][4] | z of every step [S][4] | right-hand side / solution + flags [np + 72] | the loader's slot
+// K = S: the panel of every step stays in LDS.  K < S (round 6: the 64-row window on systems of more than 45 poses, whose panel
+// store is 192 KB at 63 poses): the store is a RING of K steps -- the forward pass only ever needs the current panel, the
+// substitution wave copies each of the first E = S - K panels to global scratch as it passes (it reads the whole panel anyway),
+// panel s + K then takes panel s's slot, and during the backward pass the loader wave, which has nothing left to do, brings
+// the early panels back into the slots the backward pass has finished with, several tile columns ahead of their use.  E is a
+// multiple of 4 (whole tile columns) and E <= K, so that both [0, E) and [E, S) are contiguous in the ring: the per-column
+// pointer arithmetic of the factor waves and the backward pass's address recurrence stay as they are, only the base changes at
+// the seam (a lane of the backward pass changes its pending step in strides of 16: it crosses the seam at a step of its own).
+__device__ __host__ __forceinline__ size_t wv_lds_doubles_k(int n, int nt, int K) {
   const int np = (n + 15) & ~15, S = np >> 2;
-  return (size_t)S * (16 * nt * 4 + 4) + np + 64 + (size_t)nt * 4 * 64;
+  return (size_t)K * (16 * nt * 4) + (size_t)S * 4 + np + 88 + (size_t)nt * 4 * 64;
+}
+// the number of early panels that leave LDS (0: the whole store fits; -1: no admissible ring either)
+__device__ __host__ __forceinline__ int wv_ring_early(int n, int nt) {
+  const int np = (n + 15) & ~15, S = np >> 2;
+  for (int E = 0; E == 0 || (2 * E <= S && S - E >= 32); E += 4)   // (K >= 32: the slot hand-over distances, see the loader)
+    if (wv_lds_doubles_k(n, nt, S - E) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return E;
+  return -1;
 }
 
 #ifdef PROFILE_SOLVE
@@ -109,7 +126,7 @@ typedef int wv_i4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) volatile wv_i4 wv_lds_vint4;
 template <int N>
 __device__ __forceinline__ void wv_await_all(int *flag, int need) {
-  static_assert(N >= 1 && N <= 5, "flagW and up to four flagE");
+  static_assert(N >= 1 && N <= 6, "flagW and up to five flagE");
   __builtin_amdgcn_wave_barrier();
   for (;;) {
     const wv_i4 v = *(wv_lds_vint4 *)flag;
@@ -118,6 +135,7 @@ __device__ __forceinline__ void wv_await_all(int *flag, int need) {
     if (N > 2) m = min(m, v.z);
     if (N > 3) m = min(m, v.w);
     if (N > 4) m = min(m, *(wv_lds_vint *)(flag + 4));
+    if (N > 5) m = min(m, *(wv_lds_vint *)(flag + 5));
     if (m >= need) break;   // (polling without a sleep: these waves have their SIMD to themselves, and the chain passes through
   }                         // the wake-up of role 1 once per tile column and of the substitution wave at the end)
   asm volatile("" ::: "memory");
@@ -125,21 +143,29 @@ __device__ __forceinline__ void wv_await_all(int *flag, int need) {
 }
 
 // NT = tile rows of the window = factor waves: 3 (48 rows: bands up to 4 poses wide) or 4 (64 rows: up to ~7 poses)
-template <int WNT>
+template <int WNT, bool WRING = false>
 struct WvLayout {   // LDS, in doubles
   static constexpr int PR = 16 * WNT;  // rows of a step's panel store (the window of its tile column)
   static constexpr int PD = PR * 4;    // doubles per step
-  int np, S;
+  int np, S, K, E;                     // K panels in LDS, the first E = S - K of the S leave it for global scratch (WRING)
   double *PAN, *ZST, *BV, *RING;       // RING: the tile row on its way into the window, [WNT tiles][4 regs][64 lanes]
   // W of step s stored: flagW >= s + 1; row j of panel s stored: flagE[j] >= s + 1; tile row WNT + k in the slot: flagL >= k + 1,
-  // taken out of it: flagC >= k + 1
-  int *flagW, *flagE, *fail, *flagL, *flagC;
-  __device__ WvLayout(double *smem, int n) {
+  // taken out of it: flagC >= k + 1.  Ring of panels: the substitution wave has left step s behind (forward): flagF >= s + 1
+  // (announced per tile column); tile columns it has finished on the way back: flagB; early tile columns back in LDS: flagR
+  int *flagW, *flagE, *fail, *flagL, *flagC, *flagF, *flagB, *flagR;
+  __device__ WvLayout(double *smem, int n, int ring_e) {
     np = (n + 15) & ~15, S = np >> 2;
-    PAN = smem, ZST = PAN + (size_t)S * PD, BV = ZST + 4 * S;
-    int *f = (int *)(BV + np + 60);
-    flagW = f, flagE = f + 1, fail = f + 1 + WNT, flagL = f + 2 + WNT, flagC = f + 3 + WNT;   // (8 ints at most)
-    RING = BV + np + 64;
+    E = WRING ? ring_e : 0, K = S - E;
+    PAN = smem, ZST = PAN + (size_t)K * PD, BV = ZST + 4 * S;
+    int *f = (int *)(BV + np + 80);   // (the right-hand side reaches 16 nt rows past the last tile column's first: np + 64 at most)
+    flagW = f, flagE = f + 1;                                   // (flagW and up to five flagE: adjacent, 16-byte aligned)
+    fail = f + 8, flagL = f + 9, flagC = f + 10, flagF = f + 11, flagB = f + 12, flagR = f + 13;
+    RING = BV + np + 88;
+  }
+  // the panel of step s: steps [E, S) lie at the ring's slots [0, K), steps [0, E) at [K - E, K) (until step s + K takes the slot)
+  __device__ __forceinline__ double *pan(int s) const {
+    if constexpr (!WRING) return PAN + (size_t)s * PD;
+    else return PAN + (size_t)(s - E + (s < E ? K : 0)) * PD;
   }
 };
 
@@ -214,22 +240,21 @@ __device__ __forceinline__ void wv_pd_minors(double a, double b, double c, doubl
 // tile is finished takes the tile row that enters the window -- brought into LDS by the loader wave, so that no register of a
 // factor wave ever waits for global memory (a prefetch into registers made every loop trip wait: the compiler's copies of the
 // loop-carried registers cannot pass a pending load).
-template <int NT>
+template <int NT, bool RING>
 __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane,
-                                     int wave, long long *__restrict__ prof) {
+                                     int wave, int ring_e, long long *__restrict__ prof) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  const WvLayout<NT> L(smem, n);
-  constexpr int PD = WvLayout<NT>::PD;
+  const WvLayout<NT, RING> L(smem, n, ring_e);
+  constexpr int PD = WvLayout<NT, RING>::PD;
   const int S = L.S, TB = S >> 2;
-  double *const PAN = L.PAN;
   const int li = lane & 15, lk = lane >> 4;
 
   // tile row t of the columns of step sn -> its panel store (all 16 rows: the rows above the pivot are dead values)
   auto extract = [&](int sn, int t, const wv_d4 &c) {
     if ((li >> 2) == (sn & 3)) {
-      double *p = PAN + (size_t)sn * PD + (16 * t + lk) * 4 + (li & 3);
+      double *p = L.pan(sn) + (16 * t + lk) * 4 + (li & 3);
 #pragma unroll
       for (int r = 0; r < 4; r++) p[16 * r] = c[r];
     }
@@ -242,11 +267,11 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   double pv[10];     // the pivot block of the coming step: a b c / d e h / f g i j (the role-0 wave's)
   double raw0n[4];   // ... and this lane's row of tile 0 of that step's panel (columns XOR lk), requested together with it
   auto read_pivot = [&](int sn) {
-    const double *pp = PAN + (size_t)sn * PD + 16 * (sn & 3);
+    const double *pn = L.pan(sn), *pp = pn + 16 * (sn & 3);
 #pragma unroll
     for (int e = 0; e < 10; e++) pv[e] = pp[px[e]];
 #pragma unroll
-    for (int j = 0; j < 4; j++) raw0n[j] = PAN[(size_t)sn * PD + li * 4 + (j ^ lk)];
+    for (int j = 0; j < 4; j++) raw0n[j] = pn[li * 4 + (j ^ lk)];
   };
 
   // The same accesses inside a tile column whose first step's panel lies at `col`: the per-lane part of every address is
@@ -297,7 +322,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   // role 0, after its matrix instruction has been issued: W takes the pivot block's place in the panel store, the others may go
   auto publish_w = [&](int s, bool last_of_column) {
     const int cl = 4 * (s & 3);
-    double *const pan = PAN + (size_t)s * PD;
+    double *const pan = L.pan(s);
     if (last_of_column) {   // the verdict on this wave's four pivot blocks, before the step's W is announced
       if (__ballot(!(pmin > 0.0)) != 0ull && lane == 0) *(wv_lds_vint *)L.fail = 1;
     }
@@ -316,10 +341,9 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     wv_publish(L.flagW, s + 1);
   };
   // the part of a step every variant shares: W (computed or fetched), the operands; returns whether this tile row is touched
-  auto operands = [&](int s, auto rc, double &av, auto &uv) {
+  auto operands = [&](int s, const double *pan, auto rc, double &av, auto &uv) {   // pan: the panel of step s
     constexpr int R = decltype(rc)::value;
     const int cl = 4 * (s & 3);
-    double *const pan = PAN + (size_t)s * PD;
     double w[4];
     if constexpr (R == 0) {
       wv_invert_row0_cof(pv[0], pv[1], pv[2], pv[3], pv[4], pv[6], pv[7], pv[5], pv[8], pv[9], w, detk);
@@ -354,7 +378,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   // steps 4 tb .. 4 tb + 3 in role R; afterwards the wave is role R - 1 (R >= 1) or NT - 1 (R = 0)
   auto run_column = [&](int tb, auto rc) {
     constexpr int R = decltype(rc)::value;
-    double *const col = PAN + (size_t)(4 * tb) * PD;
+    double *const col = L.pan(4 * tb);
     double *const xe = col + (16 * R + lk) * 4 + (li & 3);
     ColPtr C;
     if constexpr (R == 0) col_ptrs(col, C);
@@ -363,7 +387,7 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
       const int s = 4 * tb + q;
       double av, uv[R + 1];
       double ma = pv[0], mb = pv[1], mc = pv[2], md = pv[3], me = pv[4], mh = pv[5];   // (role 0: for the minors, below)
-      const bool any = operands(s, rc, av, uv);
+      const bool any = operands(s, col + q * PD, rc, av, uv);
       if (any) {
 #pragma unroll
         for (int j = 0; j <= R; j++) T[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, uv[j], T[j], 0, 0, 0);
@@ -384,8 +408,11 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
     mid(std::integral_constant<int, 2>{});
     const int s = 4 * tb + 3;
     const bool more = s + 1 < S;
+    if constexpr (R >= 1) {
+      if (!more) return;   // the very last step only concerns the pivot tile (and nobody reads a panel the way back may be replacing)
+    }
     double av, uv[R + 1];
-    const bool any = operands(s, rc, av, uv);
+    const bool any = operands(s, col + 3 * PD, rc, av, uv);
     if constexpr (R >= 1) {   // tile column 0 is finished: its updates are skipped; this wave's tile (R, 1) is the next (R-1, 0)
       if (any) {
 #pragma unroll
@@ -417,7 +444,9 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
         // this one -- otherwise the readers take panel s's row for stored when it is not, and the counter steps back when the
         // late store lands.  (This wave is off the chain from here on: the wait costs nothing.)  Found in round 5 when the
         // chain got faster: one wrong solve in ~40 cold starts, scratch/solve_stress.py / solve_cold.py.
+#ifndef WV_TEST_UNFIXED_HANDOVER   // (only ever defined by scratch/build_unfixed_lib.sh: does the cold-start stress test see the race?)
         wv_await(L.flagE + (NT - 1), s + 1);
+#endif
         wv_publish(L.flagE + (NT - 1), s + 2);   // (orders the reads of the slot before ...)
         wv_publish(L.flagC, tb + 1);             // ... the slot is free again)
       }
@@ -425,55 +454,97 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   };
   int role = wave;
   for (int tb = 0; tb < TB; tb++) {
+    if (role == 0) __builtin_amdgcn_s_setprio(3);
+    else if (role == 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
     if (role == 0) run_column(tb, std::integral_constant<int, 0>{});
     else if (role == 1) run_column(tb, std::integral_constant<int, 1>{});
     else if (role == 2 || NT == 3) run_column(tb, std::integral_constant<int, 2>{});
+    else if (role == 3 || NT == 4) run_column(tb, std::integral_constant<int, (NT > 3 ? 3 : 2)>{});
     else run_column(tb, std::integral_constant<int, NT - 1>{});
     role = (role == 0) ? NT - 1 : role - 1;
   }
-  WPROF(1 + wave);
+  WPROF(wave < 3 ? 1 + wave : 5 + wave);   // (slots 1-3, then 8, 9; the substitution wave's are 4-6)
 }
 
 // ---- wave 4: the loader.  Tile row NT + k of the system (the tiles (NT + k, k + 1 .. k + NT): what the window gains when it
 // leaves tile column k) -> the one LDS slot, as soon as the previous occupant has been taken.
-template <int WNT>
-__device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane) {
-  const WvLayout<WNT> L(smem, n);
+// Ring of panels (WRING): this wave is also the one that keeps a panel slot from being written before its occupant has been
+// copied out, and the one that brings the early panels back.
+//   * forward: panel s + K takes the slot of panel s.  The chain wave runs through a tile column without waiting for anybody,
+//     so a wave working in tile column c is only known to have seen flagL >= c - (WNT - 1) (at the rotation in which it was
+//     handed the entering tile row); in column c it writes panels up to 4 c + 4.  flagL = k + 1 is therefore only announced once
+//     the substitution wave has left step 4 (k + WNT) + 4 - K behind (flagF).  The factor waves can complete everything up to
+//     step 4 k + 3 without that announcement, the substitution wave follows them: no deadlock as long as K >= 4 WNT + 1; in
+//     practice the substitution wave is two or three steps behind the chain and the wait never spins.
+//   * backward: tile column c of the early panels goes back into the slots of tile column c + K / 4, which the substitution wave
+//     has finished with when it announces flagB >= TB - (c + K / 4); it reads column c from iteration c + WNT on (its lanes'
+//     pending steps reach 4 WNT - 1 steps below the one it solves) and waits for flagR there: K / 4 - WNT >= 4 columns of
+//     slack, of which a column's round trip to L2 takes about two.
+template <int WNT, bool WRING>
+__device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane,
+                                     int ring_e, const double *__restrict__ spill) {
+  const WvLayout<WNT, WRING> L(smem, n, ring_e);
+  constexpr int PD = WvLayout<WNT, WRING>::PD;
   const int TB = L.S >> 2;
   for (int k = 0; k + 1 < TB; k++) {   // (the rotation behind the last tile column brings nothing in)
     wv_d4 t[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; j++) t[j] = wv_load_tile(H, n, L.np, lm, ep, WNT + k, k + 1 + j, lane);
     wv_await(L.flagC, k);
+    if constexpr (WRING) {
+      const int need = 4 * (k + WNT) + 5 - L.K;
+      if (need > 0) wv_await(L.flagF, need);
+    }
 #pragma unroll
     for (int j = 0; j < WNT; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) L.RING[(j * 4 + r) * 64 + lane] = t[j][r];
     wv_publish(L.flagL, k + 1);
   }
+  if constexpr (WRING) {
+    const int E4 = L.E >> 2, K4 = L.K >> 2;
+    constexpr int NL = PD / 32;          // 16-byte pieces per lane of a tile column's four panels
+    wv_await(L.flagB, 1);                // the forward pass is over and the substitution wave has waited for its stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (nothing of the scratch may be served from this CU's L1)
+    for (int c = E4 - 1; c >= 0; c--) {
+      const double *g = spill + (size_t)(4 * c) * PD + 2 * lane;
+      wv_d2 t[NL];
+#pragma unroll
+      for (int i = 0; i < NL; i++) t[i] = *(const wv_d2 *)(g + 128 * i);
+      wv_await(L.flagB, TB - (c + K4));
+      double *p = L.pan(4 * c) + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < NL; i++) *(wv_d2 *)(p + 128 * i) = t[i];
+      wv_publish(L.flagR, E4 - c);
+    }
+  }
 }
 
 // ---- wave 3: the right-hand side behind the factorisation (z = W b1, b2 -= R z), then the backward substitution,
 // right-looking: lane (slot, k) = (lane >> 2, lane & 3) accumulates v_s[k] = sum_i R_s[i][k] x[i] for the step s = slot
 // (mod 16) that still receives solved unknowns (a window spans at most 4 NT <= 16 steps); x1 = z - W v.
-template <int WNT>
+template <int WNT, bool WRING>
 __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, float *__restrict__ dx, int *__restrict__ meta,
-                                    double *__restrict__ smem, int lane, long long *__restrict__ prof) {
+                                    double *__restrict__ smem, int lane, int ring_e, double *__restrict__ spill,
+                                    long long *__restrict__ prof) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  const WvLayout<WNT> L(smem, n);
-  constexpr int PR = WvLayout<WNT>::PR, PD = WvLayout<WNT>::PD;
+  const WvLayout<WNT, WRING> L(smem, n, ring_e);
+  constexpr int PR = WvLayout<WNT, WRING>::PR, PD = WvLayout<WNT, WRING>::PD;
+  constexpr int XR = PR > 64 ? PR - 64 : 0;   // rows of the window beyond one per lane (16 with five tile rows)
+  static_assert(!WRING || PR >= 64, "the copy to scratch takes a panel row per lane");
   const int np = L.np, S = L.S;
   double *const PAN = L.PAN, *const ZST = L.ZST, *const BV = L.BV;
-  for (int i = lane; i < np + 60; i += 64) {
+  for (int i = lane; i < np + 80; i += 64) {
     const double bv = bvec[min(i, n - 1)];
     BV[i] = (i < n) ? bv : 0.0;
   }
   wv_order();
   for (int s = 0; s < S; s++) {
     const int tb = s >> 2, cl = 4 * (s & 3);
-    const double *pan = PAN + (size_t)s * PD;
+    const double *pan = L.pan(s);
     wv_await_all<WNT + 1>(L.flagW, s + 1);   // (flagW, flagE[0 .. WNT-1]: adjacent)
     double z[4];
     const double b0 = BV[4 * s], b1 = BV[4 * s + 1], b2 = BV[4 * s + 2], b3 = BV[4 * s + 3];
@@ -482,16 +553,50 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       const double *wr = pan + (cl + k) * 4;
       z[k] = fma(wr[3], b3, fma(wr[2], b2, fma(wr[1], b1, wr[0] * b0)));
     }
-    if (lane < PR && lane > cl + 3) {
-      const double *rr = pan + lane * 4;
-      double *bp = BV + 16 * tb + lane;
-      *bp = fma(-rr[3], z[3], fma(-rr[2], z[2], fma(-rr[1], z[1], fma(-rr[0], z[0], *bp))));
+    auto sub_row = [&](int row, const wv_d2 &r01, const wv_d2 &r23) {   // b2[row] -= R[row][:] z
+      double *bp = BV + 16 * tb + row;
+      *bp = fma(-r23.y, z[3], fma(-r23.x, z[2], fma(-r01.y, z[1], fma(-r01.x, z[0], *bp))));
+    };
+    if constexpr (WRING) {
+      // every lane reads its panel row (the dead rows above the pivot and W's rows too): the early panels leave for scratch
+      const wv_d2 r01 = *(const wv_d2 *)(pan + lane * 4), r23 = *(const wv_d2 *)(pan + lane * 4 + 2);
+      wv_d2 x01 = {0.0, 0.0}, x23 = {0.0, 0.0};
+      if constexpr (XR > 0) {
+        if (lane < XR) x01 = *(const wv_d2 *)(pan + (64 + lane) * 4), x23 = *(const wv_d2 *)(pan + (64 + lane) * 4 + 2);
+      }
+      if (s < L.E) {
+        double *g = spill + (size_t)s * PD + lane * 4;
+        *(wv_d2 *)g = r01, *(wv_d2 *)(g + 2) = r23;
+        if constexpr (XR > 0) {
+          if (lane < XR) *(wv_d2 *)(g + 256) = x01, *(wv_d2 *)(g + 258) = x23;
+        }
+      }
+      if (lane > cl + 3) sub_row(lane, r01, r23);
+      if constexpr (XR > 0) {
+        if (lane < XR) sub_row(64 + lane, x01, x23);
+      }
+    } else {
+      if (lane < PR && lane > cl + 3) {
+        const double *rr = pan + lane * 4;
+        double *bp = BV + 16 * tb + lane;
+        *bp = fma(-rr[3], z[3], fma(-rr[2], z[2], fma(-rr[1], z[1], fma(-rr[0], z[0], *bp))));
+      }
+      if constexpr (XR > 0) {
+        if (lane < XR) sub_row(64 + lane, *(const wv_d2 *)(pan + (64 + lane) * 4), *(const wv_d2 *)(pan + (64 + lane) * 4 + 2));
+      }
     }
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 4; k++) ZST[4 * s + k] = z[k];
     }
     wv_order();
+    if constexpr (WRING) {
+      if ((s & 3) == 3) wv_publish(L.flagF, s + 1);   // panels up to s have been read (and sent off): their slots may be rewritten
+    }
+  }
+  if constexpr (WRING) {   // the copies have arrived before anybody is told that the way back has begun (flagB)
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   }
   const bool bad = *(wv_lds_vint *)L.fail != 0;
   WPROF(4);
@@ -500,9 +605,14 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     // of W: two 16-byte reads) -- so each quad holds x1[0..3] -- and fetches the other three from its quad neighbours (DPP);
     // then its own accumulator takes the step's contribution.  ~40 instructions per step, the chain: readlane -> 4 FMA ->
     // quad broadcast -> 4 FMA.
+    // Five tile rows (80-row window): a panel spans up to 19 steps, the 16 slots do not cover them -- a lane's PREVIOUS pending
+    // step (16 steps further down) already receives its first contributions (distances 16 .. 18 - (slot & 3)) while the
+    // lane's accumulator still belongs to the current one; they go into a second accumulator, which becomes the first when the
+    // current step is solved.
+    constexpr bool FAR = PR > 64;
     const int slot = lane >> 2, kk = lane & 3;
-    double v = 0.0;
-    struct Ops { wv_d2 w01, w23; double z, r[4]; bool valid; };
+    double v = 0.0, vfar = 0.0;
+    struct Ops { wv_d2 w01, w23; double z, r[4], r2[4]; bool valid, valid2; };
     // Addresses.  The steps are walked a tile column (four steps, q = 3..0) at a time, so that what depends on the step inside
     // the column sits in the instructions' offset fields and the per-lane part is formed once per column (row k of W:
     // wc + q (PD + 16); z: zc + 4 q; the solved unknowns: xc + 4 q).  The panel rows a lane's accumulator takes
@@ -513,6 +623,12 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     const int dmax = PR / 4 - 2 - (slot & 3);
     int u = S - 2 - slot;                                  // for the step fetched next (S - 1 first)
     const double *rp = PAN + (slot * PD + 16 * (slot & 3) + kk + 16) + 16 * u + 16 * (PD - 16) * (u >> 4);
+    if constexpr (WRING) {   // (that was the address in a store of all S panels: the ring holds step s at s - E, or s - E + K below the seam)
+      const int pending = slot + 16 * (u >> 4);
+      rp += (ptrdiff_t)((u >= 0 && pending < L.E) ? L.K - L.E : -L.E) * PD;
+    }
+    // a lane's pending step slot + 16 m crosses the seam when m drops below seam_m, i.e. when its u becomes 16 seam_m - 1
+    const int seam_m = (L.E - slot + 15) >> 4, seam_u = 16 * seam_m - 1, seam_jump = L.K * PD;
     const double *const rsafe = PAN + kk;
     auto fetch = [&](const double *wc, const double *zc, int sp, auto qc, Ops &o) {   // everything step sp = 4 c + q reads off the chain
       constexpr int q = decltype(qc)::value;
@@ -522,13 +638,26 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       const double *ra = o.valid ? rp : rsafe;
 #pragma unroll
       for (int m = 0; m < 4; m++) o.r[m] = ra[4 * m];
+      if constexpr (FAR) {   // the same rows of x in the panel 16 steps down: 64 rows further into its window
+        o.valid2 = (u >= 16) && ((u & 15) <= dmax - 16);
+        const double *rb = rp - 16 * PD + 256;
+        if constexpr (WRING) rb += ((u >> 4) == seam_m) ? seam_jump : 0;   // (that panel lies below the seam, this one above)
+        rb = o.valid2 ? rb : rsafe;
+#pragma unroll
+        for (int m = 0; m < 4; m++) o.r2[m] = rb[4 * m];
+      }
       // ... and the lane's state for the step below this one
       u -= 1;
       rp -= (slot == ((sp - 1) & 15)) ? 16 * (PD - 15) : 16;
+      if constexpr (WRING) rp += (u == seam_u) ? seam_jump : 0;
       // (keeps the prefetch where it was issued)
       asm volatile("" : "+v"(o.w01), "+v"(o.w23), "+v"(o.z));
 #pragma unroll
       for (int k = 0; k < 4; k++) asm volatile("" : "+v"(o.r[k]));
+      if constexpr (FAR) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(o.r2[k]));
+      }
     };
     auto quad = [&](double x, auto mc) {   // the value of lane (quad, m) in all four lanes of the quad
       constexpr int m = decltype(mc)::value;
@@ -552,14 +681,22 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       const double x0 = quad(xk, std::integral_constant<int, 0>{}), x1 = quad(xk, std::integral_constant<int, 1>{}),
                    x2 = quad(xk, std::integral_constant<int, 2>{}), x3 = quad(xk, std::integral_constant<int, 3>{});
       const double upd = fma(o.r[3], x3, fma(o.r[2], x2, fma(o.r[1], x1, o.r[0] * x0)));
-      v = o.valid ? v + upd : v;
-      v = (slot == (sp & 15)) ? 0.0 : v;
+      if constexpr (FAR) {
+        const double upd2 = fma(o.r2[3], x3, fma(o.r2[2], x2, fma(o.r2[1], x1, o.r2[0] * x0)));
+        const bool own = slot == (sp & 15);        // this lane's step has just been solved: its next one takes over
+        const double base = own ? vfar : v;
+        v = o.valid ? base + upd : base;
+        vfar = own ? 0.0 : (o.valid2 ? vfar + upd2 : vfar);
+      } else {
+        v = o.valid ? v + upd : v;
+        v = (slot == (sp & 15)) ? 0.0 : v;
+      }
     };
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
     using Q3 = std::integral_constant<int, 3>;
-    auto wcol = [&](int c) { return PAN + (size_t)(4 * c) * PD + 4 * kk; };   // row k of W of the column's first step
+    auto wcol = [&](int c) { return L.pan(4 * c) + 4 * kk; };   // row k of W of the column's first step
     Ops oa, ob;
     const int TBs = S >> 2;   // (S is a multiple of 4: np is a multiple of 16)
     const double *wc = wcol(TBs - 1), *zc = ZST + 16 * (TBs - 1) + kk;
@@ -567,6 +704,10 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     for (int c = TBs - 1; c >= 0; c--) {   // each step's operands requested a step ahead
       const int s0 = 4 * c, cn = max(c - 1, 0);
       double *const xc = BV + 16 * c + lane;
+      if constexpr (WRING) {   // this iteration reads tile columns c - WNT .. c: are the early ones back?
+        const int E4 = L.E >> 2;
+        if (c - WNT < E4) wv_await(L.flagR, min(E4, E4 - (c - WNT)));
+      }
       fetch(wc, zc, s0 + 2, Q2{}, ob);
       solve_step(xc, s0 + 3, Q3{}, oa);
       fetch(wc, zc, s0 + 1, Q1{}, oa);
@@ -576,6 +717,7 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       wc = wcol(cn), zc = ZST + 16 * cn + kk;
       fetch(wc, zc, s0 - 1, Q3{}, oa);     // (column c - 1; below the first column: a harmless re-read of column 0)
       solve_step(xc, s0, Q0{}, ob);
+      if constexpr (WRING) wv_publish(L.flagB, TBs - c);   // (every read of tile column c and above has been issued)
     }
   }
   wv_order();
@@ -594,26 +736,39 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
 // the sixth leaves at once when the system fits the 48-row window).  Every wave runs the admission test (no exchange needed
 // to agree).  A system that is not admitted is solved by the general blocked kernel's code with the same waves; `verdict`
 // (pinned host memory) tells the host which it was: 1 taken, 2 not.
-template <int NT>
+template <int NT, bool RING>
 __device__ __forceinline__ void ba_solve_wave_run(const double *__restrict__ H, const double *__restrict__ bvec, int n, double lm,
                                                   double ep, float *__restrict__ dx, int *__restrict__ meta,
-                                                  double *__restrict__ smem, int lane, int wave, long long *__restrict__ prof) {
+                                                  double *__restrict__ smem, int lane, int wave, int ring_e,
+                                                  double *__restrict__ spill, long long *__restrict__ prof) {
   {
-    const WvLayout<NT> L(smem, n);
-    if (threadIdx.x < 8) L.flagW[threadIdx.x] = 0;   // flagW, flagE[NT], fail, flagL, flagC
+    const WvLayout<NT, RING> L(smem, n, ring_e);
+    if (threadIdx.x < 16) L.flagW[threadIdx.x] = 0;   // flagW, flagE[NT] | fail, flagL, flagC, flagF, flagB, flagR
   }
   __syncthreads();
-  if (wave < NT) ba_solve_wave_factor<NT>(n, smem, H, lm, ep, lane, wave, prof);
-  else if (wave == NT) ba_solve_wave_subst<NT>(bvec, n, dx, meta, smem, lane, prof);
-  else if (wave == NT + 1) ba_solve_wave_loader<NT>(n, smem, H, lm, ep, lane);
+  // Which hardware wave plays which part: the CU deals a workgroup's waves out to its four SIMDs in turn (wave i -> SIMD i & 3),
+  // and a wave that shares its SIMD with another busy one issues at half the rate -- with five factor waves the chain slowed from
+  // 0.40 to 0.55 us per step.  So: the factor waves that share a SIMD are two roles apart (never chain and next-in-line), the
+  // loader (asleep most of the time) and the substitution wave take the other shared places, and the instruction arbiter is told
+  // who matters (s_setprio: chain 3, next in line 2, substitution 1).
+  int part = wave;                    // 0 .. NT - 1: factor wave, NT: substitution, NT + 1: loader
+  if constexpr (NT == 5) {
+    // SIMD 0: factor 0 + 2, SIMD 1: factor 1 + loader, SIMD 2: factor 3 + substitution, SIMD 3: factor 4
+    part = wave == 2 ? 3 : wave == 3 ? 4 : wave == 4 ? 2 : wave == 5 ? 6 : wave == 6 ? 5 : wave;
+  }
+  if (part < NT) ba_solve_wave_factor<NT, RING>(n, smem, H, lm, ep, lane, part, ring_e, prof);
+  else if (part == NT) {
+    __builtin_amdgcn_s_setprio(1);
+    ba_solve_wave_subst<NT, RING>(bvec, n, dx, meta, smem, lane, ring_e, spill, prof);
+  } else if (part == NT + 1) ba_solve_wave_loader<NT, RING>(n, smem, H, lm, ep, lane, ring_e, spill);
 }
 
 template <bool GENERAL_IN_LDS>
-__global__ __launch_bounds__(384) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
+__global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
                                                             const int *__restrict__ fpose, int n, double lm, double ep,
                                                             float *__restrict__ dx, int *__restrict__ meta,
                                                             double *__restrict__ Lglobal, int *__restrict__ verdict, int max_nt,
-                                                            long long *__restrict__ prof) {
+                                                            int ring_e4, int ring_e5, long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) double wv_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nt = ba_solve_wave_admits(fpose, n, lane, max_nt);
@@ -621,15 +776,20 @@ __global__ __launch_bounds__(384) void ba_solve_wave_kernel(const double *__rest
     meta[3] = 1;   // (solved either way: a kernel queued behind with `skip_if_solved` returns at once)
     if (verdict) __hip_atomic_store(verdict, nt ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (nt == 3) ba_solve_wave_run<3>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, prof);
-  else if (nt == 4) ba_solve_wave_run<4>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, prof);
+  // (ring_e4: how many of the 64-row window's early panels leave LDS for Lglobal -- 0 up to 45 poses)
+  if (nt == 3) ba_solve_wave_run<3, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, prof);
+  else if (nt == 4 && ring_e4 == 0) ba_solve_wave_run<4, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, prof);
+  else if (nt == 4) ba_solve_wave_run<4, true>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, ring_e4, Lglobal, prof);
+  else if (nt == 5 && ring_e5 == 0) ba_solve_wave_run<5, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, prof);
+  else if (nt == 5) ba_solve_wave_run<5, true>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, ring_e5, Lglobal, prof);
   else ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
 }
 
-int ba_solve_wave_max_nt(int n) {   // the tallest window whose panel store fits LDS for a system of n unknowns (0: none)
+int ba_solve_wave_max_nt(int n) {   // the tallest window whose panel store (or a ring of it) fits LDS for n unknowns (0: none)
   if (n <= 0 || n % 6 != 0 || n / 6 > 64) return 0;
-  if (wv_lds_doubles(n, 4) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 4;
-  if (wv_lds_doubles(n, 3) * sizeof(double) <= (size_t)SOLVE_MAX_LDS_BYTES) return 3;
+  if (wv_ring_early(n, 5) >= 0) return 5;
+  if (wv_ring_early(n, 4) >= 0) return 4;
+  if (wv_ring_early(n, 3) == 0) return 3;
   return 0;
 }
 
@@ -638,8 +798,16 @@ bool ba_solve_wave_supported(int n) { return ba_solve_wave_max_nt(n) != 0; }
 // Lscratch: the workspace's packed-triangle scratch (needed by the fall-back when the system does not fit LDS: n > 199)
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                          double *Lscratch, int *verdict, hipStream_t stream, long long *prof) {
-  const int max_nt = ba_solve_wave_max_nt(n);
+  int max_nt = ba_solve_wave_max_nt(n);
   if (!max_nt || !fpose) return DBA_ERR_UNSUPPORTED;
+  const int S = ((n + 15) & ~15) >> 2;
+  int ring_e[6] = {0, 0, 0, 0, 0, 0};
+  const size_t scratch = Lscratch ? ba_solve_scratch_doubles(n) : 0;
+  for (int nt = max_nt; nt >= 3; nt--) {   // the tallest window whose early panels (if any leave LDS) have room in the scratch
+    ring_e[nt] = wv_ring_early(n, nt);
+    if (ring_e[nt] < 0 || (size_t)ring_e[nt] * (64 * nt) > scratch) max_nt = nt - 1;
+  }
+  if (max_nt < 3) return DBA_ERR_UNSUPPORTED;
   static DeviceOnce attr_once;
   if (attr_once.needed()) {
     DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_kernel<true>),
@@ -648,15 +816,16 @@ int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
     attr_once.done();
   }
-  const size_t wave_lds = wv_lds_doubles(n, max_nt) * sizeof(double);
+  size_t wave_lds = 0;
+  for (int nt = 3; nt <= max_nt; nt++) wave_lds = std::max(wave_lds, wv_lds_doubles_k(n, nt, S - ring_e[nt]) * sizeof(double));
   const size_t gen_lds = solve_packed_bytes(n) + solve_small_bytes(n);
   if (gen_lds <= (size_t)SOLVE_MAX_LDS_BYTES) {
-    hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(384), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
-                       ep, dx, meta, Lscratch, verdict, max_nt, prof);
+    hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(WV_THREADS), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
+                       ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof);
   } else {
     if (!Lscratch) return DBA_ERR_WORKSPACE;
-    hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(384), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
-                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, max_nt, prof);
+    hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(WV_THREADS), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
+                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

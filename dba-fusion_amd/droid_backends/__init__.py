@@ -126,6 +126,11 @@ class _BaWorkspaces:
         N, B, ht, wd, t0, t1 = dims
         if not (174 < 6 * (t1 - t0) <= 384):
             return 0
+        # (round 6: the window kernel takes bands of up to ten poses at these sizes too -- nothing is queued behind it, and the
+        # verdict stage 0 left in pinned host memory says so without a synchronisation; only a graph it refuses gets here)
+        ws, nbytes = self.ws[key]
+        if _lib.load().dba_ba_solver_verdict(N, B, ht, wd, t0, t1, _ptr(ws), nbytes) != 2:
+            return 0
         h = self.plan.get(key)
         if h is None:
             lay = _lib.BaLayout()

@@ -1,0 +1,3 @@
+#!/bin/bash
+OUT=$PWD/gpurun_out; mkdir -p $OUT
+( time timeout 2400 python -m pytest tests -q -m gpu ) > $OUT/r6_pytest_gpu.txt 2>&1; tail -8 $OUT/r6_pytest_gpu.txt

@@ -12,7 +12,7 @@ namespace dba { long long *g_tile_prof; }
 #else
 #include "../dba-fusion_amd/csrc/ba_solve_wave.hip"
 #endif
-namespace dba { void set_last_error(const char*, hipError_t) {} }
+namespace dba { void set_last_error(const char*, hipError_t) {} size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; } }
 static bool host_solve(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
   for (int j = 0; j < n; j++) {
     double d = A[j*n+j]; for (int k = 0; k < j; k++) d -= A[j*n+k]*A[j*n+k];
@@ -34,7 +34,10 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
   for (int p = 0; p < P; p++) {
     fpose[p] = p;
     for (int q = 0; q <= p; q++) {
-      const bool on = (p - q <= w) || (p == ex_p && q == ex_q);
+      // ex_p == -2: the literal skyline of the reduced system of BASELINE's 64-KF / 512-edge graph (|i - j| <= 4 plus (i, i + 5) for
+      // i < 10, frame 0 fixed; two poses are coupled when they see the same source frame: 8 poses wide, 9-10 among the first 18)
+      const int lit = p <= 10 ? 0 : p <= 13 ? p - 10 : p <= 17 ? p - 9 : p - 8;
+      const bool on = (p - q <= w) || (p == ex_p && q == ex_q) || (ex_p == -2 && q >= lit);
       if (!on) continue;
       if (q < fpose[p]) fpose[p] = q;
       for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
@@ -77,7 +80,7 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
         printf("   stages us (wall clock per wave; one front: top only): top factor load %.2f w0 %.2f w1 %.2f w2 %.2f | bottom factor load %.2f w0 %.2f w1 %.2f w2 %.2f | separator factor load %.2f w0 %.2f w1 %.2f w2 %.2f\n", u(0)/3, u(1), u(2), u(3), u(8)/3, u(9), u(10), u(11), u(12)/3, u(13), u(14), u(15));
         printf("          top subst: init+forward %.2f separator (wait, forward, backward) %.2f backward %.2f wait for bottom + store %.2f | bottom subst: init+forward %.2f wait for the separator %.2f backward %.2f\n", u(4), u(5), u(7), u(6), u(20), u(21), u(22)); }
 #else
-        printf("   stages us (wall clock per wave): [factor waves] load + first panel %.2f factor w0 %.2f w1 %.2f w2 %.2f | [substitution wave] init + forward (behind the factorisation) %.2f backward %.2f verdict + store %.2f\n", u(0)/3, u(1), u(2), u(3), u(4), u(5), u(6)); }
+        printf("   stages us (wall clock per wave): [factor waves] load + first panel (sum) %.2f factor w0 %.2f w1 %.2f w2 %.2f w3 %.2f w4 %.2f | [substitution wave] init + forward (behind the factorisation) %.2f backward %.2f verdict + store %.2f\n", u(0), u(1), u(2), u(3), u(8), u(9), u(4), u(5), u(6)); }
 #endif
     }
   }
@@ -92,6 +95,13 @@ int main() {
   run(8, 4, true, false); run(3, 2, true, false); run(2, 1, true, false); run(1, 0, true, false); run(29, 4, true, true); run(16, 3, true, false);
   run(63, 4, true, true); run(40, 4, true, true); run(64, 3, true, false);
   run(24, 5, true, true); run(24, 6, true, true); run(24, 7, true, false); run(24, 23, true, false);   // wider bands: NT = 4, then not admitted
+  // round 6: the ring of panels (64-row window beyond 48 poses)
+  run(63, 4, true, true, -2); run(63, 8, true, true); run(63, 9, true, true); run(63, 10, true, true); run(64, 10, true, true);
+  run(24, 8, true, true); run(24, 10, true, true); run(37, 9, true, true); run(38, 10, true, true); run(45, 8, true, false); run(52, 10, true, false);
+  run(60, 9, true, true); run(59, 10, true, false); run(63, 10, false, false); run(30, 8, false, false); run(63, 11, true, false);
+  run(63, 5, true, true); run(63, 6, true, true); run(63, 7, true, true); run(64, 7, true, true);
+  run(49, 5, true, true); run(61, 6, true, false); run(50, 7, true, false); run(56, 5, true, false); run(48, 7, true, true);
+  run(63, 5, false, false); run(64, 7, false, false);
   run(24, 4, false, false); run(63, 4, false, false); run(8, 2, false, false);                          // not positive definite
   run(24, 2, true, false, 20, 3); run(24, 2, true, false, 9, 5); run(24, 3, true, false, 23, 17);       // an extra coupling: arrow / inside the window
   return 0;

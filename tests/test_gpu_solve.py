@@ -280,7 +280,7 @@ def test_window_kernel_solves_banded_systems(P, w):
 
 @pytest.mark.parametrize("P,w", [(24, 5), (24, 6), (24, 7), (12, 7), (40, 6), (45, 5)])
 def test_window_kernel_with_four_factor_waves_takes_wider_bands(P, w):
-    """bands of 5-7 poses: the 64-row window (four factor waves), for systems whose taller panel store fits LDS (<= 45 poses)"""
+    """bands of 5-7 poses: the 64-row window (four factor waves); up to 48 poses its whole panel store fits LDS"""
     rng = np.random.default_rng(13 * P + w)
     H, b, fpose = _pose_system(rng, P, w)
     S = _SkylineSolver(P)
@@ -294,7 +294,77 @@ def test_window_kernel_with_four_factor_waves_takes_wider_bands(P, w):
         assert failed == 0 and np.array_equal(dx, first), rep
 
 
-@pytest.mark.parametrize("P,w,extra", [(24, 9, ()), (24, 23, ()), (24, 2, ((20, 3),)), (50, 6, ()), (63, 9, ()),
+def _skyline_pairs_64_512():
+    """pose-level couplings of the REDUCED system of BASELINE configs[3] (synthetic.graph_64_512: |i - j| <= 4 plus (i, i + 5) for
+    i < 10; frame 0 fixed): two poses are coupled when they see the same source frame's depths -- 8 poses wide, 9-10 among the
+    first 18 (what stage 0's skyline table records)"""
+    from dbaf_amd import synthetic
+    ii, jj = synthetic.graph_64_512()
+    pairs = set()
+    for m in set(ii):
+        grp = sorted({m} | {j for i, j in zip(ii, jj) if i == m})
+        pairs |= {(a - 1, b - 1) for a in grp for b in grp if a > b >= 1}
+    return sorted(pairs)
+
+
+@pytest.mark.parametrize("P,w", [(63, 5), (63, 6), (63, 7), (64, 5), (64, 6), (64, 7), (49, 5), (50, 7), (56, 6), (61, 6), (48, 7),
+                                  (24, 8), (24, 10), (30, 9), (37, 10), (38, 8), (45, 9), (52, 10), (59, 8), (60, 10), (63, 8),
+                                  (63, 9), (63, 10), (64, 8), (64, 10)])
+def test_window_kernel_with_the_ring_of_panels_takes_wide_bands_up_to_64_poses(P, w):
+    """round 6: bands of 5-7 poses take the 64-row window (four factor waves), 8-10 poses -- what a covisibility graph of radius
+    4-5 gives -- the 80-row window (five).  Beyond 48 (37) poses their panel stores (2 / 2.5 KB per step) do not fit LDS: a ring
+    of 56-72 steps, the early panels parked in scratch by the substitution wave and brought back by the loader wave on the
+    way back (csrc/ba_solve_wave.hip); the window kernel must TAKE these systems (verdict 1), not hand them to the skyline kernel"""
+    rng = np.random.default_rng(13 * P + w)
+    H, b, fpose = _pose_system(rng, P, w)
+    S = _SkylineSolver(P)
+    dx, failed = S.solve(H, b, fpose)
+    ref = _ref(H, b)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+    assert S.lib.dba_ba_solver_verdict(*S.dims, ctypes.c_void_p(S.ws.data_ptr()), S.nbytes) == 1
+    first = dx
+    for rep in range(40):
+        dx, failed = S.solve(H, b, fpose)
+        assert failed == 0 and np.array_equal(dx, first), rep
+
+
+def test_window_kernel_takes_the_literal_64_512_skyline():
+    """BASELINE configs[3]: 63 free poses, the reduced system 8 poses wide (9-10 among the first 18: the (i, i + 5) edges) --
+    round 5 solved this graph with the skyline kernel (101 us); three systems of that structure alternate so that no solve finds
+    its own values left behind in LDS or in the scratch"""
+    pairs = _skyline_pairs_64_512()
+    P = 63
+    systems = []
+    for k in range(3):
+        rng = np.random.default_rng(600 + k)
+        H, b, fpose = _pose_system(rng, P, 0, extra=pairs)
+        systems.append((H * (1.0 + 0.5 * k), b * (1.0 - 0.3 * k), fpose))
+    S = _SkylineSolver(P)
+    firsts = [None] * 3
+    for rep in range(20):
+        for k, (H, b, fpose) in enumerate(systems):
+            dx, failed = S.solve(H, b, fpose)
+            assert failed == 0
+            if firsts[k] is None:
+                ref = _ref(H, b)
+                np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+                firsts[k] = dx
+            assert np.array_equal(dx, firsts[k]), (rep, k)
+    assert S.lib.dba_ba_solver_verdict(*S.dims, ctypes.c_void_p(S.ws.data_ptr()), S.nbytes) == 1
+
+
+@pytest.mark.parametrize("P,w,where", [(63, 5, 3), (63, 5, 190), (63, 5, 377), (64, 7, 100), (49, 6, 293), (63, 8, 5), (63, 10, 200),
+                                        (64, 9, 383), (30, 8, 90)])
+def test_window_kernel_with_the_ring_gives_a_zero_update_for_an_indefinite_system(P, w, where):
+    rng = np.random.default_rng(P + where)
+    H, b, fpose = _pose_system(rng, P, w)
+    H[where, where] = -1.0
+    dx, failed = _SkylineSolver(P).solve(H, b, fpose)
+    assert failed == 1 and np.all(dx == 0.0)
+
+
+@pytest.mark.parametrize("P,w,extra", [(24, 12, ()), (24, 23, ()), (24, 2, ((20, 3),)), (50, 12, ()), (63, 13, ()),
                                         (63, 2, ((60, 1),))])
 def test_systems_that_are_not_banded_are_solved_in_the_same_launch_and_then_by_the_other_kernels(P, w, extra):
     """the window kernel's admission test refuses these: the general kernel's code solves them inside its launch (first solve

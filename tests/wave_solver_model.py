@@ -13,12 +13,31 @@ LI = LANES & 15          # column of the C / D layout, row of the A layout, colu
 LK = LANES >> 4          # row group of the C / D layout, k of the A and B layouts
 NT = 3                   # tile rows of the window (16 rows each): 3 or 4 in the kernel (set_window)
 PAN_ROWS = 16 * NT
+RING_K = None            # panels the LDS store holds (None: all of them); set_ring
+RELOAD = "late"          # when the early panels come back during the backward pass: as late / as early as the flags allow
 
 
 def set_window(nt):
     """the kernel's template parameter: 3 (48-row window) or 4 (64 rows, four factor waves)"""
     global NT, PAN_ROWS
     NT, PAN_ROWS = nt, 16 * nt
+
+
+def set_ring(k, reload="late"):
+    """round 6: the panel store as a ring of k steps (the kernel's wv_ring_early decides E = S - k from the LDS budget); the
+    first S - k panels are copied to scratch by the forward substitution and brought back during the backward pass"""
+    global RING_K, RELOAD
+    RING_K, RELOAD = k, reload
+
+
+def ring_early(S, pd_bytes, fixed_bytes, budget=160 * 1024):
+    """the kernel's wv_ring_early: the smallest number of early panels (whole tile columns) to evict so that the store fits"""
+    E = 0
+    while E == 0 or (2 * E <= S and S - E >= 32):
+        if (S - E) * pd_bytes + fixed_bytes <= budget:
+            return E
+        E += 4
+    return -1
 
 
 def mfma_16x16x4(a, b, c):
@@ -72,6 +91,50 @@ def band_ok(fpose, n):
     return True
 
 
+class _RingView:
+    """PAN[s, ...] of the kernel's layout: step s lives in slot s - E (s >= E) or s - E + K (s < E); a read of a step the slot
+    does not hold at that moment is an error of the protocol"""
+
+    def __init__(self, inst):
+        self.i = inst
+
+    def slot(self, s):
+        i = self.i
+        return s - i.E + (i.K if s < i.E else 0)
+
+    def _split(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        return key[0], key[1:]
+
+    def __getitem__(self, key):
+        s, rest = self._split(key)
+        i = self.i
+        if np.ndim(s) == 0:
+            s = int(s)
+            if s >= i.S:                      # (the model's harmless extra panel behind the last step)
+                return np.full((PAN_ROWS, 4), np.nan)[rest] if rest else np.full((PAN_ROWS, 4), np.nan)
+            assert i.holds[self.slot(s)] == s, "panel %d is not in its slot (which holds %d)" % (s, i.holds[self.slot(s)])
+            v = i.PAN_[self.slot(s)]
+            return v[rest] if rest else v      # (a view: writes through `pan = self.PAN[s]` land in the store)
+        raise TypeError("vector step index: use Instance.pan_read")
+
+    def __setitem__(self, key, val):
+        s, rest = self._split(key)
+        i = self.i
+        s = int(s)
+        if s >= i.S:
+            return
+        sl = self.slot(s)
+        if i.holds[sl] != s:
+            # a new occupant: the previous one must be gone for good (forward: copied out; backward: not read any more)
+            prev = i.holds[sl]
+            assert prev < 0 or prev in i.released, "panel %d would overwrite panel %d, which is still needed" % (s, prev)
+            i.PAN_[sl] = np.nan
+            i.holds[sl] = s
+        i.PAN_[sl][rest] = val
+
+
 class Instance:
     """one (sub-)system the waves of the kernel work on: `elem(i, j)` = the damped local matrix (i >= j < nloc; identity padding
     beyond nloc is added here), `rhs(i)`; `sel` = steps to eliminate (all of them for a complete solve)"""
@@ -81,12 +144,19 @@ class Instance:
         self.np_ = (nloc + 15) // 16 * 16
         self.S = self.np_ // 4
         self.sel = self.S if sel is None else sel
-        self.PAN = np.full((self.S + 1, PAN_ROWS, 4), np.nan)      # LDS: panel storage, NaN = never written
+        self.K = self.S if RING_K is None else min(RING_K, self.S)
+        self.E = self.S - self.K
+        assert self.E % 4 == 0 and self.E <= self.K
+        self.PAN_ = np.full((self.K, PAN_ROWS, 4), np.nan)          # LDS: panel storage (a ring of K steps), NaN = never written
+        self.holds = [-1] * self.K                                  # which step's panel a slot holds
+        self.SPILL = np.full((self.E, PAN_ROWS, 4), np.nan)         # global scratch: the early panels
+        self.PAN = _RingView(self)
         self.ZST = np.full((self.S, 4), np.nan)
         self.BV = np.zeros(self.np_ + 64)
         self.BV[:nloc] = [rhs(i) for i in range(nloc)]
         self.bad = np.zeros(64, bool)
         self.acc = None
+        self.released = set()                                       # panels whose slot may be taken by another step
 
     # ---- a tile in the C layout: reg r, lane -> (16 TI + (lane >> 4) + 4 r, 16 TJ + (lane & 15))
     def load_tile(self, TI, TJ):
@@ -155,6 +225,9 @@ class Instance:
                 if l > cl + 3:
                     self.BV[16 * tb + l] -= pan[l, :] @ z
             self.ZST[s] = z
+            if s < self.E:                      # the substitution wave has read the whole panel: the early ones leave for scratch
+                self.SPILL[s] = pan
+                self.released.add(s)
             # 7. the window moves on by one tile column
             if q == 3:
                 for ti in range(NT - 1):
@@ -189,10 +262,29 @@ class Instance:
         Sx = self.S if given is None else self.sel + (len(given) + 3) // 4
         slot, k = LANES >> 2, LANES & 3
         v = np.zeros(64)
+        vfar = np.zeros(64)      # five tile rows: a panel spans up to 19 steps, the lane's step 16 further down already collects
         x = np.zeros(self.np_ + 64)
         if given is not None:
             x[4 * self.sel:4 * self.sel + len(given)] = given
+        E4, K4, TB = self.E // 4, self.K // 4, self.S // 4
+
+        def reload(c):
+            for s4 in range(4 * c, 4 * c + 4):
+                self.PAN[s4] = self.SPILL[s4]
+        reloaded = E4                            # tile columns >= reloaded are in LDS
+        self.released = set()                    # (forward releases are history: on the way back a slot is free when its column is done)
         for sp in range(Sx - 1, -1, -1):
+            if self.E and (sp & 3) == 3 and given is None:
+                c = sp >> 2                      # iteration c of the kernel's backward loop begins: it reads tile columns c - NT .. c
+                if RELOAD == "early":            # everything the flags allow: column j may return once column j + K / 4 is finished
+                    while reloaded > 0 and (reloaded - 1) + K4 > c:
+                        reloaded -= 1
+                        reload(reloaded)
+                else:                            # only what this iteration waits for
+                    while reloaded > max(c - NT, 0):
+                        reloaded -= 1
+                        assert (reloaded + K4) > c, "the slots of column %d are still in use" % (reloaded + K4)
+                        reload(reloaded)
             clp, cp = 4 * (sp & 3), 4 * sp
             if sp < self.sel:
                 vk = np.array([v[4 * (sp & 15) + m] for m in range(4)])          # v_readlane
@@ -205,10 +297,22 @@ class Instance:
             s = sp - 1 - d
             lrow = cp - 16 * (s >> 2)
             valid = (s >= 0) & (s < self.sel) & (lrow + 3 <= PAN_ROWS - 1)
+            s2 = s - 16                          # the lane's previous pending step: distances 16 .. (only with PAN_ROWS > 64)
+            lrow2 = cp - 16 * (s2 >> 2)
+            valid2 = (s2 >= 0) & (s2 < self.sel) & (lrow2 + 3 <= PAN_ROWS - 1)
+            own = slot == (sp & 15)              # this lane's step has just been solved: the next one's collection takes over
+            base = np.where(own, vfar, v)
+            upd, upd2 = np.zeros(64), np.zeros(64)
             for l in range(64):
                 if valid[l]:
-                    v[l] += self.PAN[s[l], lrow[l]:lrow[l] + 4, k[l]] @ x1
-            v[slot == (sp & 15)] = 0.0
+                    upd[l] = self.PAN[s[l], lrow[l]:lrow[l] + 4, k[l]] @ x1
+                if valid2[l]:
+                    assert not own[l]
+                    upd2[l] = self.PAN[s2[l], lrow2[l]:lrow2[l] + 4, k[l]] @ x1
+            v = base + upd
+            vfar = np.where(own, 0.0, vfar + upd2)
+            if (sp & 3) == 0:                    # flagB: tile column sp >> 2 and everything above it is finished
+                self.released.update(range(sp, self.S))
         return x
 
 
