@@ -177,25 +177,16 @@ int dba_ba_get_layout(int N, int B, int ht, int wd, int t0, int t1, dba_ba_layou
   return DBA_OK;
 }
 
-// Pinned, host-coherent status words the prepare kernel reports an eta / |kx| mismatch through (one set per process,
-// sticky until polled): [0] = 1 when set, [1] = the eta rows the call was given, [2] = |kx| of its graph.
-static int *eta_status() {
-  static int *p = [] {
-    int *q = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&q), 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return (int *)nullptr;
-    memset(q, 0, 64);
-    return q;
-  }();
-  return p;
-}
+// The prepare kernel reports an eta / |kx| mismatch through pinned, host-coherent words of the WORKSPACE it ran on (ws_eta_status,
+// ba_solve.hip: sticky until polled; [0] = 1 when set, [1] = the eta rows the call was given, [2] = |kx| of its graph) -- and the
+// call itself has changed nothing (ba_prepare_kernel::check_eta).
+int dba_ba_poll_eta_error(int *eta_rows, int *num_kx) { return ws_poll_eta(nullptr, eta_rows, num_kx); }
 
-int dba_ba_poll_eta_error(int *eta_rows, int *num_kx) {
-  int *st = eta_status();
-  if (!st || __atomic_load_n(st, __ATOMIC_ACQUIRE) == 0) return 0;
-  if (eta_rows) *eta_rows = st[1];
-  if (num_kx) *num_kx = st[2];
-  __atomic_store_n(st, 0, __ATOMIC_RELEASE);
-  return 1;
+int dba_ba_poll_eta_error_ws(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, int *eta_rows, int *num_kx) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  return ws_poll_eta(plan.T.meta, eta_rows, num_kx);
 }
 
 int dba_ba_gather_edges(const float *target_inac, const float *weight_inac, const int64_t *ii_inac, const int64_t *jj_inac,
@@ -233,6 +224,7 @@ int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws
   if (rc != DBA_OK) return rc;
   // meta and the graph key are adjacent: no graph is recorded, nothing was solved
   DBA_HIP_CHECK(hipMemsetAsync(plan.T.meta, 0, (size_t)((char *)(plan.T.gkey + 8) - (char *)plan.T.meta), (hipStream_t)stream));
+  ws_words_reset(plan.T.meta);   // (the allocator may have handed out the address of a workspace of another shape or graph)
   return DBA_OK;
 }
 
@@ -272,7 +264,7 @@ static int ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, 
   int *band_verdict = max_nt ? solver_verdict_slot(plan.T.meta) : nullptr;
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, ii, jj, N, B, t0, t1,
                      (int)scan_ints, ba_schur_frame_form(N, plan.P) ? 1 : 0, check ? 1 : 0, eta_rows,
-                     eta_rows > 1 ? eta_status() : nullptr, plan.T, band_verdict, max_nt);
+                     eta_rows > 1 ? ws_eta_status(plan.T.meta) : nullptr, plan.T, band_verdict, max_nt);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

@@ -137,6 +137,10 @@ int ba_solve_wave_max_nt(int n);   // the tallest window (3 | 4 tile rows) whose
 // the word of pinned host memory that carries "banded (1) / not banded (2)" for the workspace whose meta block this is
 // (launch_ba_solve reads it without synchronising; the window kernel and, on a graph change, stage 0 write it); null: no pool
 int *solver_verdict_slot(const int *meta);
+// (the workspace's pinned words, ba_solve.hip: [0] verdict, [1] probe counter, [4..6] stage 0's eta report)
+void ws_words_reset(const int *meta);
+int *ws_eta_status(const int *meta);         // ... [4..6]: stage 0's eta report
+int ws_poll_eta(const int *meta, int *eta_rows, int *num_kx);
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
                          double *Lscratch, int *verdict, hipStream_t stream, long long *prof = nullptr);
 size_t ba_solve_scratch_doubles(int n);

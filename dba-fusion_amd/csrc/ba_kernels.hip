@@ -63,12 +63,19 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   const int my_i = (tid < N) ? (int)ii[tid] : -1, my_j = (tid < N) ? (int)jj[tid] : -1;
   auto src = [&](int n) { return (n == tid) ? my_i : (int)ii[n]; };
   auto dst = [&](int n) { return (n == tid) ? my_j : (int)jj[n]; };
-  // eta.view(-1, HW) must have one row, or one per entry of kx (the reference's broadcast raises otherwise); the count only
-  // exists here, so a mismatch is reported to the host through pinned memory and raised by the adapter's next call
+  // eta.view(-1, HW) must have one row, or one per entry of kx (the reference's broadcast raises otherwise, before it touches
+  // anything: droid_kernels.cu:1476); the count only exists here, so a mismatch (a) turns the rest of THIS call into a no-op --
+  // the word gkey[7] of the workspace, which the kernels that write the caller's state honour: poses and depths stay as they
+  // are, dx and dz come back zero -- and (b) is reported to the host through the workspace's own pinned words, raised by the
+  // adapter's next call on that workspace (or check_async_errors)
   auto check_eta = [&](int nk) {
-    if (tid == 0 && eta_rows > 1 && eta_rows != nk && status) {
-      status[1] = eta_rows, status[2] = nk;
-      __hip_atomic_store(status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+      const bool bad = eta_rows > 1 && eta_rows != nk;
+      T.gkey[7] = bad ? 1 : 0;
+      if (bad && status) {
+        status[1] = eta_rows, status[2] = nk;
+        __hip_atomic_store(status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   };
 
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
   for (int n = tid; n < N; n += nt) T.gkey[8 + n] = (int)ii[n], T.gkey[8 + N + n] = (int)jj[n];
   if (tid == 0) {
     int *key = T.gkey;
-    key[0] = GKEY_MAGIC, key[1] = N, key[2] = B, key[3] = t0, key[4] = t1, key[5] = ftable, key[6] = T.Mmax, key[7] = 0;
+    key[0] = GKEY_MAGIC, key[1] = N, key[2] = B, key[3] = t0, key[4] = t1, key[5] = ftable, key[6] = T.Mmax;   // (key[7]: check_eta)
   }
 }
 
@@ -617,8 +624,10 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
     const float *__restrict__ disps_sens, const float *__restrict__ targets,
     const float *__restrict__ weights, const float *__restrict__ eta, int eta_rows,
     const int64_t *__restrict__ jj, const uint8_t *__restrict__ frame_owned, int N, int HW, int wd,
-    int t0, int P, float alpha, int upd, float *__restrict__ poses_out, float *__restrict__ disps_w, BaTables T,
+    int t0, int P, float alpha, int upd_arg, float *__restrict__ poses_out, float *__restrict__ disps_w, BaTables T,
     BaBuffers W) {
+  // (a call whose eta does not fit its graph changes nothing: stage 0 left its verdict in the workspace, see check_eta)
+  const int upd = T.gkey[7] ? 0 : upd_arg;
   // upd != 0: the back-substitution + retraction of the PREVIOUS Gauss-Newton iteration is folded into this launch
   // (dba_ba: one launch and one kernel boundary less per iteration).  W.dx, W.E, W.Q, W.w still hold that iteration's
   // values: a workgroup first moves the depths of its own pixels (bit 1; nobody else reads them: the linearisation only
@@ -1587,6 +1596,13 @@ __global__ __launch_bounds__(256) void ba_update_kernel(float *__restrict__ pose
                                                         float *__restrict__ dx_out, BaTables T, BaBuffers W,
                                                         float disp_floor) {
   const int m = blockIdx.y;
+  if (T.gkey[7]) {   // stage 0 refused the call (eta rows != |kx|): the state stays as it is, the caller gets zero updates
+    if (m == T.Mmax && blockIdx.x == 0 && dx_out)
+      for (int i = threadIdx.x; i < 6 * P; i += blockDim.x) dx_out[i] = 0.f;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < T.Mmax && k < HW && dz_out && update_disps) dz_out[(size_t)m * HW + k] = 0.f;   // (every row the caller may look at)
+    return;
+  }
   if (m > T.Mmax) {
     // dba_ba_run's disp_floor > 0, frames this launch does not update: `self.disps.clamp_(min=0.001)` is over the WHOLE
     // buffer (dbaf/depth_video.py:560), and the caller rescales inverse depths between BA calls (dbaf_frontend.py:570,814),
@@ -1646,11 +1662,13 @@ __global__ __launch_bounds__(256) void ba_gather_edges_kernel(const float2 *__re
                                                               int64_t *__restrict__ ii_out, int64_t *__restrict__ jj_out) {
   const int o = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
   const bool inac = o < n_sel;
-  // (an index outside the inactive list reads edge 0 and is reported by the host wrapper's range check of `sel` only when the
-  // caller asks for it: torch's own gather would fault here)
+  // (torch's own gather device-asserts on an index outside the inactive list; here such an output edge gets the ids of edge 0 --
+  // valid frames, so that no table is built from garbage -- with ZERO weights and targets: it contributes nothing to the BA
+  // instead of feeding it a plausible wrong edge)
   int64_t src = inac ? (sel ? sel[o] : (int64_t)o) : (int64_t)(o - n_sel);
   if (inac) src = (src < 0) ? src + n_inac : src;   // (torch's negative indices)
-  if (inac && (src < 0 || src >= n_inac)) src = 0;
+  const bool bad = inac && (src < 0 || src >= n_inac);
+  if (bad) src = 0;
   if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     ii_out[o] = inac ? ii_inac[src] : ii_act[src];
     jj_out[o] = inac ? jj_inac[src] : jj_act[src];
@@ -1658,7 +1676,8 @@ __global__ __launch_bounds__(256) void ba_gather_edges_kernel(const float2 *__re
   if (k >= HW) return;
   const float2 *in = blockIdx.z ? (inac ? wgt_inac : wgt_act) : (inac ? tgt_inac : tgt_act);
   float *out = blockIdx.z ? wgt_out : tgt_out;
-  const float2 v = in[(size_t)src * HW + k];
+  float2 v = in[(size_t)src * HW + k];
+  if (bad) v = make_float2(0.f, 0.f);
   out[((size_t)o * 2 + 0) * HW + k] = v.x;
   out[((size_t)o * 2 + 1) * HW + k] = v.y;
 }

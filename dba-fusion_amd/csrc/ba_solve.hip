@@ -84,29 +84,75 @@ size_t ba_solve_scratch_doubles(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 // without any synchronisation.  It steers the NEXT solve of that workspace -- 2: straight to the register-tile / skyline
 // kernels, which are faster than the in-launch fall-back on such systems; anything else: the window kernel -- and is only
 // ever a performance hint: whatever is launched solves whatever it is given.
-int *solver_verdict_slot(const int *meta) {
-  static std::mutex mu;
-  static std::unordered_map<const void *, int> index;
-  static int *pool = nullptr;
-  static int next = 0;
-  constexpr int SLOTS = 1024, STRIDE = 16;   // ints per slot: [0] verdict, [1] solves since the verdict said "not banded"
-  std::lock_guard<std::mutex> lock(mu);
-  if (!pool) {
-    if (hipHostMalloc(reinterpret_cast<void **>(&pool), sizeof(int) * SLOTS * STRIDE, hipHostMallocCoherent | hipHostMallocMapped) !=
-        hipSuccess) {
-      pool = nullptr;
+// The pinned words of a workspace (16 ints, keyed by its meta pointer): [0] solver verdict, [1] solves since the verdict said "not
+// banded", [4..6] stage 0's eta report (set, the call's eta rows, |kx|).  1024 slots; when they are all taken the OLDEST entry
+// gives its slot up (one entry, not the table: kernels in flight for the other workspaces keep valid addresses, and the
+// evicted workspace merely starts over with "nothing known" if it is ever used again).
+namespace {
+constexpr int WSW_SLOTS = 1024, WSW_STRIDE = 16;
+struct WsWords {
+  std::mutex mu;
+  std::unordered_map<const void *, int> index;
+  const void *owner[WSW_SLOTS] = {};
+  int *pool = nullptr;
+  int next = 0;
+};
+WsWords &ws_words() {
+  static WsWords *w = new WsWords;   // (never destroyed: kernels may still write into the pool at exit)
+  return *w;
+}
+}  // namespace
+
+static int *ws_words_slot(const int *meta, bool reset) {
+  WsWords &w = ws_words();
+  std::lock_guard<std::mutex> lock(w.mu);
+  if (!w.pool) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&w.pool), sizeof(int) * WSW_SLOTS * WSW_STRIDE,
+                      hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+      w.pool = nullptr;
       (void)hipGetLastError();
       return nullptr;
     }
-    memset(pool, 0, sizeof(int) * SLOTS * STRIDE);
+    memset(w.pool, 0, sizeof(int) * WSW_SLOTS * WSW_STRIDE);
   }
-  auto it = index.find(meta);
-  if (it == index.end()) {
-    if ((int)index.size() >= SLOTS) index.clear(), next = 0;   // (a process that went through 1024 workspaces starts over)
-    it = index.emplace(meta, next++).first;
-    pool[it->second * STRIDE] = 0, pool[it->second * STRIDE + 1] = 0;
+  auto it = w.index.find(meta);
+  bool fresh = false;
+  if (it == w.index.end()) {
+    const int slot = w.next;
+    w.next = (w.next + 1) % WSW_SLOTS;
+    if (w.owner[slot]) w.index.erase(w.owner[slot]);
+    w.owner[slot] = meta;
+    it = w.index.emplace(meta, slot).first;
+    fresh = true;
   }
-  return pool + it->second * STRIDE;
+  int *p = w.pool + it->second * WSW_STRIDE;
+  if (fresh || reset)
+    for (int i = 0; i < WSW_STRIDE; i++) __atomic_store_n(p + i, 0, __ATOMIC_RELAXED);
+  return p;
+}
+
+int *solver_verdict_slot(const int *meta) { return ws_words_slot(meta, false); }
+// a workspace that is (re)initialised forgets what an earlier workspace at the same address was told
+void ws_words_reset(const int *meta) { (void)ws_words_slot(meta, true); }
+int *ws_eta_status(const int *meta) {
+  int *p = ws_words_slot(meta, false);
+  return p ? p + 4 : nullptr;
+}
+// the first pending eta report of ANY workspace (meta == nullptr) or of this one; clears it
+int ws_poll_eta(const int *meta, int *eta_rows, int *num_kx) {
+  WsWords &w = ws_words();
+  std::lock_guard<std::mutex> lock(w.mu);
+  if (!w.pool) return 0;
+  for (auto &kv : w.index) {
+    if (meta && kv.first != meta) continue;
+    int *st = w.pool + kv.second * WSW_STRIDE + 4;
+    if (__atomic_load_n(st, __ATOMIC_ACQUIRE) == 0) continue;
+    if (eta_rows) *eta_rows = st[1];
+    if (num_kx) *num_kx = st[2];
+    __atomic_store_n(st, 0, __ATOMIC_RELEASE);
+    return 1;
+  }
+  return 0;
 }
 
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
@@ -135,7 +181,7 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     int verdict = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
     if (verdict) last_known.store(verdict, std::memory_order_relaxed);
     else verdict = last_known.load(std::memory_order_relaxed);
-    const bool probe = slot && verdict == 2 && (++slot[1] & 1023) == 0;   // has the graph become banded again?
+    const bool probe = slot && verdict == 2 && ((__atomic_add_fetch(slot + 1, 1, __ATOMIC_RELAXED)) & 1023) == 0;   // has the graph become banded again?
     if (forced == 4 || verdict != 2 || probe) return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream);
   }
   int chained = 0;

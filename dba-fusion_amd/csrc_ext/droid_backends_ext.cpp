@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <list>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -70,7 +71,8 @@ BaDims ba_dims(const torch::Tensor &disps, const torch::Tensor &eta, const torch
 torch::Tensor workspace(const BaDims &d, const torch::Tensor &like, size_t *nbytes, int pool) {
   using Key = std::tuple<int, int, void *, int, int, int, int, int, int>;
   static std::mutex mu;
-  static std::list<std::pair<Key, torch::Tensor>> cache;
+  // (leaked on purpose: at static-destruction time the HIP runtime may be gone already, and freeing device memory then faults)
+  static auto &cache = *new std::list<std::pair<Key, torch::Tensor>>;
   *nbytes = dba_ba_workspace_bytes(d.N, d.B, d.ht, d.wd, d.t0, d.t1);
   TORCH_CHECK(*nbytes > 0, "dba_ba_workspace_bytes: invalid sizes");
   const Key key{pool, (int)like.get_device(), (void *)stream_of(like), d.N, d.B, d.ht, d.wd, d.t0, d.t1};
@@ -393,6 +395,10 @@ class BACore {
                              d_.ht, d_.wd, d_.t0, d_.t1, Hh.data_ptr<double>(), vh.data_ptr<double>(), ws_.data_ptr(), nbytes_,
                              stream_of(poses_), /*prepared=*/2),
           "dba_bacore_hessian");
+    {   // the linearisation retract() uses lives in the workspace BACore objects of one window shape share: whose is it now?
+      std::lock_guard<std::mutex> lock(owner_mu());
+      owner()[ws_.data_ptr()] = this;
+    }
     raise_pending_eta_error();   // (hessian synchronises the stream: the verdict of its own stage 0 is in)
     if (!direct) {   // the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
       H.copy_(Hh.slice(0, 0, H.size(0)).slice(1, 0, H.size(1)));
@@ -411,6 +417,13 @@ class BACore {
 
   std::vector<torch::Tensor> retract(torch::Tensor _dx) {
     TORCH_CHECK(ready_, "BACore.init must be called first");
+    {
+      std::lock_guard<std::mutex> lock(owner_mu());
+      auto it = owner().find(ws_.data_ptr());
+      TORCH_CHECK(it == owner().end() || it->second == this,
+                  "BACore.retract: another BACore of the same window shape has linearised into the shared workspace since this "
+                  "object's hessian(); call hessian() again before retract()");
+    }
     torch::Tensor dxh = _dx.to(torch::kCPU, torch::kDouble).contiguous().view({-1});
     const int P = d_.t1 - d_.t0;
     TORCH_CHECK(dxh.numel() >= 6 * P, "BACore.retract: dx must have ", 6 * P, " entries");
@@ -425,6 +438,8 @@ class BACore {
   }
 
  private:
+  static std::mutex &owner_mu() { static auto &m = *new std::mutex; return m; }
+  static std::unordered_map<void *, const void *> &owner() { static auto &o = *new std::unordered_map<void *, const void *>; return o; }
   torch::Tensor poses_, disps_, intrinsics_, disps_sens_, targets_, weights_, eta_, ii_, jj_, ws_, dx_;
   BaDims d_{};
   size_t nbytes_ = 0;

@@ -41,6 +41,7 @@ SYMBOLS = {
     "dba_ba_workspace_init": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
     "dba_ba_solver_verdict": (c_int, [c_int] * 6 + [_P, c_size_t]),
     "dba_ba_poll_eta_error": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "dba_ba_poll_eta_error_ws": (c_int, [c_int] * 6 + [_P, c_size_t, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dba_ba_gather_edges": (c_int, [_P] * 4 + [c_int, _P, c_int] + [_P] * 4 + [c_int] * 3 + [_P] * 5),
     "dba_ba_linearize": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
     "dba_ba_reduce": (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),

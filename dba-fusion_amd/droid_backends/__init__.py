@@ -142,6 +142,7 @@ class _BaWorkspaces:
 
 
 _BA_WS = _BaWorkspaces()
+_BACORE_OWNER = {}   # workspace address -> id of the BACore whose hessian() linearised into it last
 
 
 def _num_kx(eta, ii, t0, t1, ht, wd):
@@ -161,18 +162,26 @@ def _num_kx_exact(ii, t0, t1):
 _ETA_CHECK_SYNC = _os.environ.get("DBA_ETA_CHECK", "") == "sync"
 
 
-def _raise_pending_eta_error():
+def _raise_pending_eta_error(ws=None, dims=None):
     """eta.view(-1, HW) must broadcast against the |kx| rows of C (droid_kernels.cu:1476): one row, or one per kx entry.  The
-    reference raises a broadcast error in the call itself (its torch::_unique synchronises the host anyway); here |kx| only
-    exists on the device, stage 0 compares, and a mismatch surfaces at the NEXT call of this module (or at an explicit
-    droid_backends.check_async_errors() after a synchronisation) -- the price of a call that never stops the host.
+    reference raises a broadcast error in the call itself, before it touches anything (its torch::_unique synchronises the host
+    anyway); here |kx| only exists on the device, stage 0 compares, and a mismatch (a) makes the offending call a no-op ON THE
+    DEVICE -- poses and inverse depths stay as they were, dx and dz come back zero -- and (b) surfaces at the NEXT call on that
+    workspace (the report lives in the workspace's own pinned words: other devices, streams or threads do not see it), or at an
+    explicit droid_backends.check_async_errors() after a synchronisation -- the price of a call that never stops the host.
     DBA_ETA_CHECK=sync restores the synchronous check."""
     r, k = ctypes.c_int(0), ctypes.c_int(0)
-    if _lib.load().dba_ba_poll_eta_error(ctypes.byref(r), ctypes.byref(k)):
+    lib = _lib.load()
+    if ws is not None:
+        hit = lib.dba_ba_poll_eta_error_ws(*dims, _ptr(ws[0]), ws[1], ctypes.byref(r), ctypes.byref(k)) == 1
+    else:
+        hit = lib.dba_ba_poll_eta_error(ctypes.byref(r), ctypes.byref(k)) == 1
+    if hit:
         _BA_WS.graph.clear()   # (whichever note remembered that row count as checked must not skip stage 0 with it again)
         raise RuntimeError("an earlier droid_backends.ba / BACore.hessian call was given eta with %d rows; it must have 1 or "
                            "|unique(arange(t0,t1) U ii)| = %d rows (droid_kernels.cu:1476: eta.view(-1, ht*wd) is added to C "
-                           "row by row); that call reused the last eta row for the missing ones" % (r.value, k.value))
+                           "row by row); that call changed nothing (poses and inverse depths untouched, dx = dz = 0)"
+                           % (r.value, k.value))
 
 
 def check_async_errors():
@@ -281,14 +290,17 @@ def _ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0,
     eta, N, B, ht, wd, eta_rows = _ba_args(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj)
     t0, t1 = int(t0), int(t1)
     P = t1 - t0
-    _raise_pending_eta_error()
+    dims = (N, B, ht, wd, t0, t1)
+    if _BA_WS.enabled:   # what an earlier call on THIS workspace (device, stream, window shape) was found to be wrong with
+        key = (poses.device, torch.cuda.current_stream().cuda_stream, dims)
+        _raise_pending_eta_error(_BA_WS.workspace(key, dims, poses.device), dims)
+    else:
+        _raise_pending_eta_error()
     _check_eta_rows(eta_rows, ii, t0, t1)
     if int(iterations) <= 0:   # the reference returns two undefined tensors and touches nothing (:1437, :1511)
         return [None, None]
     lib = _lib.load()
-    dims = (N, B, ht, wd, t0, t1)
     if _BA_WS.enabled:
-        key = (poses.device, torch.cuda.current_stream().cuda_stream, dims)
         ws, nbytes = _BA_WS.workspace(key, dims, poses.device)
         # the same tensor objects as last time: stage 0 is not even launched; anything else: stage 0 compares the edge list
         # with the key in the workspace and leaves at once when it is the graph the tables were built for
@@ -426,6 +438,9 @@ class BACore:
             ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream(),
             self._prepared)
         _lib.check(rc, "dba_bacore_hessian")
+        # the linearisation retract() back-substitutes with lives in the workspace, which BACore objects of one window shape
+        # share: remember whose it is (the reference's objects are independent; DepthVideo.ba has one alive at a time)
+        _BACORE_OWNER[self.ws.data_ptr()] = id(self)
         _raise_pending_eta_error()    # (hessian() synchronises the stream: the verdict of its own stage 0 is in)
         if not direct:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
             H.copy_(Hh[:H.shape[0], :H.shape[1]])
@@ -450,6 +465,9 @@ class BACore:
 
     def retract(self, _dx):
         assert self._ready, "BACore.init must be called first"
+        if _BACORE_OWNER.get(self.ws.data_ptr(), id(self)) != id(self):
+            raise RuntimeError("BACore.retract: another BACore of the same window shape has linearised into the shared "
+                               "workspace since this object's hessian(); call hessian() again before retract()")
         dxh = _dx.detach().to("cpu", torch.float64).contiguous().view(-1)
         if dxh.numel() < 6 * self.P:
             raise RuntimeError("BACore.retract: dx must have %d entries" % (6 * self.P))

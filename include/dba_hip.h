@@ -83,7 +83,7 @@ int dba_ba_prepare(const int64_t *ii, const int64_t *jj, int N, int B, int ht, i
  * valid: one that went through dba_ba_workspace_init (fresh memory) or an earlier stage 0.
  * eta_rows > 1: the number of rows of the call's eta, which must equal |kx| (droid_kernels.cu:1476 adds eta.view(-1, HW) to
  * the |kx| rows of C; the reference raises a broadcast error otherwise).  |kx| only exists on the device, so a mismatch is
- * recorded in pinned host memory and reported by dba_ba_poll_eta_error (the kernels then reuse the last eta row). */
+ * recorded in pinned host memory and reported by dba_ba_poll_eta_error[_ws]; the call it belongs to changes nothing. */
 int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int ht, int wd, int t0, int t1, int eta_rows,
                          int check, void *ws, size_t ws_bytes, dba_stream_t stream);
 /* diagnostic: what the library currently believes about the reduced camera system of this workspace's graph -- 1: banded enough
@@ -95,9 +95,15 @@ int dba_ba_prepare_keyed(const int64_t *ii, const int64_t *jj, int N, int B, int
 int dba_ba_solver_verdict(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes);
 /* marks a freshly allocated workspace as "no graph prepared" (clears meta and the key header; asynchronous on `stream`) */
 int dba_ba_workspace_init(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream);
-/* 1 (and the two counts) if a stage 0 that has COMPLETED since the last poll saw eta_rows != |kx|, else 0; clears the record.
+/* 1 (and the two counts) if a stage 0 that has COMPLETED since the last poll saw eta_rows != |kx| on any workspace, else 0; clears
+ * that record.
  * Host memory only: no synchronisation.  The adapters poll at the top of every ba call and raise for the earlier one. */
 int dba_ba_poll_eta_error(int *eta_rows, int *num_kx);
+/* the same for ONE workspace (the report lives in pinned words of the workspace stage 0 ran on, so a mismatch is attributed to the
+ * caller that made it whatever other devices, streams or threads do).  The offending call itself is harmless: stage 0 also leaves
+ * its verdict in the workspace, and the kernels that write the caller's state honour it -- poses and inverse depths stay as they
+ * were, dx and dz come back zero (the reference raises before it touches anything: /root/reference/src/droid_kernels.cu:1476). */
+int dba_ba_poll_eta_error_ws(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, int *eta_rows, int *num_kx);
 
 /* The edge tensors of one BA call as the reference's caller assembles them (dbaf/covisible_graph.py:242-247: torch.cat of the
  * selected inactive edges' and the active edges' ii / jj / target / weight; :332-333: target, weight from [n, ht, wd, 2] to the

@@ -367,10 +367,11 @@ def test_ba_eta_broadcast_row():
 
 
 def test_ba_rejects_an_eta_with_the_wrong_number_of_rows():
-    """1 < rows != |kx|: the reference's eta.view(-1, HW) would fail to broadcast against C (:1476); the kernels would
-    silently reuse the last row.  |kx| only exists on the device: stage 0 compares and records the mismatch in pinned
-    memory, and the module raises at its next call (or at check_async_errors() after a synchronisation) -- the call itself
-    never stops the host.  The graph is the same in every call here, so the check also runs on the early-out path."""
+    """1 < rows != |kx|: the reference's eta.view(-1, HW) fails to broadcast against C (:1476) before anything is touched.  |kx|
+    only exists on the device: stage 0 compares, turns the rest of the call into a no-op on the device (state untouched, zero
+    dx / dz: round 6) and records the mismatch in the workspace's pinned words; the module raises at the next call on that
+    workspace (or at check_async_errors() after a synchronisation) -- the call itself never stops the host.  The graph is the
+    same in every call here, so the check also runs on the early-out path."""
     import droid_backends
     W = syn.window_tiny_b(85)
     d = to_dev(W)
@@ -385,8 +386,11 @@ def test_ba_rejects_an_eta_with_the_wrong_number_of_rows():
             with pytest.raises(RuntimeError):
                 droid_backends.ba(*args(eta))
             continue
-        droid_backends.ba(*args(eta))            # (asynchronous: returns; the last eta row was reused)
+        p_before, d_before = d["poses"].clone(), d["disps"].clone()
+        dx_bad, dz_bad = droid_backends.ba(*args(eta))   # (asynchronous: returns -- and changes nothing, like the reference's raise)
         torch.cuda.synchronize()
+        assert torch.equal(d["poses"], p_before) and torch.equal(d["disps"], d_before)
+        assert not dx_bad.any() and not dz_bad.any()
         with pytest.raises(RuntimeError, match="eta with %d rows.*= %d rows" % (rows, W.M)):
             droid_backends.check_async_errors()
         droid_backends.check_async_errors()      # reported once
