@@ -506,6 +506,39 @@ def main():
                                   sensor_frac=0.25)
             extras["bacore_update_us_10kf_54edges_48x64_sensor_depth"] = bacore_unit(W48, bacore_state(W48))
             del W48
+        # ... and the hand-over in the factor-graph side's coordinates (round 6): hessian + the caller's stabiliser + BA2GTSAM
+        # (depth_video.py:394-401) in one call, against the same three statements with the host-side numpy BA2GTSAM
+        def gtsam_handover(Wx, st):
+            from dbaf_amd import fusion
+            Tbc = np.array([0.03, 0.01, -0.08, 0.02, -0.01, 0.7, 0.71])
+            P6 = 6 * (Wx.t1 - Wx.t0)
+            core = droid_backends.BACore()
+            core.init(st["poses"], st["disps"], st["intr"], st["dsens"], st["target"], st["weight"], st["eta"], st["ii"], st["jj"],
+                      Wx.t0, Wx.t1, 2, Wx.lm, Wx.ep, False)
+            H = torch.zeros([P6, P6], dtype=torch.float64, device="cpu")
+            v = torch.zeros([P6], dtype=torch.float64, device="cpu")
+
+            def host_form():
+                core.hessian(H, v)
+                for i in range(6):
+                    H[i, i] += 0.00025
+                return fusion.BA2GTSAM_augmented(H.numpy(), v.numpy(), Tbc)
+
+            def device_form():
+                return core.hessian_gtsam(Tbc)
+
+            out = {}
+            for name, fn in (("hessian_then_host_ba2gtsam_us", host_form), ("hessian_gtsam_us", device_form)):
+                for _ in range(3):
+                    fn()
+                nrep = max(10, args.steps // 2)
+                t_ = time.perf_counter()
+                for _ in range(nrep):
+                    fn()
+                out[name] = round((time.perf_counter() - t_) / nrep * 1e6, 1)
+            return out
+
+        extras["bacore_gtsam_handover_us"] = gtsam_handover(W, bacore_state(W))
         extras["bacore_update_note"] = ("BACore() + init + 2 x {hessian -> CPU float64 H, v (pageable, as depth_video.py:392-393 "
                                         "allocates them) -> dense numpy solve in place of GTSAM -> retract} + clamp, wall clock; "
                                         "new edge tensor objects per update; device_side_us = update minus the host solve")

@@ -11,6 +11,9 @@
 #include "ba_kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #ifndef GRAM_F32_DEFAULT
 #define GRAM_F32_DEFAULT true   // per-frame Schur products: 16-term float chains flushed into float64 (DBA_SCHUR_MFMA=f64:
@@ -584,14 +587,77 @@ int dba_bacore_hessian(const float *poses, const float *disps, const float *intr
                                 t0, t1, H_host, v_host, ws, ws_bytes, stream, 0);
 }
 
-int dba_bacore_hessian_run(const float *poses, const float *disps, const float *intrinsics,
-                           const float *disps_sens, const float *targets, const float *weights,
-                           const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
-                           int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
-                           size_t ws_bytes, dba_stream_t stream, int prepared) {
+// ---- BACore.hessian's hand-over (round 6).  Per workspace (keyed by its meta pointer, like the pinned words of ba_solve.hip): a
+// block of pinned, host-coherent, device-mapped memory for the exported system, a completion word in it and a device counter.
+// The export kernel writes the system there itself and sets the word when its last workgroup is through; the host spins on the
+// word.  Never freed (a process goes through a handful of window shapes; 1.2 MB at 64 poses).
+namespace {
+struct BacoreStage {
+  double *host = nullptr;     // [doubles] payload, then the flag (one int, 64-byte aligned)
+  size_t doubles = 0;
+  unsigned *counter = nullptr;
+  int seq = 0;
+};
+std::mutex g_stage_mu;
+std::unordered_map<const void *, BacoreStage> &stage_map() {
+  static auto &m = *new std::unordered_map<const void *, BacoreStage>;
+  return m;
+}
+int *stage_flag(const BacoreStage &st) { return reinterpret_cast<int *>(st.host + st.doubles + 8); }
+}  // namespace
+
+static int bacore_stage_for(const int *meta, size_t need, hipStream_t stream, BacoreStage **out) {
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  BacoreStage &st = stage_map()[meta];
+  if (st.doubles < need) {
+    if (st.host) {   // a larger window at the same address: nothing of the old block may still be in flight
+      DBA_HIP_CHECK(hipStreamSynchronize(stream));
+      (void)hipHostFree(st.host);
+      st.host = nullptr, st.doubles = 0;
+    }
+    void *p = nullptr;
+    DBA_HIP_CHECK(hipHostMalloc(&p, sizeof(double) * (need + 16), hipHostMallocCoherent | hipHostMallocMapped));
+    st.host = static_cast<double *>(p), st.doubles = need;
+    memset(p, 0, sizeof(double) * (need + 16));
+    if (!st.counter) {
+      DBA_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&st.counter), 64));
+      DBA_HIP_CHECK(hipMemset(st.counter, 0, 64));
+    }
+  }
+  *out = &st;
+  return DBA_OK;
+}
+
+// spins until the export kernel's word shows `seq`; every few thousand looks asks the runtime whether the stream has drained
+// (a launch that failed never sets the word)
+static int bacore_wait(int *flag, int seq, hipStream_t stream) {
+  for (unsigned long spins = 1;; spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return DBA_OK;
+    if ((spins & 0x3fff) == 0) {
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return DBA_OK;
+        set_last_error("BACore.hessian: the stream drained without the export kernel's completion word", hipErrorUnknown);
+        return DBA_ERR_HIP;
+      }
+      if (q != hipErrorNotReady) {
+        set_last_error("hipStreamQuery", q);
+        return DBA_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+  }
+}
+
+int dba_bacore_hessian_host(const float *poses, const float *disps, const float *intrinsics,
+                            const float *disps_sens, const float *targets, const float *weights,
+                            const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
+                            int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream, int prepared,
+                            int layout, const double *A36, double stabilizer, double **out_host) {
   BaPlan plan;
   int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
+  if (!out_host || (layout != 0 && layout != 1) || (layout == 1 && !A36)) return DBA_ERR_ARG;
   if (prepared != 1) {
     rc = dba_ba_prepare_keyed(ii, jj, N, B, ht, wd, t0, t1, eta_rows, prepared == 2, ws, ws_bytes, stream);
     if (rc != DBA_OK) return rc;
@@ -599,28 +665,74 @@ int dba_bacore_hessian_run(const float *poses, const float *disps, const float *
   rc = dba_ba_linearize(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, nullptr,
                         N, B, ht, wd, t0, t1, 0.001f /* :1872 */, ws, ws_bytes, stream);
   if (rc != DBA_OK) return rc;
-  rc = dba_ba_reduce(ii, jj, nullptr, N, B, ht, wd, t0, t1, 0, ws, ws_bytes, stream);
+  // (the lower triangle is all the export reads: no mirroring launch)
+  rc = ba_reduce_stage(ii, jj, nullptr, N, B, ht, wd, t0, t1, 0, 1, ws, ws_bytes, stream);
   if (rc != DBA_OK) return rc;
-  const size_t n = (size_t)6 * plan.P;
-  if (n && H_host)
-    DBA_HIP_CHECK(hipMemcpyAsync(H_host, plan.W.H, sizeof(double) * n * n, hipMemcpyDeviceToHost,
-                                 (hipStream_t)stream));
-  if (n && v_host)
-    DBA_HIP_CHECK(hipMemcpyAsync(v_host, plan.W.b, sizeof(double) * n, hipMemcpyDeviceToHost,
-                                 (hipStream_t)stream));
-  DBA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return dba_bacore_export_host(N, B, ht, wd, t0, t1, ws, ws_bytes, stream, layout, A36, stabilizer, out_host);
+}
+
+int dba_bacore_export_host(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream, int layout,
+                           const double *A36, double stabilizer, double **out_host) {
+  BaPlan plan;
+  int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (!out_host || (layout != 0 && layout != 1) || (layout == 1 && !A36)) return DBA_ERR_ARG;
+  const int n = 6 * plan.P;
+  BacoreStage *st = nullptr;
+  rc = bacore_stage_for(plan.T.meta, (size_t)n * (n + 1), (hipStream_t)stream, &st);
+  if (rc != DBA_OK) return rc;
+  *out_host = st->host;
+  if (n == 0) return DBA_OK;
+  ExportArg arg;
+  for (int i = 0; i < 36; i++) arg.A[i] = (layout == 1) ? A36[i] : 0.0;
+  const int seq = ++st->seq;
+  const int total = n * (n + 1);
+  hipLaunchKernelGGL(ba_export_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.H, plan.W.b, n,
+                     st->host, layout, arg, stabilizer, st->counter, stage_flag(*st), seq);
+  DBA_LAUNCH_CHECK();
+  return bacore_wait(stage_flag(*st), seq, (hipStream_t)stream);
+}
+
+int dba_bacore_staging(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, double **out_host) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (!out_host) return DBA_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  auto it = stage_map().find(plan.T.meta);
+  *out_host = (it == stage_map().end()) ? nullptr : it->second.host;
+  return *out_host ? DBA_OK : DBA_ERR_ARG;
+}
+
+int dba_bacore_hessian_run(const float *poses, const float *disps, const float *intrinsics,
+                           const float *disps_sens, const float *targets, const float *weights,
+                           const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N, int B,
+                           int ht, int wd, int t0, int t1, double *H_host, double *v_host, void *ws,
+                           size_t ws_bytes, dba_stream_t stream, int prepared) {
+  double *stage = nullptr;
+  const int rc = dba_bacore_hessian_host(poses, disps, intrinsics, disps_sens, targets, weights, eta, eta_rows, ii, jj, N, B, ht, wd,
+                                         t0, t1, ws, ws_bytes, stream, prepared, 0, nullptr, 0.0, &stage);
+  if (rc != DBA_OK) return rc;
+  const size_t n = (size_t)6 * std::max(t1 - t0, 0);
+  if (n && H_host && H_host != stage) memcpy(H_host, stage, sizeof(double) * n * n);
+  if (n && v_host && v_host != stage + n * n) memcpy(v_host, stage + n * n, sizeof(double) * n);
   return DBA_OK;
 }
+
 
 // the externally solved update as a kernel ARGUMENT (up to 64 poses: 1.5 KB of the 4 KB an argument block may have): it reaches
 // the device with the launch itself -- no staging copy, no stream synchronisation before the host buffer may go away
 struct DxArg {
   float v[384];
 };
-__global__ void ba_dx_from_arg_kernel(DxArg a, float *__restrict__ dx, int n) {
+__global__ void ba_dx_from_arg_kernel(DxArg a, float *__restrict__ dx, float *__restrict__ dx_out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dx[i] = a.v[i];
+  if (i < n) {
+    dx[i] = a.v[i];
+    if (dx_out) dx_out[i] = a.v[i];   // (the caller's copy rides along: one launch less)
+  }
 }
+
 
 int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int N, int B, int ht,
                        int wd, int t0, int t1, const double *dx_host, float *dx_out, float *dz_out, void *ws,
@@ -633,7 +745,7 @@ int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int6
     if (!dx_host) return DBA_ERR_ARG;
     DxArg a;
     for (int i = 0; i < n; i++) a.v[i] = (float)dx_host[i];  // f64 -> f32 (:1929-1930)
-    hipLaunchKernelGGL(ba_dx_from_arg_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, a, plan.W.dx, n);
+    hipLaunchKernelGGL(ba_dx_from_arg_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, a, plan.W.dx, dx_out, n);
     DBA_LAUNCH_CHECK();
   } else if (n > 0) {
     if (!dx_host) return DBA_ERR_ARG;
@@ -645,7 +757,7 @@ int dba_bacore_retract(float *poses, float *disps, const int64_t *ii, const int6
   }
   rc = dba_ba_update(poses, disps, ii, jj, nullptr, N, B, ht, wd, t0, t1, 1, 1, dz_out, ws, ws_bytes, stream);
   if (rc != DBA_OK) return rc;
-  if (dx_out && n > 0) {
+  if (dx_out && n > 384) {
     hipLaunchKernelGGL(ba_copy_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan.W.dx,
                        dx_out, n);
     DBA_LAUNCH_CHECK();

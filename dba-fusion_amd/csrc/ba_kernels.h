@@ -88,6 +88,11 @@ __global__ void ba_assemble_kernel(const int64_t *ii, const int64_t *jj, const u
 __global__ void ba_schur_kernel(const int64_t *ii, const int64_t *jj, const uint8_t *frame_owned, int N, int HW,
                                 int t0, int P, int lower, BaTables T, BaBuffers W);
 __global__ void ba_symmetrize_kernel(double *H, int n);
+struct ExportArg {
+  double A[36];   // row-major 6 x 6 (BA2GTSAM's block, depth_video.py:21-23)
+};
+__global__ void ba_export_kernel(const double *H, const double *b, int n, double *out, int gtsam, ExportArg arg, double stab,
+                                 unsigned *counter, int *host_flag, int seq);
 __global__ void ba_fixed_to_f64_kernel(double *H, double *b, int n);
 constexpr int GRAM_LIST_CAP = 1024;  // edges (+ 1) up to which the prepare kernel builds the frame row table (one thread per edge)
 template <bool VEC, bool F32>

@@ -1582,6 +1582,66 @@ __global__ __launch_bounds__(256) void ba_symmetrize_kernel(double *__restrict__
   if (j > i) H[idx] = H[(size_t)j * n + i];
 }
 
+// BACore.hessian's way out (round 6): the reduced system leaves the device from THIS kernel, written straight into pinned host
+// memory -- full symmetric H mirrored from the lower triangle the reduction keeps up, v behind it -- and the host is told by a
+// word of the same memory when the last workgroup is through (it spins on that word: no copy engine, no stream
+// synchronisation).  gtsam != 0: in the factor-graph side's tangent coordinates instead, the congruence of
+// /root/reference/dbaf/depth_video.py:20-29 (BA2GTSAM: Hg = J^T H J, vg = J^T v, J = blockdiag(A), A = -Ad(Tbc^-1) with its row
+// halves swapped) with the caller's stabiliser on the first pose's diagonal (:397) applied first, as the augmented
+// [n, n + 1] matrix [Hg | vg] the fork's gtsam.BA2GTSAM returns (:400-401).  One thread per output entry: 36 loads (L2) and
+// 72 multiply-adds for the congruence.
+__global__ __launch_bounds__(256) void ba_export_kernel(const double *__restrict__ H, const double *__restrict__ b, int n,
+                                                        double *__restrict__ out, int gtsam, ExportArg arg, double stab,
+                                                        unsigned *__restrict__ counter, int *__restrict__ host_flag, int seq) {
+  const int ld = gtsam ? n + 1 : n;   // plain: H [n, n] then v [n]; gtsam: [n, n + 1]
+  const int total = n * ld + (gtsam ? 0 : n);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  auto h = [&](int i, int j) {   // the symmetric matrix (lower triangle stored), the stabiliser on the first six diagonal entries
+    const double x = H[(size_t)max(i, j) * n + min(i, j)];
+    return (gtsam && i == j && i < 6) ? x + stab : x;
+  };
+  if (idx < total) {
+    double r;
+    if (!gtsam) {
+      if (idx < n * n) {
+        const int i = idx / n, j = idx - i * n;
+        r = H[(size_t)max(i, j) * n + min(i, j)];
+      } else {
+        r = b[idx - n * n];
+      }
+    } else {
+      const int i = idx / ld, j = idx - i * ld;
+      const int p = i / 6, a = i - 6 * p;
+      if (j == n) {   // vg[i] = sum_k A[k][a] v[6 p + k]
+        r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) r = fma(arg.A[6 * k + a], b[6 * p + k], r);
+      } else {
+        const int q = j / 6, c = j - 6 * q;
+        r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          double t = 0.0;   // (H A)[6 p + k][6 q + c]
+#pragma unroll
+          for (int l = 0; l < 6; l++) t = fma(h(6 * p + k, 6 * q + l), arg.A[6 * l + c], t);
+          r = fma(arg.A[6 * k + a], t, r);
+        }
+      }
+    }
+    out[idx] = r;
+  }
+  __threadfence_system();   // this thread's stores to host memory are out ...
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(counter, 1u);
+    if (done == gridDim.x - 1) {   // ... and so are everybody's: tell the host
+      *counter = 0;
+      __threadfence_system();
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage 4: back-substitution + retraction
 // ---------------------------------------------------------------------------------------------

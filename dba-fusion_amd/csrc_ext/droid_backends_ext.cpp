@@ -406,6 +406,29 @@ class BACore {
     }
   }
 
+  // hessian() + the caller's stabiliser on the first pose's diagonal + gtsam.BA2GTSAM(H, v, Tbc) (dbaf/depth_video.py:394-401) in
+  // one call: A = the 6 x 6 block -Ad(Tbc^-1) with swapped row halves (:21-23, CPU float64); returns the augmented [6P, 6P + 1]
+  // matrix [Hg | vg] as a CPU tensor over the library's pinned block (valid until the next hessian call on this window shape)
+  torch::Tensor hessian_gtsam(torch::Tensor A, double stabilizer) {
+    TORCH_CHECK(ready_, "BACore.init must be called first");
+    torch::Tensor Ah = A.to(torch::kCPU, torch::kDouble).contiguous();
+    TORCH_CHECK(Ah.numel() == 36, "BACore.hessian_gtsam: A must be the 6 x 6 tangent block");
+    const int n = 6 * (d_.t1 - d_.t0);
+    double *out = nullptr;
+    check(dba_bacore_hessian_host(poses_.data_ptr<float>(), disps_.data_ptr<float>(), intrinsics_.data_ptr<float>(),
+                                  disps_sens_.data_ptr<float>(), targets_.data_ptr<float>(), weights_.data_ptr<float>(),
+                                  eta_.data_ptr<float>(), d_.eta_rows, ii_.data_ptr<int64_t>(), jj_.data_ptr<int64_t>(), d_.N, d_.B,
+                                  d_.ht, d_.wd, d_.t0, d_.t1, ws_.data_ptr(), nbytes_, stream_of(poses_), /*prepared=*/2,
+                                  /*layout=*/1, Ah.data_ptr<double>(), stabilizer, &out),
+          "dba_bacore_hessian");
+    {
+      std::lock_guard<std::mutex> lock(owner_mu());
+      owner()[ws_.data_ptr()] = this;
+    }
+    raise_pending_eta_error();
+    return torch::from_blob(out, {n, n + 1}, torch::TensorOptions().dtype(torch::kDouble));
+  }
+
   void optimize(torch::Tensor H, torch::Tensor v) {
     TORCH_CHECK(ready_, "BACore.init must be called first");
     torch::Tensor Hh = H.to(torch::kCPU, torch::kDouble).contiguous(), vh = v.to(torch::kCPU, torch::kDouble).contiguous();
@@ -472,6 +495,7 @@ PYBIND11_MODULE(_droid_backends_C, m) {
       .def(py::init<>())
       .def("init", &BACore::init)
       .def("hessian", &BACore::hessian)
+      .def("hessian_gtsam", &BACore::hessian_gtsam, pybind11::arg("A"), pybind11::arg("stabilizer") = 0.00025)
       .def("optimize", &BACore::optimize)
       .def("retract", &BACore::retract);
 }

@@ -72,6 +72,10 @@ SYMBOLS = {
                                                                          c_size_t, _P, c_int, c_int, c_float]),
     "dba_bacore_hessian": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P]),
     "dba_bacore_hessian_run": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, _P, _P, c_size_t, _P, c_int]),
+    "dba_bacore_staging": (c_int, [c_int] * 6 + [_P, c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "dba_bacore_export_host": (c_int, [c_int] * 6 + [_P, c_size_t, _P, c_int, _P, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]),
+    "dba_bacore_hessian_host": (c_int, [_P] * 7 + [c_int] + [_P, _P] + [c_int] * 6 + [_P, c_size_t, _P, c_int, c_int, _P,
+                                        ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]),
     "dba_bacore_retract": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
     "dba_bacore_optimize": (c_int, [_P, _P] + [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),
     "dba_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),

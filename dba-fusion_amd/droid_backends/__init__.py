@@ -413,43 +413,98 @@ class BACore:
             self.ws, self.nbytes = _ws(N, B, ht, wd, self.t0, self.t1, poses.device)
             self._prepared = 0
         self.dx = None
-        # pinned host staging for the hand-off to the factor-graph side: the reduced system leaves
-        # the device with ONE DMA per hessian() call and is only then copied into the caller's pageable H, v
-        # (torch's caching host allocator recycles the block across the BACore objects DepthVideo.ba creates per call)
-        n = 6 * self.P
-        self._stage = torch.empty(n * n + n, dtype=torch.float64, pin_memory=True)
+        # the hand-off to the factor-graph side: the reduced system leaves the device in pinned host memory
+        # the LIBRARY keeps per workspace -- written there by the last kernel of hessian() itself, which the call waits for on a
+        # completion word (round 6: no DMA launches, no stream synchronisation, nothing allocated here)
+        self._stage_ptr, self._stage_layout = None, None
+        self._args, self._linearised = None, None
         self._ready = True
 
     def _dims(self):
         return (self.N, self.B, self.ht, self.wd, self.t0, self.t1)
+
+    def _front_args(self):
+        """the 16 leading arguments of the hessian entries (pointers and sizes: fixed once init() has run)"""
+        if self._args is None:
+            self._args = (_ptr(self.poses), _ptr(self.disps), _ptr(self.intrinsics), _ptr(self.disps_sens), _ptr(self.targets),
+                          _ptr(self.weights), _ptr(self.eta), self.eta_rows, _ptr(self.ii), _ptr(self.jj)) + self._dims()
+        return self._args
+
+    def _stage0_mode(self):
+        """1: this object's previous hessian() built (or confirmed) the tables for exactly these edge tensors -- the second
+        hessian of an update (depth_video.py:527) does not even launch stage 0; else the workspace's mode (2: compare by key)"""
+        if self._prepared == 2 and self._linearised == (self.ii._version, self.jj._version) and \
+                _BACORE_OWNER.get(self.ws.data_ptr()) == id(self):
+            return 1
+        return self._prepared
+
+    def _after_hessian(self, stage_ptr, layout):
+        # the linearisation retract() back-substitutes with lives in the workspace, which BACore objects of one window shape
+        # share: remember whose it is (the reference's objects are independent; DepthVideo.ba has one alive at a time)
+        _BACORE_OWNER[self.ws.data_ptr()] = id(self)
+        self._linearised = (self.ii._version, self.jj._version)
+        self._stage_ptr, self._stage_layout = stage_ptr, layout
+        _raise_pending_eta_error()    # (the call has waited for its last kernel: the verdict of its own stage 0 is in)
+
+    def _hessian_host(self, layout, A36=None, stabilizer=0.0):
+        out = ctypes.c_void_p()
+        a = None if A36 is None else (ctypes.c_double * 36)(*[float(x) for x in A36])
+        rc = _lib.load().dba_bacore_hessian_host(
+            *self._front_args(), _ptr(self.ws), self.nbytes, _stream(), self._stage0_mode(), layout,
+            None if a is None else ctypes.cast(a, ctypes.c_void_p), float(stabilizer), ctypes.byref(out))
+        _lib.check(rc, "dba_bacore_hessian")
+        self._after_hessian(out.value, layout)
+
+    def _stage_view(self, count):
+        import numpy as _np
+        return _np.ctypeslib.as_array((ctypes.c_double * count).from_address(self._stage_ptr))
 
     def hessian(self, H, v):
         assert self._ready, "BACore.init must be called first"
         if H.is_cuda or v.is_cuda or H.dtype != torch.float64 or v.dtype != torch.float64:
             raise RuntimeError("BACore.hessian: H, v must be CPU float64 tensors (droid_kernels.cu:1889-1890)")
         n = 6 * self.P
-        direct = (H.is_pinned() and v.is_pinned() and H.is_contiguous() and v.is_contiguous()
-                  and tuple(H.shape) == (n, n) and tuple(v.shape) == (n,))
-        Hh = H if direct else self._stage[:n * n].view(n, n)   # DMA target: the caller's own pinned buffers, or ours
-        vh = v if direct else self._stage[n * n:]
-        rc = _lib.load().dba_bacore_hessian_run(
-            _ptr(self.poses), _ptr(self.disps), _ptr(self.intrinsics), _ptr(self.disps_sens), _ptr(self.targets),
-            _ptr(self.weights), _ptr(self.eta), self.eta_rows, _ptr(self.ii), _ptr(self.jj), *self._dims(),
-            ctypes.c_void_p(Hh.data_ptr()), ctypes.c_void_p(vh.data_ptr()), _ptr(self.ws), self.nbytes, _stream(),
-            self._prepared)
-        _lib.check(rc, "dba_bacore_hessian")
-        # the linearisation retract() back-substitutes with lives in the workspace, which BACore objects of one window shape
-        # share: remember whose it is (the reference's objects are independent; DepthVideo.ba has one alive at a time)
-        _BACORE_OWNER[self.ws.data_ptr()] = id(self)
-        _raise_pending_eta_error()    # (hessian() synchronises the stream: the verdict of its own stage 0 is in)
-        if not direct:  # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
-            H.copy_(Hh[:H.shape[0], :H.shape[1]])
-            v.copy_(vh[:v.shape[0]])
+        if tuple(H.shape) == (n, n) and tuple(v.shape) == (n,) and H.is_contiguous() and v.is_contiguous():
+            # the library copies its pinned block into the caller's tensors itself (two memcpys, no tensor views on the way)
+            rc = _lib.load().dba_bacore_hessian_run(*self._front_args(), ctypes.c_void_p(H.data_ptr()),
+                                                    ctypes.c_void_p(v.data_ptr()), _ptr(self.ws), self.nbytes, _stream(),
+                                                    self._stage0_mode())
+            _lib.check(rc, "dba_bacore_hessian")
+            self._after_hessian(None, 0)
+            return
+        self._hessian_host(0)
+        if n == 0:
+            return
+        Hh, vh = self.hessian_staging()   # the reference fills H_accessor.size(0) x size(1) entries (:1892-1897)
+        H.copy_(Hh[:H.shape[0], :H.shape[1]])
+        v.copy_(vh[:v.shape[0]])
 
     def hessian_staging(self):
-        """zero-copy access to the pinned staging buffers the last hessian() filled: (H [6P,6P], v [6P]) float64"""
+        """zero-copy access to what the last hessian() left in the library's pinned block of this workspace: (H [6P,6P], v [6P])
+        float64 CPU tensors, valid until the next hessian call on a BACore of this window shape"""
+        assert self._stage_layout == 0, "hessian() has not run"
         n = 6 * self.P
-        return self._stage[:n * n].view(n, n), self._stage[n * n:]
+        if self._stage_ptr is None:   # (the last hessian() went straight into the caller's tensors: ask where the block is)
+            out = ctypes.c_void_p()
+            _lib.check(_lib.load().dba_bacore_staging(*self._dims(), _ptr(self.ws), self.nbytes, ctypes.byref(out)), "dba_bacore_staging")
+            self._stage_ptr = out.value
+        flat = torch.from_numpy(self._stage_view(n * n + n))
+        return flat[:n * n].view(n, n), flat[n * n:]
+
+    def hessian_gtsam(self, Tbc, stabilizer=0.00025):
+        """hessian() + `for i in range(6): H[i,i] += 0.00025` + gtsam.BA2GTSAM(H, v, Tbc) of dbaf/depth_video.py:394-401 (:524-529)
+        in one call: the export kernel applies the stabiliser and the change of tangent coordinates (Hg = J^T H J, vg = J^T v,
+        J = blockdiag(-Ad(Tbc^-1) with swapped row halves), :20-29) on the device and writes the augmented matrix
+        [Hg | vg] of shape [6P, 6P + 1] -- what the fork's gtsam.BA2GTSAM returns -- into pinned host memory.  Returns a numpy
+        view of it (valid until the next hessian call on this window shape).  Tbc: a gtsam.Pose3, a 4x4 matrix, a (t, q) 7-vector,
+        or the 6x6 block itself."""
+        assert self._ready, "BACore.init must be called first"
+        import numpy as _np
+        from dbaf_amd import fusion
+        A = _np.asarray(Tbc, _np.float64) if (not hasattr(Tbc, "matrix") and _np.shape(Tbc) == (6, 6)) else fusion.tangent_block(Tbc)
+        n = 6 * self.P
+        self._hessian_host(1, A.reshape(-1), stabilizer)
+        return self._stage_view(n * (n + 1)).reshape(n, n + 1)
 
     def optimize(self, H, v):
         assert self._ready, "BACore.init must be called first"

@@ -301,8 +301,32 @@ int dba_bacore_hessian_run(const float *poses, const float *disps, const float *
                            int B, int ht, int wd, int t0, int t1, double *H_host, double *v_host,
                            void *ws, size_t ws_bytes, dba_stream_t stream, int prepared);
 
+/* BACore::hessian with the reduced system handed over in PINNED HOST MEMORY OF THE LIBRARY (one block per workspace, valid until
+ * the next hessian call on that workspace): *out_host.  The last kernel of the sequence writes the system there itself -- mirrored
+ * from the lower triangle the reduction keeps up -- and sets a completion word the call spins on: no copy engine, no stream
+ * synchronisation (round 5: two hipMemcpyAsync + hipStreamSynchronize, 94 us per call on the 25-KF window).
+ * layout 0: H [6P, 6P] row-major followed by v [6P] (what src/droid_kernels.cu:1889-1897 copies out).
+ * layout 1: the system in the factor-graph side's tangent coordinates, as the augmented matrix [Hg | vg] of shape [6P, 6P + 1]
+ *   that the GTSAM fork's BA2GTSAM returns (/root/reference/dbaf/depth_video.py:20-29, :397-401, :527-529):
+ *   Hg = J^T (H + stabilizer on the first pose's diagonal, :397) J, vg = J^T v, J = blockdiag(A36), A36 the row-major 6 x 6 block
+ *   -Ad(Tbc^-1) with its row halves swapped (:21-23).  A36 is ignored for layout 0. */
+int dba_bacore_hessian_host(const float *poses, const float *disps, const float *intrinsics,
+                            const float *disps_sens, const float *targets, const float *weights,
+                            const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N,
+                            int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream,
+                            int prepared, int layout, const double *A36, double stabilizer, double **out_host);
+
+/* where this workspace's pinned block is (what the last hessian / export call on it filled); error if there is none yet */
+int dba_bacore_staging(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, double **out_host);
+
+/* the last step of dba_bacore_hessian_host alone: the reduced system that lies in the workspace (H lower triangle, b: after
+ * dba_ba_reduce, or after a sum over ranks) -> the workspace's pinned block, layout as above; waits for completion. */
+int dba_bacore_export_host(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream, int layout,
+                           const double *A36, double stabilizer, double **out_host);
+
 /* BACore::hessian: stages 1-2 with alpha = 0.001, then copies H [6P,6P], v [6P] (float64) to HOST
- * memory and synchronises the stream (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897). */
+ * memory (the caller owns CPU tensors, src/droid_kernels.cu:1889-1897): dba_bacore_hessian_host + two host memcpys; complete
+ * on return. */
 int dba_bacore_hessian(const float *poses, const float *disps, const float *intrinsics,
                        const float *disps_sens, const float *targets, const float *weights,
                        const float *eta, int eta_rows, const int64_t *ii, const int64_t *jj, int N,

@@ -78,6 +78,14 @@ def test_compiled_bacore_and_operators_equal_the_ctypes_adapter():
         H = torch.zeros(6 * P, 6 * P, dtype=torch.float64)
         v = torch.zeros(6 * P, dtype=torch.float64)
         core.hessian(H, v)
+        # ... and in the factor-graph side's coordinates (round 6): both adapters' hessian_gtsam against the host-side BA2GTSAM
+        from dbaf_amd import fusion
+        Tbc = np.array([0.03, 0.01, -0.08, 0.02, -0.01, 0.7, 0.71])
+        Hn = H.numpy().copy()
+        Hn[np.arange(6), np.arange(6)] += 0.00025
+        ref = fusion.BA2GTSAM_augmented(Hn, v.numpy(), Tbc)
+        aug = core.hessian_gtsam(Tbc) if cls is db.BACore else core.hessian_gtsam(torch.from_numpy(fusion.tangent_block(Tbc)), 0.00025).numpy()
+        np.testing.assert_allclose(np.array(aug), ref, rtol=0, atol=1e-10 * np.abs(ref).max())
         dx = torch.linalg.solve(H + 1e-3 * torch.eye(6 * P, dtype=torch.float64), v)
         core.retract(dx)
         res.append((H, v, s["poses"].cpu(), s["disps"].cpu()))
