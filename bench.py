@@ -760,6 +760,14 @@ def main():
             args.no_cpu_baseline = True
         achieved = alg_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
         gn_bytes = N * HW * 16 + W.M * HW * 16  # SURVEY 8(d) B_gn: target, weight + disps r/w, eta, disps_sens
+        ranks_seen = world
+        if world > 1 and dist is not None:
+            try:
+                from dbaf_amd.sharded import _Comms
+                seen = _Comms.info(_Comms.any_existing()) if args.backend == "nccl" else None   # (no collective here: rank 0 only)
+                ranks_seen = seen[0] if seen else int(dist.get_world_size())
+            except Exception:
+                ranks_seen = int(dist.get_world_size())
         out = {
             "metric": ("DBA iterations/sec (%d-KF, %d-edge, %dx%d) [dba_update/s]" % (W.num_kf, N, 8 * w, 8 * h) if scaling != "weak" else
                        "DBA iterations/sec, edge-normalised (%d-KF, %d-edge window; x edges/96) [dba_update/s per 96 edges]"
@@ -794,7 +802,10 @@ def main():
                        "scaling_mode": scaling,
                        "exchange": ("gloo (host-staged)" if args.backend == "gloo" and world > 1 else
                                     "peer-read" if ba_dist is not dist else "rccl"),
-                       "pyramid_copies": ncopies},
+                       "pyramid_copies": ncopies,
+                       # who the exchange step actually spans: RCCL's own ncclCommCount of the library's communicator when the
+                       # sharded BA runs in-stream, else the process group's size
+                       "ranks_seen": ranks_seen},
             "roofline": {
                 "kernel": "%s (fused 4-level r=3 lookup%s, f16, %d edges on rank 0, "
                           "%s)" % ("corr_lookup_rowtile_kernel<3>" if (w % 64 == 0 and h % 4 == 0) else

@@ -298,7 +298,16 @@ static int ba_linearize_stage(const float *poses, const float *disps, const floa
   if (plan.W.ppl == 4) LAUNCH_LIN(4, false, 1);
   else if (plan.W.ppl == 2) LAUNCH_LIN(2, false, 1);
   else if (no_mfma) LAUNCH_LIN(1, false, 1);
-  else LAUNCH_LIN(1, true, 2);
+  else {
+    // Two waves per pixel slice halve a wave's life but pay the prologue / epilogue (5.9 of ~19 us at 64 KF / 512 edges) twice:
+    // worth it while every wave of the launch is resident at once (25 KF: 3200 waves on 4096 places), not when the launch
+    // already comes in rounds (64 KF: 8192 waves).  DBA_LIN_EW=1|2 forces one.
+    static const int env_ew = [] { const char *e = getenv("DBA_LIN_EW"); return e ? atoi(e) : 0; }();
+    const long waves2 = (long)plan.nchunks * 2 * 4 * plan.T.Mmax;
+    const bool one = env_ew ? env_ew == 1 : waves2 > 4096;
+    if (one) LAUNCH_LIN(1, true, 1);
+    else LAUNCH_LIN(1, true, 2);
+  }
 #undef LAUNCH_LIN
   DBA_LAUNCH_CHECK();
   return DBA_OK;

@@ -1011,6 +1011,10 @@ template __global__ void ba_linearize_kernel<1, true, 2>(const float *, const fl
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, int, float *, float *,
                                                 BaTables, BaBuffers);
+template __global__ void ba_linearize_kernel<1, true, 1>(const float *, const float *, const float *, const float *,
+                                                const float *, const float *, const float *, int, const int64_t *,
+                                                const uint8_t *, int, int, int, int, int, float, int, float *, float *,
+                                                BaTables, BaBuffers);
 template __global__ void ba_linearize_kernel<1, false, 1>(const float *, const float *, const float *, const float *,
                                                 const float *, const float *, const float *, int, const int64_t *,
                                                 const uint8_t *, int, int, int, int, int, float, int, float *, float *,

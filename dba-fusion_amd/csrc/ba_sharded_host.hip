@@ -28,6 +28,8 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // (optional: dba_comm_info)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 
@@ -49,6 +51,8 @@ Rccl &rccl() {
     RCCL_SYM(AllReduce, "ncclAllReduce");
     RCCL_SYM(AllGather, "ncclAllGather");
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    RCCL_SYM(CommCount, "ncclCommCount");
+    RCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef RCCL_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather;
     return r;
@@ -107,6 +111,24 @@ int dba_comm_unique_id(void *id128) {
   const ncclResult_t e = rccl().GetUniqueId(&id);
   if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
   memcpy(id128, &id, 128);
+  return DBA_OK;
+}
+
+// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the number of ranks it spans and this
+// process's rank in it -- bench.py puts the former on its line ("ranks_seen") so that RCCL's own view of N is on record
+int dba_comm_info(dba_comm *c, int *world, int *rank) {
+  if (!c) return DBA_ERR_ARG;
+  int w = c->world, r = c->rank;
+  if (rccl().CommCount) {
+    const ncclResult_t e = rccl().CommCount(c->comm, &w);
+    if (e != ncclSuccess) return rccl_fail("ncclCommCount", e);
+  }
+  if (rccl().CommUserRank) {
+    const ncclResult_t e = rccl().CommUserRank(c->comm, &r);
+    if (e != ncclSuccess) return rccl_fail("ncclCommUserRank", e);
+  }
+  if (world) *world = w;
+  if (rank) *rank = r;
   return DBA_OK;
 }
 

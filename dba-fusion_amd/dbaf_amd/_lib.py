@@ -60,6 +60,7 @@ SYMBOLS = {
     "dba_comm_unique_id": (c_int, [_P]),
     "dba_comm_create": (c_int, [_P, c_int, c_int, ctypes.POINTER(_P)]),
     "dba_comm_destroy": (c_int, [_P]),
+    "dba_comm_info": (c_int, [_P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dba_comm_allreduce_f64": (c_int, [_P, c_size_t, _P]),
     "dba_ba_sharded_run": (c_int, [_P] * 7 + [c_int] + [_P] * 3 + [c_int] * 7 + [c_float, c_float, c_float, c_int, _P, c_int,
                                                                                   c_int, ctypes.POINTER(ShardExchange), _P,

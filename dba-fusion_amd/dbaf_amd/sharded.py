@@ -73,6 +73,17 @@ def window_fpose(ii, jj, t0, t1):
     return fp.astype(np.int32)
 
 
+def hand_round_id(dist, make_id):
+    """the communicator's 128-byte unique id: made by rank 0 (make_id() -> bytes | None), the same bytes on every rank of `dist`
+    afterwards (None everywhere if rank 0 could not make one).  torch.distributed is only this set-up channel."""
+    box = [make_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    idb = box[0]
+    if idb is not None and len(idb) != 128:
+        raise RuntimeError("a communicator id is 128 bytes, got %d" % len(idb))
+    return idb
+
+
 class _Comms:
     """RCCL communicators of libdba_hip.so (dba_comm_*), one per process group: the collectives of a sharded ba are then
     issued by the library itself on the caller's stream, inside dba_ba_sharded_run, instead of by Python between stage
@@ -96,16 +107,15 @@ class _Comms:
         if ent is None:
             lib = _lib.load()
             world, rank = dist.get_world_size(), dist.get_rank()
-            buf = (ctypes.c_ubyte * 128)()
-            box = [None]
-            if rank == 0:
-                rc = lib.dba_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
-                box = [bytes(buf) if rc == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is None:
+
+            def make_id():
+                buf = (ctypes.c_ubyte * 128)()
+                return bytes(buf) if lib.dba_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)) == 0 else None
+            idbytes = hand_round_id(dist, make_id)
+            if idbytes is None:
                 cls._by_group[key] = ent = (None,)
                 return None
-            idb = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+            idb = (ctypes.c_ubyte * 128).from_buffer_copy(idbytes)
             comm = ctypes.c_void_p()
             with torch.cuda.device(device):
                 rc = lib.dba_comm_create(ctypes.cast(idb, ctypes.c_void_p), world, rank, ctypes.byref(comm))
@@ -123,6 +133,24 @@ class _Comms:
                 return None
             cls._by_group[key] = ent = (comm,)
         return ent[0]
+
+    @classmethod
+    def any_existing(cls):
+        """a communicator this process has already made (None if the sharded BA has not run in-stream): never collective"""
+        for ent in cls._by_group.values():
+            if ent[0] is not None:
+                return ent[0]
+        return None
+
+    @staticmethod
+    def info(comm):
+        """(ranks the communicator spans, this process's rank in it) as RCCL reports them, or None without a communicator"""
+        if comm is None:
+            return None
+        w, r = ctypes.c_int(0), ctypes.c_int(0)
+        if _lib.load().dba_comm_info(comm, ctypes.byref(w), ctypes.byref(r)) != 0:
+            return None
+        return w.value, r.value
 
     @classmethod
     def close(cls):

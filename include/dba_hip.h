@@ -212,6 +212,8 @@ typedef struct dba_comm dba_comm;
 int dba_comm_unique_id(void *id128);
 int dba_comm_create(const void *id128, int world, int rank, dba_comm **out);
 int dba_comm_destroy(dba_comm *c);
+/* RCCL's own view of the communicator: ranks it spans, this process's rank (ncclCommCount / ncclCommUserRank) */
+int dba_comm_info(dba_comm *c, int *world, int *rank);
 int dba_comm_allreduce_f64(dba_comm *c, double *buf, size_t count, dba_stream_t stream);   /* in-place sum */
 
 /* who carries what between the ranks in dba_ba_sharded_run.  world = 1: nothing is exchanged (the other fields are ignored).

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from dbaf_amd import synthetic as syn, _lib
 import droid_backends
 lib = _lib.load()
-W = syn.window_25_96(0)
+W = getattr(syn, "window_" + (sys.argv[1] if len(sys.argv) > 1 else "25_96"))(0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 poses, disps = t(W.poses), t(W.disps)
 args = (t(W.intrinsics), t(W.disps_sens), t(W.target), t(W.weight), t(W.eta), t(W.ii), t(W.jj))

@@ -273,3 +273,63 @@ def test_band_index_covers_the_reduced_system_of_the_complete_graph_and_the_exch
         want = before.clone()
         want[torch.from_numpy(idx)] += theirs[torch.from_numpy(idx)]
         assert torch.equal(mine, want)
+
+
+def _worker_world8(rank, world, port, out):
+    """what bench.py --gpus 8 sets up, on CPU: the communicator id made by rank 0 and handed round through the process group
+    (dbaf_amd.sharded.hand_round_id: the set-up channel of the library's own RCCL communicator), then one sharded ba over all
+    eight ranks"""
+    import hashlib
+    from dbaf_amd.sharded import hand_round_id
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    made = []
+
+    def make_id():          # (only rank 0 may be asked)
+        made.append(rank)
+        return hashlib.sha512(b"dba-fusion").digest() * 2
+    idb = hand_round_id(dist, make_id)
+    assert made == ([0] if rank == 0 else []) and len(idb) == 128
+    ids = [None] * world
+    dist.all_gather_object(ids, idb)
+    assert all(x == ids[0] for x in ids)
+    assert hand_round_id(dist, lambda: None) is None          # rank 0 cannot make one: every rank learns it
+    W = syn.make_window(*syn.graph_banded(16, 3), 16, 8, 8, seed=9, intr=(6.0, 6.1, 3.9, 4.1))
+    sh = ShardedWindow(W.ii, W.jj, W.t0, W.t1, W.B, world, rank)
+    sel = sh.local_edges
+    counts = [None] * world
+    dist.all_gather_object(counts, len(sel))
+    assert sum(counts) == W.N and min(counts) > 0             # every rank works, every edge has one owner
+    poses, disps = _t(W.poses), _t(W.disps)
+    sh.ba(poses, disps, _t(W.intrinsics), _t(W.disps_sens), _t(W.target[sel]), _t(W.weight[sel]), _t(W.eta),
+          _t(W.ii[sel], torch.int64), _t(W.jj[sel], torch.int64), 1, W.lm, W.ep, dist, stages=OracleStages())
+    ref = [torch.zeros_like(disps) for _ in range(world)]
+    dist.all_gather(ref, disps)
+    assert all(torch.equal(r, ref[0]) for r in ref)
+    if rank == 0:
+        np.savez(out, poses=poses.numpy(), disps=disps.numpy())
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_id_hand_round_and_sharded_ba(tmp_path):
+    """world_size 8 (the node the scaling bench runs on), gloo: the id hand-round reaches every rank, the partition gives every
+    rank edges, the sharded ba equals the unsharded flow"""
+    from oracle import oracle as orc
+    out = str(tmp_path / "rank0.npz")
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="1", OMP_WAIT_POLICY="passive", PYTHONPATH=os.pathsep.join(sys.path))
+    code = "import sys; import test_sharded_cpu as T; T._worker_world8(int(sys.argv[1]), 8, int(sys.argv[2]), sys.argv[3])"
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), out], env=env,
+                              cwd=os.path.dirname(os.path.abspath(__file__))) for r in range(8)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    W = syn.make_window(*syn.graph_banded(16, 3), 16, 8, 8, seed=9, intr=(6.0, 6.1, 3.9, 4.1))
+    core = orc.BACore(W.poses.astype(np.float64), W.disps.astype(np.float64), W.intrinsics, W.disps_sens, W.target, W.weight, W.eta,
+                      W.ii, W.jj, W.t0, W.t1, W.lm, W.ep, np.float64)
+    H, v = core.hessian()
+    core.retract(np.linalg.solve(H + np.diag(W.ep + W.lm * np.diag(H)), v))
+    np.testing.assert_allclose(got["poses"], core.poses, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["disps"], core.disps, rtol=1e-8, atol=1e-9)
