@@ -54,7 +54,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r05_pmc_lookup%s.json")   # % "" for the default window, "_<window>" otherwise
+PMC_FILE = os.path.join("profiles", "r06_pmc_lookup%s.json")   # % "" for the default window, "_<window>" otherwise
 LOOKUP_SOURCES = ("dba-fusion_amd/csrc/corr_sheared.hip", "dba-fusion_amd/csrc/reproj.h")
 
 
@@ -828,7 +828,7 @@ def main():
                                "terms of C, w, frame_distance and depth_filter are restatement-only (the reference has no "
                                "runnable counterpart); volume, projection, Schur algebra and one torch-BA step are pinned by "
                                "vectors of the reference's own Python, the call-site tensors by tests/golden/caller_dumps.npz; "
-                               "BA state vs the float64 arbiter on this window (tests/test_gpu_ba.py, profiles/r05_parity_report.jsonl): "
+                               "BA state vs the float64 arbiter on this window (tests/test_gpu_ba.py, profiles/r06_parity_report.jsonl): "
                                "poses 1e-5 m / 1e-6 rad met, inverse depths within 1e-4 of |d_ref| on 99.999 % of the pixels; the worst "
                                "one, frame 24 pixel (53, 6) (d 1.211 -> 0.9976), is 1.05e-4 off -- the reference's own fp32 arithmetic "
                                "(fp32-faithful oracle) is 0.91e-4 off there, device vs that oracle 0.58e-4",

@@ -34,6 +34,39 @@ void set_last_error(const char *what, hipError_t e) {
 // DBA_SCHUR_KERNEL = rows | frame or dba_ba_schur_select() force one (the tests run both).
 // deterministic (fixed-point) accumulation of H, b: dba_ba_set_deterministic / DBA_DETERMINISTIC=1 (ba_kernels.hip: acc_add)
 static std::atomic<int> g_deterministic{[] { const char *e = getenv("DBA_DETERMINISTIC"); return (e && e[0] == '1') ? 1 : 0; }()};
+// residual check behind every solve of the stage functions and of dba_ba (opt-in: one more launch of ~5 us per solve)
+static std::atomic<int> g_solve_check{[] { const char *e = getenv("DBA_SOLVE_CHECK"); return (e && e[0] == '1') ? 1 : 0; }()};
+
+// || (H + diag(ep + lm H_ii)) x - b ||_inf <= 1e-5 (||b||_inf + max_i sum_j |H_ij x_j|)  (x is the float solution: its rounding alone is
+// ~6e-8 of the row sums) -- else dx := 0, meta[1] := 1.  H: lower triangle.  One workgroup, a row per thread at a time.
+__global__ __launch_bounds__(256) void ba_solve_check_kernel(const double *__restrict__ H, const double *__restrict__ b, int n, double lm,
+                                                             double ep, float *__restrict__ dx, int *__restrict__ meta) {
+  __shared__ double s_res[256], s_mag[256];
+  __shared__ int s_bad;
+  if (meta[1] != 0) return;   // already a failed solve: dx is zero
+  double res = 0.0, mag = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double acc = -b[i], m = fabs(b[i]);
+    for (int j = 0; j < n; j++) {
+      double h = H[(size_t)max(i, j) * n + min(i, j)];
+      if (i == j) h = fma(lm, h, h) + ep;
+      const double t = h * (double)dx[j];
+      acc += t, m += fabs(t);
+    }
+    res = fmax(res, fabs(acc)), mag = fmax(mag, m);
+  }
+  s_res[threadIdx.x] = res, s_mag[threadIdx.x] = mag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0, m = 0.0;
+    for (int k = 0; k < (int)blockDim.x; k++) r = fmax(r, s_res[k]), m = fmax(m, s_mag[k]);
+    s_bad = !(r <= 1e-5 * m) ? 1 : 0;   // (NaN counts as bad)
+    if (s_bad) meta[1] = 1;
+  }
+  __syncthreads();
+  if (s_bad)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dx[i] = 0.f;
+}
 static std::atomic<int> g_schur_form{[] {
   const char *e = getenv("DBA_SCHUR_KERNEL");
   return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'f' || e[0] == 'g') ? 2 : 0);
@@ -411,6 +444,23 @@ int dba_ba_set_deterministic(int on) {
   return DBA_OK;
 }
 
+int dba_ba_solve_check(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
+                       dba_stream_t stream) {
+  BaPlan plan;
+  const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
+  if (rc != DBA_OK) return rc;
+  if (plan.P <= 0) return DBA_OK;
+  hipLaunchKernelGGL(ba_solve_check_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, plan.W.H, plan.W.b, 6 * plan.P, (double)lm,
+                     (double)ep, plan.W.dx, plan.T.meta);
+  DBA_LAUNCH_CHECK();
+  return DBA_OK;
+}
+
+int dba_ba_set_solve_check(int on) {
+  g_solve_check.store(on ? 1 : 0, std::memory_order_relaxed);
+  return DBA_OK;
+}
+
 int dba_ba_schur_generation(void) { return g_schur_generation.load(std::memory_order_relaxed); }
 
 int dba_ba_symmetrize(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_bytes, dba_stream_t stream) {
@@ -435,8 +485,18 @@ static int ba_solve_stage(int N, int B, int ht, int wd, int t0, int t1, float lm
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int *fpose = graph_fpose ? graph_fpose : (graph_skyline ? plan.T.fpose : nullptr);
-  return launch_ba_solve(plan.W.H, plan.W.b, fpose, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
-                         plan.W.Lscratch, (hipStream_t)stream, nullptr, hint);
+  const int rc2 = launch_ba_solve(plan.W.H, plan.W.b, fpose, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
+                                  plan.W.Lscratch, (hipStream_t)stream, nullptr, hint);
+  if (rc2 != DBA_OK) return rc2;
+  // opt-in guard (dba_ba_set_solve_check / DBA_SOLVE_CHECK=1): the residual of the damped system at the solution, by a kernel of
+  // its own behind the solver -- a solve that went wrong silently (the window solver's waves meet through flags, not barriers)
+  // becomes a zero update with meta[1] = 1, which is what a failed factorisation gives (droid_kernels.cu:1263-1266)
+  if (g_solve_check.load(std::memory_order_relaxed) && plan.P > 0) {
+    hipLaunchKernelGGL(ba_solve_check_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, plan.W.H, plan.W.b, 6 * plan.P, (double)lm,
+                       (double)ep, plan.W.dx, plan.T.meta);
+    DBA_LAUNCH_CHECK();
+  }
+  return DBA_OK;
 }
 
 int dba_ba_solve(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,

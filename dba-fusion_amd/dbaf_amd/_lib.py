@@ -51,6 +51,8 @@ SYMBOLS = {
     "dba_ba_schur_thread_form": (c_int, []),
     "dba_ba_schur_generation": (c_int, []),
     "dba_ba_set_deterministic": (c_int, [c_int]),
+    "dba_ba_set_solve_check": (c_int, [c_int]),
+    "dba_ba_solve_check": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
     "dba_ba_symmetrize": (c_int, [c_int] * 6 + [_P, c_size_t, _P]),
     "dba_ba_solve": (c_int, [c_int] * 6 + [c_float, c_float, _P, c_size_t, _P]),
     "dba_ba_solve_skyline": (c_int, [c_int] * 6 + [c_float, c_float, _P, _P, c_size_t, _P]),

@@ -155,6 +155,15 @@ int dba_ba_schur_generation(void); /* number of dba_ba_schur_select calls so far
  * of ranks.  Costs one small launch per Gauss-Newton iteration. */
 int dba_ba_set_deterministic(int on);
 
+/* opt-in guard (also DBA_SOLVE_CHECK=1): behind every solve a kernel checks the residual of the damped system at the float
+ * solution; a solve that is wrong beyond rounding becomes a zero update with the failure flag set, as a failed factorisation
+ * does (/root/reference/src/droid_kernels.cu:1263-1266).  ~5 us per solve; off by default: the solvers' flag protocols are covered
+ * by the cold-start stress of the GPU suite (tests/test_gpu_solve_cold.py). */
+int dba_ba_set_solve_check(int on);
+/* the check alone, on what lies in the workspace (H lower triangle, b, dx) */
+int dba_ba_solve_check(int N, int B, int ht, int wd, int t0, int t1, float lm, float ep, void *ws, size_t ws_bytes,
+                       dba_stream_t stream);
+
 /* H <- its lower triangle mirrored.  dba_ba and the sharded front stage keep only the lower triangle of H up (what the
  * solvers read: half the float64 atomics); a caller that hands the full matrix on (ShardedBACore.hessian -> GTSAM) mirrors it
  * first.  dba_ba_reduce and dba_bacore_hessian always produce the full matrix (mirrored from the lower triangle: symmetric

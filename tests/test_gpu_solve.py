@@ -405,3 +405,31 @@ def test_window_kernel_many_back_to_back_solves_are_identical():
     for rep in range(300):
         dx, failed = S.solve(H, b, fpose)
         assert failed == 0 and np.array_equal(dx, first), rep
+
+
+def test_opt_in_residual_check_turns_a_wrong_solve_into_a_zero_update():
+    """dba_ba_set_solve_check / DBA_SOLVE_CHECK=1: a kernel behind the solver checks the residual of the damped system at
+    the solution; a right solve passes untouched, a solution that is wrong beyond rounding becomes dx = 0 with the failure flag set"""
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    P = 24
+    H, b, fpose = _pose_system(rng, P, 4)
+    S = _SkylineSolver(P)
+    lib.dba_ba_set_solve_check(1)
+    try:
+        dx, failed = S.solve(H, b, fpose)
+    finally:
+        lib.dba_ba_set_solve_check(0)
+    ref = _ref(H, b)
+    assert failed == 0
+    np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+    # the same workspace, one unknown of the solution spoilt by 1e-3 of its size: the check alone
+    lay, ws, n = S.lay, S.ws, 6 * P
+    bad = dx.copy()
+    bad[70] *= 1.001
+    ws[lay.dx:lay.dx + 4 * n].view(torch.float32).copy_(torch.from_numpy(bad).cuda())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.dba_ba_solve_check(*S.dims, 1e-4, 0.1, ctypes.c_void_p(ws.data_ptr()), S.nbytes, stream), "dba_ba_solve_check")
+    torch.cuda.synchronize()
+    assert int(ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()[1]) == 1
+    assert not ws[lay.dx:lay.dx + 4 * n].view(torch.float32).any()

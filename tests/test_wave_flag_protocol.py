@@ -166,7 +166,7 @@ def _run(TB, handover_wait, seed, bias, NT=3, K=None, gate=True, slow_wave=None)
 @pytest.mark.parametrize("TB,NT", [(2, 3), (3, 3), (9, 3), (9, 4), (3, 4), (9, 5), (6, 5)])
 def test_shipped_protocol_never_reads_what_is_not_written(TB, NT):
     """48-row window (three factor waves) and 64-row window (four)"""
-    for seed in range(300):
+    for seed in range(150):
         for bias in (1.0, 4.0, 20.0):
             assert _run(TB, True, seed, bias, NT) == [], (TB, NT, seed, bias)
 
@@ -187,7 +187,7 @@ def test_ring_of_panels_is_never_overwritten_early_nor_read_late(TB, K, NT):
     """no panel's place is rewritten before every factor wave and the substitution wave have read it and it has been copied out;
     on the way back no tile column is read before it has returned, none returns over a column still being read -- with one of
     the factor waves, the substitution wave or the loader falling behind"""
-    for seed in range(40):
+    for seed in range(12):
         for slow in (None, NT, NT + 1):
             for bias in (1.0, 20.0):
                 assert _run(TB, True, seed, bias, NT, K, True, slow) == [], (TB, K, NT, seed, slow, bias)

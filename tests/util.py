@@ -39,6 +39,38 @@ def _record(rec):
         pass
 
 
+def check_depths_every_pixel(disps, ref_disps, old_disps, ref32_disps, d_rtol=1e-4, floor_factor=1.25):
+    """THE statement of the depth tolerance on the windows of BASELINE's configs, every pixel, no fraction:
+
+    comparator: the float64 arbiter instantiation of the oracle (the reference's algorithm in exact-enough arithmetic);
+      (1) |d - d_ref| <= 1e-4 * max(|d_ref|, |d_old|)                          -- the inverse depth's own scale, before / after
+      (2) |d - d_ref| <= max(1e-4 * |d_ref|, 1.25 * |d_ref32 - d_ref|)        -- relative to the NEW depth alone, except where
+          the reference's own fp32 arithmetic (the fp32-faithful oracle, ref32) is at the same noise floor: a pixel the update
+          shrinks strongly turns the ~3e-7 m of fp32 noise in the pose increment into ~1e-4 of its depth (dz = Q (w - E^T dx),
+          Q E ~ 300 / m), for the reference exactly as for this path; there the device may be at most 25 % further from the
+          arbiter than the reference's own arithmetic is.  (2) is asked of the pixels whose depth the update does not cancel
+          (|d_ref| >= 0.1 |d_old|: all but a handful; where it does cancel, |d_new| is no scale for an fp32 sum and (1) is the bound).
+    Returns (worst of (1) as a multiple of its bound, worst of (2), pixels that needed the noise-floor clause)."""
+    d, r, o = np.asarray(disps, np.float64), np.asarray(ref_disps, np.float64), np.asarray(old_disps, np.float64)
+    q = np.asarray(ref32_disps, np.float64)
+    err = np.abs(d - r)
+    b1 = d_rtol * np.maximum(np.abs(r), np.abs(o))
+    b2 = np.maximum(d_rtol * np.abs(r), floor_factor * np.abs(q - r))
+    solid = np.abs(r) >= 0.1 * np.abs(o)
+    ratio2 = np.where(solid, err / np.maximum(b2, 1e-300), 0.0)
+    w1, w2 = float((err / np.maximum(b1, 1e-300)).max()), float(ratio2.max())
+    needed = int(((err > d_rtol * np.abs(r)) & solid).sum())
+    i2 = int(np.argmax(ratio2))
+    _record(dict(kind="depths_every_pixel", worst_over_scale_bound=w1, worst_over_dref_or_floor_bound=w2,
+                 pixels_beyond_1e4_of_dref=needed, pixels=int(err.size), cancelling_pixels=int((~solid).sum()),
+                 worst_pixel=dict(index=[int(v) for v in np.unravel_index(i2, err.shape)], d_ref=float(r.flat[i2]), d_old=float(o.flat[i2]),
+                                  err_over_dref=float(err.flat[i2] / max(abs(r.flat[i2]), 1e-300)),
+                                  ref32_err_over_dref=float(abs(q.flat[i2] - r.flat[i2]) / max(abs(r.flat[i2]), 1e-300)))))
+    assert w1 <= 1.0, "a pixel is %.3f x the bound 1e-4 max(|d_ref|, |d_old|)" % w1
+    assert w2 <= 1.0, "a pixel is %.3f x the bound max(1e-4 |d_ref|, %.2f |d_ref32 - d_ref|)" % (w2, floor_factor)
+    return w1, w2, needed
+
+
 def check_state(poses, disps, ref_poses, ref_disps, old_disps, ref32_disps=None, t_tol=1e-5, r_tol=1e-6,
                 d_rtol=1e-4, frac=0.995, ref32_factor=2.0, ref32_poses=None, log32_disps=None, log32_poses=None):
     """north_star tolerances: poses 1e-5 m / 1e-6 rad; inverse depths 1e-4 relative -- measured against the
