@@ -136,7 +136,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   L.Q = take(sizeof(float) * (size_t)Mmax * HW);
   L.w = take(sizeof(float) * (size_t)Mmax * HW);
   const size_t o_hparte = take(sizeof(float) * (size_t)(N > 0 ? N : 1) * nparts_max * HPE_STRIDE);
-  const size_t o_hpartf = take(sizeof(float) * (size_t)(Mmax > 0 ? Mmax : 1) * nparts_max * HPF_STRIDE);
+  const size_t o_aedge = take(sizeof(double) * 36 * (size_t)(N > 0 ? N : 1));
   L.dx = take(sizeof(float) * (size_t)(n6 > 0 ? n6 : 1));
   const size_t o_ptmp = take(sizeof(float) * 2 * 7 * (size_t)B);
   L.H = take(sizeof(double) * (size_t)(n6 > 0 ? n6 * (size_t)n6 : 1));
@@ -178,7 +178,7 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
     plan->W.Q = reinterpret_cast<float *>(base + L.Q);
     plan->W.w = reinterpret_cast<float *>(base + L.w);
     plan->W.HpartE = reinterpret_cast<float *>(base + o_hparte);
-    plan->W.HpartF = reinterpret_cast<float *>(base + o_hpartf);
+    plan->W.Aedge = reinterpret_cast<double *>(base + o_aedge);
     plan->W.dx = reinterpret_cast<float *>(base + L.dx);
     plan->W.poses_tmp = reinterpret_cast<float *>(base + o_ptmp);
     plan->W.H = reinterpret_cast<double *>(base + L.H);
@@ -363,7 +363,7 @@ static int ba_reduce_stage(const int64_t *ii, const int64_t *jj, const uint8_t *
   BaPlan plan;
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
-  const int ablocks = (N + 3) / 4 + (plan.T.Mmax + 7) / 8;
+  const int ablocks = (N + 3) / 4;   // pose-block assembly: one wave per edge (round 6: the per-frame blocks are products of the per-edge ones)
   if (plan.P <= 0) return DBA_OK;
   static const bool force_full = [] { const char *e = getenv("DBA_H_FULL"); return e && e[0] == '1'; }();
   if (force_full) lower = 0;

@@ -4,8 +4,7 @@
 
 namespace dba {
 
-constexpr int HPE_STRIDE = 64;  // floats per per-wave, per-edge partial (63 used: Hji, Hjj, vj)
-constexpr int HPF_STRIDE = 32;  // floats per per-wave, per-frame partial (27 used: Hii, vi)
+constexpr int HPE_STRIDE = 32;  // floats per per-wave, per-edge partial (27 used: Hjj lower triangle, vj)
 #ifndef SCHUR_KP_CFG
 #define SCHUR_KP_CFG 8
 #endif
@@ -44,7 +43,7 @@ struct BaBuffers {
   float *Q;      // [Mmax, HW]      1 / C
   float *w;      // [Mmax, HW]
   float *HpartE; // [N, nparts, HPE_STRIDE]
-  float *HpartF; // [Mmax, nparts, HPF_STRIDE]
+  double *Aedge; // [N, 36]  per edge: A with Ji = Jj A (row-major), written by the linearisation, read by the assembly
   double *H;     // [6P, 6P]
   double *b;     // [6P]
   float *dx;     // [P, 6]

@@ -441,11 +441,36 @@ __device__ __forceinline__ float backsub_pixel(const BaTables &T, const BaBuffer
 // stage 1: fused linearisation per (source frame, 64-pixel wave slice)
 // ---------------------------------------------------------------------------------------------
 
+// Round 6: only the TARGET pose's Jacobian rows are formed per pixel.  The source pose's are the same rows times a matrix that
+// depends on the edge alone -- Ji = Jj A, A = -Ad(Gij)^T as adjSE3 spells it (droid_kernels.cu:181-198, :375-383) -- so
+//   Hjj = sum w Jj^T Jj,  vj = sum w Jj^T r      are reduced over the pixels (27 sums per edge instead of 63 + 27),
+//   Hij = A^T Hjj,  Hii += A^T Hjj A,  vi += A^T vj    follow per EDGE in float64 in the assembly (ba_assemble_block), and
+//   Ei  = sum over the frame's edges of A^T Eij        per pixel (27 multiply-adds: A has a zero 3 x 3 block).
 struct PixelLin {
-  float Ju[12], Jv[12];  // rows of the 2x12 Jacobian wrt (pose i | pose j)
+  float Ju[6], Jv[6];    // rows of the 2x6 Jacobian wrt pose j
   float Jzu, Jzv;        // wrt inverse depth of the source pixel
   float ru, rv, wu, wv;
 };
+
+// A [6][6] row-major with Ji[c] = sum_k Jj[k] A[k][c], from the edge's relative pose (tij, R row-major):
+//   tau columns:  -R^T a_tau            ;  phi columns:  -(R^T a_phi + R^T (a_tau x t))
+template <typename T>
+__device__ __forceinline__ void edge_adjoint(const T *t, const T *R, T *A) {
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      A[6 * k + c] = -R[3 * k + c];
+      A[6 * (3 + k) + 3 + c] = -R[3 * k + c];
+      A[6 * (3 + k) + c] = (T)0;
+    }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    A[6 * 0 + 3 + c] = t[2] * R[3 + c] - t[1] * R[6 + c];
+    A[6 * 1 + 3 + c] = t[0] * R[6 + c] - t[2] * R[c];
+    A[6 * 2 + 3 + c] = t[1] * R[c] - t[0] * R[3 + c];
+  }
+}
 
 __device__ __forceinline__ void linearize_pixel(float u, float v, float disp, float tu, float tv,
                                                 float wgt_u, float wgt_v, const float *intr,
@@ -466,7 +491,7 @@ __device__ __forceinline__ void linearize_pixel(float u, float v, float disp, fl
   L.ru = tu - fmaf(fx * d, x, cx);
   L.rv = tv - fmaf(fy * d, y, cy);
 
-  float *Jju = L.Ju + 6, *Jjv = L.Jv + 6;
+  float *Jju = L.Ju, *Jjv = L.Jv;
   Jju[0] = fx * (h * d);
   Jju[1] = 0.f;
   Jju[2] = fx * (-x * h * d2);
@@ -488,30 +513,11 @@ __device__ __forceinline__ void linearize_pixel(float u, float v, float disp, fl
   if (stereo) { wu = 0.f; wv = 0.f; }
   L.wu = wu;
   L.wv = wv;
-
-  // Ji = -Ad(Gij)^T Jj :  tau part -R^T a_tau ; phi part -(R^T a_phi + R^T (a_tau x t))
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const float *a = c ? Jjv : Jju;
-    float *o = c ? L.Jv : L.Ju;
-    const float c0 = a[1] * tij[2] - a[2] * tij[1] + a[3];
-    const float c1 = a[2] * tij[0] - a[0] * tij[2] + a[4];
-    const float c2 = a[0] * tij[1] - a[1] * tij[0] + a[5];
-    o[0] = -(R.r[0] * a[0] + R.r[3] * a[1] + R.r[6] * a[2]);
-    o[1] = -(R.r[1] * a[0] + R.r[4] * a[1] + R.r[7] * a[2]);
-    o[2] = -(R.r[2] * a[0] + R.r[5] * a[1] + R.r[8] * a[2]);
-    o[3] = -(R.r[0] * c0 + R.r[3] * c1 + R.r[6] * c2);
-    o[4] = -(R.r[1] * c0 + R.r[4] * c1 + R.r[7] * c2);
-    o[5] = -(R.r[2] * c0 + R.r[5] * c1 + R.r[8] * c2);
-  }
 }
 
-// Per-wave partial layouts (one wave = 64*PPL pixels of one source frame):
-//   per edge  (HPE_STRIDE = 64 floats): [0,36) Hji[a][b] = sum Jj_a Ji_b ; [36,57) lower triangle of Hjj
-//                                       (a >= b, index a(a+1)/2 + b) ; [57,63) vj
-//   per frame (HPF_STRIDE = 32 floats): [0,21) lower triangle of Hii ; [21,27) vi
-// Hii and vi only involve the source pose, so they are summed over the frame's out-edges in registers
-// and folded across the wave once per frame instead of once per edge.
+// Per-wave partial layout (one wave = 64*PPL pixels of one source frame), per edge, HPE_STRIDE = 32 floats:
+//   [0,21) lower triangle of Hjj (a >= b, index a(a+1)/2 + b) ; [21,27) vj
+// (round 5 also kept Hji per edge and Hii | vi per frame: 63 + 27 sums; they are products of these with the edge's A now)
 
 // Cross-lane sums by LDS transpose: every lane drops value #L into column `lane` of row L of a per-wave
 // [64][RED_PITCH] float tile (consecutive lanes -> consecutive banks); afterwards lane L adds up row L with 16
@@ -545,28 +551,13 @@ __device__ __forceinline__ void wave_lds_fence() {  // one wave: its LDS writes 
 }
 
 template <int PPL, int A, int B_>
-struct HjiLoop {  // A in [0,6) indexes Jj, B_ in [0,6) indexes Ji
-  __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
-    float val = 0.f;
-#pragma unroll
-    for (int q = 0; q < PPL; q++)
-      val += L[q].wu * L[q].Ju[6 + A] * L[q].Ju[B_] + L[q].wv * L[q].Jv[6 + A] * L[q].Jv[B_];
-    reduce_deposit<A * 6 + B_>(val, acc);
-    if constexpr (B_ < 5)
-      HjiLoop<PPL, A, B_ + 1>::run(L, acc);
-    else if constexpr (A < 5)
-      HjiLoop<PPL, A + 1, 0>::run(L, acc);
-  }
-};
-
-template <int PPL, int A, int B_>
 struct HjjLoop {
   __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
     float val = 0.f;
 #pragma unroll
     for (int q = 0; q < PPL; q++)
-      val += L[q].wu * L[q].Ju[6 + A] * L[q].Ju[6 + B_] + L[q].wv * L[q].Jv[6 + A] * L[q].Jv[6 + B_];
-    reduce_deposit<36 + A * (A + 1) / 2 + B_>(val, acc);
+      val += L[q].wu * L[q].Ju[A] * L[q].Ju[B_] + L[q].wv * L[q].Jv[A] * L[q].Jv[B_];
+    reduce_deposit<A * (A + 1) / 2 + B_>(val, acc);
     if constexpr (B_ < A)
       HjjLoop<PPL, A, B_ + 1>::run(L, acc);
     else if constexpr (A < 5)
@@ -579,31 +570,24 @@ struct VjLoop {
   __device__ __forceinline__ static void run(const PixelLin (&L)[PPL], float *acc) {
     float val = 0.f;
 #pragma unroll
-    for (int q = 0; q < PPL; q++) val += L[q].wu * L[q].ru * L[q].Ju[6 + A] + L[q].wv * L[q].rv * L[q].Jv[6 + A];
-    reduce_deposit<57 + A>(val, acc);
+    for (int q = 0; q < PPL; q++) val += L[q].wu * L[q].ru * L[q].Ju[A] + L[q].wv * L[q].rv * L[q].Jv[A];
+    reduce_deposit<21 + A>(val, acc);
     if constexpr (A < 5) VjLoop<PPL, A + 1>::run(L, acc);
   }
 };
 
-template <int I>
-struct FrameReduce {  // 27 per-frame sums held in fsum[]
-  __device__ __forceinline__ static void run(const float (&fsum)[27], float *acc) {
-    reduce_deposit<I>(fsum[I], acc);
-    if constexpr (I < 26) FrameReduce<I + 1>::run(fsum, acc);
-  }
-};
-
-// MF: the cross-lane sums of one edge (12 x 13 block [Hii Hij vi; Hji Hjj vj] = sum over the wave's 128 residual rows of
-// w J^T [J r]) run on the matrix cores: the wave stages its rows transposed in LDS and feeds 32
-// v_mfma_f32_16x16x4_f32 (A = w J^T, B = [J r]); both operands of a lane are the same staged value.  This replaces
-// 63 x (4 flops + one LDS deposit) + 27 x 4 flops per lane and the 17 KB transpose tile by 28 deposits and 8.5 KB.
+// MF: the cross-lane sums of one edge run on the matrix cores.  Rows 0..6 of the 16 x 16 tile are the u residual row's
+// [Jj | r], rows 8..14 the v row's; K runs over the wave's 64 pixels: D = (w X) X^T holds sum w_u [Jj r]_u^T [Jj r]_u in its
+// block (0..6, 0..6) and the v row's in (8..14, 8..14) -- their sum is [Hjj vj] -- and the cross blocks are not read.  The wave
+// stages its 14 values + 2 weights per pixel transposed in LDS and issues 16 v_mfma_f32_16x16x4_f32 whose two operands are the
+// same staged value (round 5: the 12 x 13 block over 128 residual rows, 32 instructions, 26 staged values).
 typedef float lin_f4 __attribute__((ext_vector_type(4)));
-constexpr int MFS_T = 32;                      // K steps of 4 residual rows
-constexpr int MFS_P = 36;                      // row pitch in floats: the 16 rows a 16-lane group reads with one
-                                               // ds_read_b128 start 36 banks apart (pitch 32: 8-way conflicts, which
-                                               // made the operand reads the kernel's bottleneck)
+constexpr int MFS_T = 16;                      // K steps of 4 pixels
+constexpr int MFS_P = 20;                      // row pitch in floats: the 16 rows a 16-lane group reads with one ds_read_b128
+                                               // start 20 banks apart -- sixteen different multiples of 4 mod 64: conflict-free
 constexpr int MFS_VALS = 4 * 16 * MFS_P;       // staged [k][i][t]
-constexpr int MFS_FLOATS = MFS_VALS + 4 * MFS_P;  // + weights [k][t]
+constexpr int MFS_WTS = 4 * 2 * MFS_P;         // weights [k][u | v][t]
+constexpr int MFS_FLOATS = (MFS_VALS + MFS_WTS) > (64 + 8 * 64) ? (MFS_VALS + MFS_WTS) : (64 + 8 * 64);  // (>= the EW hand-over's 8 x 64)
 
 #ifdef LIN_PROF
 __device__ unsigned long long g_lin_prof[16];
@@ -700,10 +684,6 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
 #pragma unroll
     for (int c = 0; c < 6; c++) Ei[q][c] = 0.f;
   }
-  float fsum[27];  // per-lane sums over pixels and edges of Hii (lower triangle) and vi
-#pragma unroll
-  for (int i = 0; i < 27; i++) fsum[i] = 0.f;
-
   // The out-edges of the frame are resolved in batches of up to EB by the first wave, one edge per lane
   // (elist -> jj -> poses is a chain of three dependent global loads: paid once per batch, not per edge);
   // the per-edge relative pose then comes out of LDS, and the next edge's targets/weights are in flight
@@ -711,12 +691,12 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
   constexpr int EB = 16;            // (16, not 64: with the staging tiles below the workgroup then needs 40 KB of LDS and
                                     // four of them fit a CU: every workgroup of a 25-keyframe window is resident at once)
   __shared__ float s_pose[EB][12];  // tij[3], R[9]
+  __shared__ __attribute__((aligned(16))) float s_adj[EB][28];  // the 27 non-zero entries of A (Ji = Jj A): [k < 3][6] then [3 + k][3]
   __shared__ int s_edge[EB][2];     // edge id, target frame
   constexpr int RED_FLOATS = MF ? MFS_FLOATS : 64 * RED_PITCH;
   __shared__ __attribute__((aligned(16))) float s_red[4][RED_FLOATS];  // per-wave transpose tiles / MFMA staging
   float *red_wave = s_red[wv];
   float *red_lane = red_wave + lane;
-  lin_f4 facc = {0.f, 0.f, 0.f, 0.f};  // MF: rows 0..5 of the block (frame sums), accumulated over the edges
   const int e0 = T.eoff[m], e1 = T.eoff[m + 1];
   LP(0);
   for (int batch = e0; batch < e1; batch += EB) {
@@ -739,6 +719,22 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
       for (int c = 0; c < 3; c++) s_pose[threadIdx.x][c] = (float)t64[c];
 #pragma unroll
       for (int c = 0; c < 9; c++) s_pose[threadIdx.x][3 + c] = (float)R64[c];
+      // the source pose's Jacobian is the target pose's times A (see PixelLin): in float for the per-pixel rows of E, in float64
+      // for the assembly of the pose blocks (one workgroup per frame leaves it in the workspace)
+      // (entry by entry, edge_adjoint's formulas: a 36-double array would cost 72 registers in every lane of the kernel)
+      double *Aw = (blockIdx.x == 0) ? W.Aedge + (size_t)n * 36 : nullptr;
+      float *As = s_adj[threadIdx.x];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double rkc = -R64[3 * k + c];
+          const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+          const double x = t64[k2] * R64[3 * k1 + c] - t64[k1] * R64[3 * k2 + c];   // A[k][3 + c]
+          As[6 * k + c] = (float)rkc, As[6 * k + 3 + c] = (float)x, As[18 + 3 * k + c] = (float)rkc;
+          if (Aw) Aw[6 * k + c] = rkc, Aw[6 * k + 3 + c] = x, Aw[6 * (3 + k) + c] = 0.0, Aw[6 * (3 + k) + 3 + c] = rkc;
+        }
+      }
     }
     __syncthreads();
     LP(2);
@@ -792,53 +788,49 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
         wsum[q] += bz;
         float *Eij = W.E + ((size_t)(P + n) * 6) * HW + kc[q];
         const float wJzu = L[q].wu * L[q].Jzu, wJzv = L[q].wv * L[q].Jzv;
+        float ej[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-          Ei[q][c] += wJzu * L[q].Ju[c] + wJzv * L[q].Jv[c];
+          ej[c] = wJzu * L[q].Ju[c] + wJzv * L[q].Jv[c];
 #ifndef LIN_ABLATE_ESTORE
-          if (active[q]) Eij[(size_t)c * HW] = wJzu * L[q].Ju[6 + c] + wJzv * L[q].Jv[6 + c];
+          if (active[q]) Eij[(size_t)c * HW] = ej[c];
 #endif
         }
-#ifndef LIN_ABLATE_FSUM
-        if constexpr (!MF) {
-        // source-pose terms accumulate in registers across the frame's edges
-        int idx = 0;
+        // Ei += A^T Eij (the depth coupling of the source pose: w Jz Ji^T with Ji = Jj A); A[3..5][0..2] = 0
+        const float *Ae = s_adj[i];
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+        for (int c = 0; c < 3; c++)
+          Ei[q][c] += fmaf(ej[2], Ae[12 + c], fmaf(ej[1], Ae[6 + c], ej[0] * Ae[c]));
 #pragma unroll
-          for (int b = 0; b <= a; b++) {
-            fsum[idx] += L[q].wu * L[q].Ju[a] * L[q].Ju[b] + L[q].wv * L[q].Jv[a] * L[q].Jv[b];
-            idx++;
-          }
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-          fsum[21 + a] += L[q].wu * L[q].ru * L[q].Ju[a] + L[q].wv * L[q].rv * L[q].Jv[a];
-        }
-#endif
+        for (int c = 0; c < 3; c++)
+          Ei[q][3 + c] += fmaf(ej[5], Ae[24 + c], fmaf(ej[4], Ae[21 + c], fmaf(ej[3], Ae[18 + c],
+                          fmaf(ej[2], Ae[15 + c], fmaf(ej[1], Ae[9 + c], ej[0] * Ae[3 + c])))));
       }
       float acc;
       if constexpr (MF) {
         static_assert(!MF || PPL == 1, "the matrix-core reduction is written for one pixel per lane");
-        // stage: residual row kappa = 2 lane + c -> [k = kappa & 3][value i][t = kappa >> 2]
+        // stage: pixel = lane -> [k = lane & 3][value i][t = lane >> 2]; i = 0..6: the u row's Jj | r, i = 8..14: the v row's
         {
-          const int t_ = lane >> 1, k0 = 2 * (lane & 1);
-          float *su = red_wave + (k0 * 16) * MFS_P + t_, *sv = su + 16 * MFS_P;
+          const int t_ = lane >> 2, k0 = lane & 3;
+          float *su = red_wave + (k0 * 16) * MFS_P + t_, *sv = su + 8 * MFS_P;
 #pragma unroll
-          for (int i = 0; i < 12; i++) {
+          for (int i = 0; i < 6; i++) {
             su[i * MFS_P] = L[0].Ju[i];
             sv[i * MFS_P] = L[0].Jv[i];
           }
-          su[12 * MFS_P] = L[0].ru;
-          sv[12 * MFS_P] = L[0].rv;
-          red_wave[MFS_VALS + k0 * MFS_P + t_] = L[0].wu;
-          red_wave[MFS_VALS + (k0 + 1) * MFS_P + t_] = L[0].wv;
+          su[6 * MFS_P] = L[0].ru;
+          sv[6 * MFS_P] = L[0].rv;
+          su[7 * MFS_P] = 0.f;    // (rows 7 and 15 are not read back, but a NaN there would not be confined to them:
+          sv[7 * MFS_P] = 0.f;    //  0 * NaN in the products of the OTHER operand's rows)
+          red_wave[MFS_VALS + (k0 * 2) * MFS_P + t_] = L[0].wu;
+          red_wave[MFS_VALS + (k0 * 2 + 1) * MFS_P + t_] = L[0].wv;
         }
         wave_lds_fence();
         lin_f4 c4 = {0.f, 0.f, 0.f, 0.f};
         {
           const lin_f4 *xs = reinterpret_cast<const lin_f4 *>(red_wave + ((lane >> 4) * 16 + (lane & 15)) * MFS_P);
-          const lin_f4 *ws = reinterpret_cast<const lin_f4 *>(red_wave + MFS_VALS + (lane >> 4) * MFS_P);
-          lin_f4 c4b = {0.f, 0.f, 0.f, 0.f};  // two accumulators: the 32 products are not one dependent chain
+          const lin_f4 *ws = reinterpret_cast<const lin_f4 *>(red_wave + MFS_VALS + ((lane >> 4) * 2 + ((lane >> 3) & 1)) * MFS_P);
+          lin_f4 c4b = {0.f, 0.f, 0.f, 0.f};  // two accumulators: the 16 products are not one dependent chain
 #pragma unroll
           for (int t4 = 0; t4 < MFS_T / 4; t4 += 2) {
             const lin_f4 x = xs[t4], w4 = ws[t4], y = xs[t4 + 1], v4 = ws[t4 + 1];
@@ -852,31 +844,28 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
           for (int r = 0; r < 4; r++) c4[r] += c4b[r];
         }
         wave_lds_fence();
-        // D: register r <-> row 4 (lane >> 4) + r, column lane & 15.  Rows 6..11 are this edge's Hji | Hjj | vj;
-        // rows 0..5 (Hii | . | vi) add up over the frame's edges.  The 63 edge values go through LDS once more so
-        // that the partial leaves as one coalesced row, in the layout the assembly kernel reads.
+        // D: register r <-> row 4 (lane >> 4) + r, column lane & 15.  Block (0..6, 0..6) is the u row's [Hjj vj], block
+        // (8..14, 8..14) the v row's: both go to LDS (slots 0..26 and 32..58) and lane l < 27 adds its pair, so that the
+        // partial leaves as one coalesced row in the layout the assembly reads.
         {
           const int g = lane >> 4, col = lane & 15;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int row = 4 * g + r;
-            if (row < 6) facc[r] += c4[r];
-            const int a = row - 6;
+            const int a = row & 7, b = col & 7;
             int slot = -1;
-            if (a >= 0 && a < 6) {
-              if (col < 6) slot = a * 6 + col;
-              else if (col < 12) slot = (col - 6 <= a) ? 36 + a * (a + 1) / 2 + (col - 6) : -1;
-              else if (col == 12) slot = 57 + a;
+            if (((row >> 3) == (col >> 3)) && a < 6) {
+              if (b <= a) slot = a * (a + 1) / 2 + b;
+              else if (b == 6) slot = 21 + a;
             }
-            if (slot >= 0) red_wave[slot] = c4[r];
+            if (slot >= 0) red_wave[32 * (row >> 3) + slot] = c4[r];
           }
         }
         wave_lds_fence();
-        acc = red_wave[lane];  // lane 63 reads a stale slot: never used
+        acc = red_wave[lane & 31] + red_wave[32 + (lane & 31)];  // lanes >= 27 read stale slots: never used
         wave_lds_fence();
       } else {
 #ifndef LIN_ABLATE_REDUCE  // ablation builds only (scratch/)
-      HjiLoop<PPL, 0, 0>::run(L, red_lane);
       HjjLoop<PPL, 0, 0>::run(L, red_lane);
       VjLoop<PPL, 0>::run(L, red_lane);
       wave_lds_fence();
@@ -886,14 +875,14 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
       acc = L[0].Ju[0] + L[0].Jv[7];
 #endif
       }
-      W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
+      if (lane < HPE_STRIDE) W.HpartE[((size_t)n * nparts + wave_global) * HPE_STRIDE + lane] = acc;
       LP(3);
     }
   }
   LP(4);
   if constexpr (EW > 1) {
     // the other waves of the slice hand their per-frame sums over through their (now idle) staging tiles
-    constexpr int NV = 8 * PPL + (MF ? 4 : 27);
+    constexpr int NV = 8 * PPL;
     __syncthreads();
     if (ew != 0) {
 #pragma unroll
@@ -902,13 +891,6 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
         red_lane[(8 * q + 1) * 64] = wsum[q];
 #pragma unroll
         for (int c = 0; c < 6; c++) red_lane[(8 * q + 2 + c) * 64] = Ei[q][c];
-      }
-      if constexpr (MF) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) red_lane[(8 * PPL + r) * 64] = facc[r];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 27; i++) red_lane[(8 * PPL + i) * 64] = fsum[i];
       }
     }
     __syncthreads();
@@ -924,36 +906,8 @@ __global__ __launch_bounds__(256, (PPL == 1 ? (MF ? 4 : 2) : 1)) void ba_lineari
 #pragma unroll
         for (int c = 0; c < 6; c++) Ei[q][c] += src[(8 * q + 2 + c) * 64];
       }
-      if constexpr (MF) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) facc[r] += src[(8 * PPL + r) * 64];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 27; i++) fsum[i] += src[(8 * PPL + i) * 64];
-      }
     }
   }
-  if constexpr (MF) {
-    const int g = lane >> 4, col = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 4 * g + r;
-      int slot = -1;
-      if (row < 6) {
-        if (col <= row) slot = row * (row + 1) / 2 + col;
-        else if (col == 12) slot = 21 + row;
-      }
-      if (slot >= 0) red_wave[slot] = facc[r];
-    }
-    wave_lds_fence();
-    if (lane < HPF_STRIDE) W.HpartF[((size_t)m * nparts + wave_global) * HPF_STRIDE + lane] = red_wave[lane];
-  } else {
-    FrameReduce<0>::run(fsum, red_lane);
-    wave_lds_fence();
-    const float acc = reduce_row(red_wave, lane);
-    if (lane < HPF_STRIDE) W.HpartF[((size_t)m * nparts + wave_global) * HPF_STRIDE + lane] = acc;
-  }
-
 #pragma unroll
   for (int q = 0; q < PPL; q++) {
     if (!active[q]) continue;
@@ -1075,83 +1029,82 @@ __device__ __forceinline__ void ba_assemble_block(int block, const int64_t *__re
   const int n6 = 6 * P;
   const int edge_blocks = (N + 3) / 4;
   if (block < edge_blocks) {
+    // one wave per edge.  Lanes 0..26 add up the edge's partials over the pixel slices in float64 (Hjj lower triangle, vj); every
+    // lane then holds the 6 x 6 block and forms its share of  Hji = Hjj A,  Hii += A^T Hjj A,  vi += A^T vj  with the edge's
+    // A (float64, left in the workspace by the linearisation) -- round 5 reduced these over the pixels as well.
     const int n = 4 * block + (tid >> 6);
     const int l = tid & 63;
-    if (n >= N || l >= 63) return;
+    if (n >= N) return;
     const int src = (int)ii[n];
     if (frame_owned && !frame_owned[src]) return;
-    const float *hp = W.HpartE + (size_t)n * W.nparts * HPE_STRIDE + l;
+    // this lane's entries of the edge's A, requested before the chain of partial loads (they are needed after it)
+    int ta = 0;   // l < 21: the lower-triangle entry (ta, tb) of a 6 x 6 block
+    while ((ta + 1) * (ta + 2) / 2 <= min(l, 20)) ta++;
+    const int tb = min(l, 20) - ta * (ta + 1) / 2;
+    const int ja = min(l, 35) / 6, jb = min(l, 35) % 6;
+    const int va = (l >= 21 && l < 27) ? l - 21 : 0;
+    double Ajb[6], Atb[6], Ata[6], Ava[6];
+    {
+      const double *A = W.Aedge + (size_t)n * 36;
+#pragma unroll
+      for (int k = 0; k < 6; k++) Ajb[k] = A[6 * k + jb], Atb[k] = A[6 * k + tb], Ata[k] = A[6 * k + ta], Ava[k] = A[6 * k + va];
+    }
     double s = 0.0;
-    int part = 0;
-    for (; part + 32 <= W.nparts; part += 32) {  // 32 independent loads in flight: the 64 partials of a 64x64 map are two
-      float v[32];                                // round trips to memory (with 8 in flight this block was the launch's tail)
+    if (l < 27) {
+      const float *hp = W.HpartE + (size_t)n * W.nparts * HPE_STRIDE + l;
+      int part = 0;
+      for (; part + 32 <= W.nparts; part += 32) {  // 32 independent loads in flight: the 64 partials of a 64x64 map are two
+        float v[32];                                // round trips to memory (with 8 in flight this block was the launch's tail)
 #pragma unroll
-      for (int q = 0; q < 32; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
+        for (int q = 0; q < 32; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
 #pragma unroll
-      for (int q = 0; q < 32; q++) s += (double)v[q];
+        for (int q = 0; q < 32; q++) s += (double)v[q];
+      }
+      for (; part + 8 <= W.nparts; part += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += (double)v[q];
+      }
+      for (; part < W.nparts; part++) s += (double)hp[(size_t)part * HPE_STRIDE];
     }
-    for (; part + 8 <= W.nparts; part += 8) {
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPE_STRIDE];
-#pragma unroll
-      for (int q = 0; q < 8; q++) s += (double)v[q];
-    }
-    for (; part < W.nparts; part++) s += (double)hp[(size_t)part * HPE_STRIDE];
     const int i = src - t0, j = (int)jj[n] - t0;
     const bool iv = (i >= 0 && i < P), jv = (j >= 0 && j < P);
-    if (l < 36) {  // Hji[a][b] and its transpose Hij[b][a]
-      const int a = l / 6, b = l % 6;
-      if (iv && jv) h_add_pair(W, n6, 6 * j + a, 6 * i + b, s, lower, fixed);
-    } else if (l < 57) {  // Hjj
-      int a = 0;
-      const int t = l - 36;
-      while ((a + 1) * (a + 2) / 2 <= t) a++;
-      const int b = t - a * (a + 1) / 2;
-      if (jv) {
-        acc_add(&W.H[(size_t)(6 * j + a) * n6 + 6 * j + b], s, fixed);
-        if (a != b && !lower) acc_add(&W.H[(size_t)(6 * j + b) * n6 + 6 * j + a], s, fixed);
+    if (!iv && !jv) return;
+    // (no arrays indexed by the lane's (a, b): the sums travel by __shfl from the lane that holds them)
+    auto tri = [](int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+    if (jv) {      // (a fixed target pose: its block and the coupling are dropped, :1191; the source pose's terms below stay)
+      if (l < 21) {  // Hjj
+        acc_add(&W.H[(size_t)(6 * j + ta) * n6 + 6 * j + tb], s, fixed);
+        if (ta != tb && !lower) acc_add(&W.H[(size_t)(6 * j + tb) * n6 + 6 * j + ta], s, fixed);
+      } else if (l < 27) {
+        acc_add(&W.b[6 * j + (l - 21)], s, fixed);
       }
-    } else {
-      if (jv) acc_add(&W.b[6 * j + (l - 57)], s, fixed);
+    }
+    if (!iv) return;   // (wave-uniform)
+    // Hji[a][b] = (Hjj A)[a][b] for the lanes l = 6 a + b < 36
+    double hji = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) hji = fma(__shfl(s, tri(ja, k), 64), Ajb[k], hji);
+    // Hii[a][b] += (A^T Hjj A)[a][b] for the lanes l < 21 (lower triangle), vi[a] += (A^T vj)[a] for 21 <= l < 27
+    double hii = 0.0, vi = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double u = 0.0;   // (Hjj A)[k][tb]
+#pragma unroll
+      for (int m = 0; m < 6; m++) u = fma(__shfl(s, k >= m ? k * (k + 1) / 2 + m : m * (m + 1) / 2 + k, 64), Atb[m], u);
+      hii = fma(Ata[k], u, hii);
+      vi = fma(Ava[k], __shfl(s, 21 + k, 64), vi);
+    }
+    if (jv && l < 36) h_add_pair(W, n6, 6 * j + ja, 6 * i + jb, hji, lower, fixed);   // ... and its transpose Hij[b][a]
+    if (l < 21) {
+      acc_add(&W.H[(size_t)(6 * i + ta) * n6 + 6 * i + tb], hii, fixed);
+      if (ta != tb && !lower) acc_add(&W.H[(size_t)(6 * i + tb) * n6 + 6 * i + ta], hii, fixed);
+    } else if (l < 27) {
+      acc_add(&W.b[6 * i + va], vi, fixed);
     }
     return;
-  }
-  const int M = T.meta[0];
-  const int m = 8 * (block - edge_blocks) + (tid >> 5);
-  const int l = tid & 31;
-  if (m >= M || l >= 27) return;
-  const int frame = T.kx[m];
-  if (frame_owned && !frame_owned[frame]) return;
-  if (T.eoff[m + 1] == T.eoff[m]) return;  // no out-edges: no partials were written
-  const int i = frame - t0;
-  if (i < 0 || i >= P) return;  // fixed pose: its block is dropped (:1191)
-  const float *hp = W.HpartF + (size_t)m * W.nparts * HPF_STRIDE + l;
-  double s = 0.0;
-  int part = 0;
-  for (; part + 32 <= W.nparts; part += 32) {
-    float v[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++) v[q] = hp[(size_t)(part + q) * HPF_STRIDE];
-#pragma unroll
-    for (int q = 0; q < 32; q++) s += (double)v[q];
-  }
-  for (; part + 8 <= W.nparts; part += 8) {
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = hp[(size_t)(part + q) * HPF_STRIDE];
-#pragma unroll
-    for (int q = 0; q < 8; q++) s += (double)v[q];
-  }
-  for (; part < W.nparts; part++) s += (double)hp[(size_t)part * HPF_STRIDE];
-  if (l < 21) {
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= l) a++;
-    const int b = l - a * (a + 1) / 2;
-    acc_add(&W.H[(size_t)(6 * i + a) * n6 + 6 * i + b], s, fixed);
-    if (a != b && !lower) acc_add(&W.H[(size_t)(6 * i + b) * n6 + 6 * i + a], s, fixed);
-  } else {
-    acc_add(&W.b[6 * i + (l - 21)], s, fixed);
   }
 }
 
@@ -1175,13 +1128,16 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const int64_t *__restrict
   __shared__ float red[4][44];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n6 = 6 * P;
-  if ((int)blockIdx.x >= P + N) {
+  // (round 6: the assembly workgroups come FIRST in the grid -- their chain of partial loads, shuffles and atomics is the longest
+  // in the launch, and dispatched last it was its tail)
+  const int ablk = (N + 3) / 4;
+  if ((int)blockIdx.x < ablk) {
     if (blockIdx.y == 0 && blockIdx.z == 0)
-      ba_assemble_block((int)blockIdx.x - (P + N), ii, jj, frame_owned, N, t0, P, lower, T, W);
+      ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, lower, T, W);
     return;
   }
   // everything a row needs comes from its table row (one load): slot, target pose, partner range, source frame
-  const int r1 = blockIdx.x;
+  const int r1 = (int)blockIdx.x - ablk;
   const int4 ri = *reinterpret_cast<const int4 *>(T.rowinfo + 8 * r1);
   const int m = ri.x, tgt1 = ri.y, first_partner = ri.z, e1 = ri.w;  // partners: r1 itself, then list positions [first_partner, e1)
   if (m < 0) return;
@@ -1494,12 +1450,13 @@ __global__ __launch_bounds__(512, 2) void ba_schur_gram_kernel(const int64_t *__
   __shared__ double red[GRAM_MAX_TILES * 256];
   __shared__ int s_tgt[64];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int frames_blocks = T.Mmax * nch;
-  if ((int)blockIdx.x >= frames_blocks) {
-    if (tid < 256) ba_assemble_block((int)blockIdx.x - frames_blocks, ii, jj, frame_owned, N, t0, P, lower, T, W);
+  const int ablk = (N + 3) / 4;   // (the assembly workgroups first: see ba_schur_kernel)
+  if ((int)blockIdx.x < ablk) {
+    if (tid < 256) ba_assemble_block((int)blockIdx.x, ii, jj, frame_owned, N, t0, P, lower, T, W);
     return;
   }
-  const int m = (int)blockIdx.x / nch, ch = (int)blockIdx.x - m * nch;
+  const int fblk = (int)blockIdx.x - ablk;
+  const int m = fblk / nch, ch = fblk - m * nch;
   const int4 fh = *reinterpret_cast<const int4 *>(T.fhead + 4 * m);  // frame, first row entry, rows
   const int frame = fh.x, nrows = fh.z;
   if (frame < 0 || nrows == 0) return;
