@@ -926,6 +926,7 @@ def cpu_baseline(W, fmaps, ii, jj, sample_edges=8):
     t_look = (time.perf_counter() - t0) / reps * (W.N / ne)
     total = t_ba + t_rep + t_look
     return {"value": round(1.0 / total, 4), "unit": "dba_update/s", "cores": cores, "kind": "port",
+            "sampled": "ba and reprojection in full; lookup leg on %d of %d edges, scaled" % (ne, W.N),
             "sample": "oracle (C, -O3 -march=native, OpenMP over edges/pixels): ba(itrs=2) on the full 25-KF/96-edge "
                       "window %.1f ms + reprojection %.1f ms + 4-level lookup on %d of 96 edges scaled x%.0f = %.1f ms"
                       % (1e3 * t_ba, 1e3 * t_rep, ne, W.N / ne, 1e3 * t_look)}
