@@ -706,10 +706,13 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
 #define FB_PROF_ARG
 #endif
   if (loop_form) {
-    // strips per workgroup: as many as leave >= ~512 workgroups (two rounds of the 256 CUs), at most 16
+    // strips per workgroup: as many as leave ~256 workgroups (ONE round of the 256 CUs: a workgroup's prologue -- its waves' target
+    // fragments, 128 KB -- costs ~11 us against ~7 per strip, so two rounds of short walks pay it twice: a one-edge build, the
+    // motion filter's, was 36 us at 512 workgroups of one strip; round 6), at most 16
     const int nstrips = HW1p / 64;
     const long long rows = (long long)grid.y * n;
-    int spw = (int)(((long long)nstrips * rows) / 512);
+    static const int wg_target = [] { const char *e = getenv("DBA_BUILD_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int spw = (int)(((long long)nstrips * rows + wg_target - 1) / wg_target);
     spw = spw < 1 ? 1 : (spw > 16 ? 16 : spw);
     if (force == 2 && spw < 2) spw = 2;
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
