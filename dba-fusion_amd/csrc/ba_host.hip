@@ -120,7 +120,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   };
   dba_ba_layout L;
   memset(&L, 0, sizeof(L));
-  L.meta = take(sizeof(int) * 16);  // [8..15]: handshake flags of the solver's two workgroups (nothing else writes there)
+  L.meta = take(sizeof(int) * 32);  // [8..15]: handshake flags of the solver's two workgroups (nothing else writes there);
+                                    // [16..23]: the window solver's plan for this graph (launch_ba_solve's splan)
   const size_t o_gkey = take(sizeof(int) * (8 + 2 * (size_t)N));   // (right behind meta: dba_ba_workspace_init clears both)
   L.kx = take(sizeof(int) * (size_t)(Mmax > 0 ? Mmax : 1));
   const size_t o_fslot = take(sizeof(int) * (size_t)B);
@@ -485,8 +486,10 @@ static int ba_solve_stage(int N, int B, int ht, int wd, int t0, int t1, float lm
   const int rc = ba_plan(N, B, ht, wd, t0, t1, ws, ws_bytes, &plan);
   if (rc != DBA_OK) return rc;
   const int *fpose = graph_fpose ? graph_fpose : (graph_skyline ? plan.T.fpose : nullptr);
+  // (the plan kept in the workspace belongs to the workspace's own skyline table: a caller-supplied one is planned every time)
   const int rc2 = launch_ba_solve(plan.W.H, plan.W.b, fpose, 6 * plan.P, (double)lm, (double)ep, plan.W.dx, plan.T.meta,
-                                  plan.W.Lscratch, (hipStream_t)stream, nullptr, hint);
+                                  plan.W.Lscratch, (hipStream_t)stream, nullptr, hint,
+                                  (fpose && fpose == plan.T.fpose) ? plan.T.meta + 16 : nullptr);
   if (rc2 != DBA_OK) return rc2;
   // opt-in guard (dba_ba_set_solve_check / DBA_SOLVE_CHECK=1): the residual of the damped system at the solution, by a kernel of
   // its own behind the solver -- a solve that went wrong silently (the window solver's waves meet through flags, not barriers)

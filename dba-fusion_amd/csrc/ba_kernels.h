@@ -124,8 +124,10 @@ int ba_run_loop(float *poses, float *disps, const float *intrinsics, const float
 
 // damped float64 Cholesky solve of H x = b, one workgroup
 // fpose: optional [n/6] skyline of the system at pose granularity (see BaTables); null = measure it from H
+// splan: optional 8 ints of the workspace (meta + 16) where the window solver keeps what it derived from fpose -- window height, the
+// cut for two fronts -- between the solves of one graph; stage 0 clears it when it rebuilds the tables; null = derive every time
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream, long long *prof = nullptr, int hint = 0);
+                    double *Lscratch, hipStream_t stream, long long *prof = nullptr, int hint = 0, int *splan = nullptr);
 bool ba_solve_fits_lds(int n);
 bool ba_solve_tile_supported(int n);
 bool ba_solve_band_supported(int n);
@@ -146,7 +148,7 @@ void ws_words_reset(const int *meta);
 int *ws_eta_status(const int *meta);         // ... [4..6]: stage 0's eta report
 int ws_poll_eta(const int *meta, int *eta_rows, int *num_kx);
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof = nullptr);
+                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof = nullptr, int *splan = nullptr);
 size_t ba_solve_scratch_doubles(int n);
 constexpr int SOLVE_MAX_LDS_BYTES = 160 * 1024;
 

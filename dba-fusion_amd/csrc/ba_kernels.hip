@@ -142,6 +142,7 @@ __global__ __launch_bounds__(1024) void ba_prepare_kernel(const int64_t *__restr
     T.meta[1] = 0;
     T.meta[2] = (M > T.Mmax) ? 1 : 0;
     T.meta[7] = 0;  // (which skyline-solver variant solved this graph: not known yet)
+    T.meta[16] = 0; // (... nor what the window solver makes of the new skyline: launch_ba_solve's splan)
   }
   check_eta(min(M, T.Mmax));
   __syncthreads();

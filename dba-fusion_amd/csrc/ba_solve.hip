@@ -156,7 +156,7 @@ int ws_poll_eta(const int *meta, int *eta_rows, int *num_kx) {
 }
 
 int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                    double *Lscratch, hipStream_t stream, long long *prof, int hint) {
+                    double *Lscratch, hipStream_t stream, long long *prof, int hint, int *splan) {
   if (n <= 0) return DBA_OK;
   // n <= 174 (29 poses): the register-tile kernel (ba_solve_tile.hip).  Above that, up to n = 384, the skyline kernel
   // (ba_solve_band.hip) tries first; a system whose skyline does not fit one workgroup is left to this file's
@@ -182,7 +182,7 @@ int launch_ba_solve(const double *H, const double *b, const int *fpose, int n, d
     if (verdict) last_known.store(verdict, std::memory_order_relaxed);
     else verdict = last_known.load(std::memory_order_relaxed);
     const bool probe = slot && verdict == 2 && ((__atomic_add_fetch(slot + 1, 1, __ATOMIC_RELAXED)) & 1023) == 0;   // has the graph become banded again?
-    if (forced == 4 || verdict != 2 || probe) return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream);
+    if (forced == 4 || verdict != 2 || probe) return launch_ba_solve_wave(H, b, fpose, n, lm, ep, dx, meta, Lscratch, slot, stream, nullptr, splan);
   }
   int chained = 0;
   if (!prof && forced <= 1 && ba_solve_tile_supported(n)) return launch_ba_solve_tile(H, b, n, lm, ep, dx, meta, stream);

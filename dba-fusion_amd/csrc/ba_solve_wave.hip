@@ -44,6 +44,7 @@
 #include "ba_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "ba_solve_admit.h"
@@ -51,6 +52,7 @@
 
 namespace dba {
 
+constexpr int WV_PLAN_TAG = 0x5a10;   // splan[0] = tag | window height (0: not admitted)
 constexpr int WV_THREADS = 448;   // up to five factor waves, the substitution wave, the loader
 
 typedef double wv_d4 __attribute__((ext_vector_type(4)));
@@ -153,9 +155,10 @@ struct WvLayout {   // LDS, in doubles
   // taken out of it: flagC >= k + 1.  Ring of panels: the substitution wave has left step s behind (forward): flagF >= s + 1
   // (announced per tile column); tile columns it has finished on the way back: flagB; early tile columns back in LDS: flagR
   int *flagW, *flagE, *fail, *flagL, *flagC, *flagF, *flagB, *flagR;
-  __device__ WvLayout(double *smem, int n, int ring_e) {
+  // kfr > 0 (a front of the two-workgroup solve: WvFront): only the panels of the steps it eliminates are kept
+  __device__ WvLayout(double *smem, int n, int ring_e, int kfr = 0) {
     np = (n + 15) & ~15, S = np >> 2;
-    E = WRING ? ring_e : 0, K = S - E;
+    E = WRING ? ring_e : 0, K = kfr > 0 ? kfr : S - E;
     PAN = smem, ZST = PAN + (size_t)K * PD, BV = ZST + 4 * S;
     int *f = (int *)(BV + np + 80);   // (the right-hand side reaches 16 nt rows past the last tile column's first: np + 64 at most)
     flagW = f, flagE = f + 1;                                   // (flagW and up to five flagE: adjacent, 16-byte aligned)
@@ -202,6 +205,59 @@ __device__ __forceinline__ wv_d4 wv_load_tile(const double *__restrict__ H, int 
   return t;
 }
 
+// ---- Two fronts on two workgroups (round 6, systems of 50+ poses).  The chain is the cost of this kernel, and it is as long as the
+// system: cut the system into top | separator | bottom such that no top column reaches the bottom part (the separator is one band
+// wide), let workgroup 0 eliminate the top part and workgroup 1 the bottom part IN REVERSE ORDER (the same code on the mirrored
+// matrix) at the same time, add up what both leave of the separator block, solve that small dense system (redundantly, by the
+// same code), and back-substitute each part with the separator's unknowns given.  Each chain is (n - sep) / 8 steps instead of
+// n / 4.  tests/wave_solver_model.py::TwoFrontSolver is this arithmetic lane by lane; round 5 built it on ONE workgroup (eight /
+// ten waves sharing four SIMDs: slower than one front, scratch/ba_solve_wave_two_fronts.hip) -- two workgroups share nothing but
+// a hand-shake through global memory.
+struct WvFront {
+  int nloc;     // unknowns of the local system: the front's own part, then the separator
+  int sel;      // steps it eliminates (own part / 4)
+  int sep, a;   // separator unknowns, first local index of the separator (= 4 sel)
+  int mirror;   // 0: local index = original index; 1: local index i <-> original n4 - 1 - i
+  int n4;       // the system padded to a multiple of 4 (identity)
+};
+
+// a tile of the damped, padded LOCAL system of a front (accumulator layout, as wv_load_tile)
+__device__ __forceinline__ wv_d4 wv_load_tile_front(const double *__restrict__ H, int n, const WvFront F, int np, double lm, double ep,
+                                                    int TI, int TJ, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  wv_d4 t;
+  // a tile below the diagonal, inside the local system and inside the original one: the local element (row, col) is
+  // H[row n + col], or, mirrored, H[(n4 - 1 - col) n + (n4 - 1 - row)] -- affine either way: four loads off one address (the
+  // loader wave has a tile column's time for its tiles: with the general path below it set the fronts' pace)
+  if (TI != TJ && 16 * TI + 15 < F.nloc && (!F.mirror || 16 * TJ >= F.n4 - n)) {   // (wave-uniform)
+    const ptrdiff_t sr = F.mirror ? -1 : n, sc = F.mirror ? -(ptrdiff_t)n : 1;
+    const double *p = H + (F.mirror ? (ptrdiff_t)(F.n4 - 1) * (n + 1) : 0) + (16 * TI + lk) * sr + (16 * TJ + li) * sc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = p[4 * r * sr];
+    return t;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = 16 * TI + lk + 4 * r, col = 16 * TJ + li;
+    const int hi = max(row, col), lo = min(row, col);
+    // (always a load from inside the matrix, selected afterwards: loads inside branches would be waited for one by one, and the
+    // loader wave has a tile column's time for five tiles)
+    const int hic = min(hi, F.nloc - 1), loc = min(lo, F.nloc - 1);
+    const int oi = F.mirror ? F.n4 - 1 - loc : hic, oj = F.mirror ? F.n4 - 1 - hic : loc;   // original (row >= column)
+    const double hv = H[(size_t)min(oi, n - 1) * n + min(oj, n - 1)];
+    const double vin = (oi >= n) ? ((oi == oj) ? 1.0 : 0.0) : ((oi == oj) ? fma(lm, hv, hv) + ep : hv);
+    t[r] = (hi >= np) ? 0.0 : (hi >= F.nloc) ? ((row == col) ? 1.0 : 0.0) : vin;
+  }
+  return t;
+}
+// element (i >= j) of the damped, padded local system (the separator block's own entries, for its assembly)
+__device__ __forceinline__ double wv_front_elem(const double *__restrict__ H, int n, const WvFront F, double lm, double ep, int i, int j) {
+  const int oi = F.mirror ? F.n4 - 1 - j : i, oj = F.mirror ? F.n4 - 1 - i : j;
+  if (oi >= n) return (oi == oj) ? 1.0 : 0.0;
+  const double hv = H[(size_t)oi * n + oj];
+  return (oi == oj) ? fma(lm, hv, hv) + ep : hv;
+}
+
 // Row 0 of the inverse of a symmetric positive definite 4 x 4 block (lower triangle a b c / d e h / f g i j) by cofactors:
 // the six 2 x 2 minors of rows 2, 3 serve the four 3 x 3 cofactors of row 0; det = sum_j A[0][j] C[0][j].  35 operations, 13
 // deep (the 2 x 2-block route: 42, 26 deep), on the chain of every step.  A block that is not positive definite gives garbage
@@ -240,13 +296,17 @@ __device__ __forceinline__ void wv_pd_minors(double a, double b, double c, doubl
 // tile is finished takes the tile row that enters the window -- brought into LDS by the loader wave, so that no register of a
 // factor wave ever waits for global memory (a prefetch into registers made every loop trip wait: the compiler's copies of the
 // loop-carried registers cannot pass a pending load).
-template <int NT, bool RING>
+// FR: a front -- the local system of F, its first F.sel steps only; what is left of the separator block goes to `dump`
+// ([sep][sep], lower triangle, local orientation)
+template <int NT, bool RING, bool FR = false>
 __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane,
-                                     int wave, int ring_e, long long *__restrict__ prof) {
+                                     int wave, int ring_e, long long *__restrict__ prof, const WvFront F = WvFront{},
+                                     double *__restrict__ dump = nullptr) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  const WvLayout<NT, RING> L(smem, n, ring_e);
+  static_assert(!(FR && RING), "a front keeps its panels in LDS");
+  const WvLayout<NT, RING> L(smem, FR ? F.nloc : n, ring_e, FR ? ((F.sel + 4) & ~3) : 0);
   constexpr int PD = WvLayout<NT, RING>::PD;
   const int S = L.S, TB = S >> 2;
   const int li = lane & 15, lk = lane >> 4;
@@ -311,7 +371,10 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
   for (int j = 0; j < 4; j++) raw0n[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < NT; j++)
-    if (j <= wave) T[j] = wv_load_tile(H, n, L.np, lm, ep, wave, j, lane);
+    if (j <= wave) {
+      if constexpr (FR) T[j] = wv_load_tile_front(H, n, F, L.np, lm, ep, wave, j, lane);
+      else T[j] = wv_load_tile(H, n, L.np, lm, ep, wave, j, lane);
+    }
   extract(0, wave, T[0]);
   wv_order();
   if (wave == 0) read_pivot(0);
@@ -403,13 +466,29 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
       }
       wv_publish(L.flagE + R, s + 2);
     };
+    // (a front stops behind its step F.sel - 1, wherever in the tile column that is; the chain wave's verdict on the pivot blocks
+    // it has seen is due then)
+    auto front_done = [&](int sdone) {
+      if constexpr (FR) {
+        if (sdone + 1 == F.sel) {
+          if constexpr (R == 0) {
+            if (__ballot(!(pmin > 0.0)) != 0ull && lane == 0) *(wv_lds_vint *)L.fail = 1;
+          }
+          return true;
+        }
+      }
+      return false;
+    };
     mid(std::integral_constant<int, 0>{});
+    if (front_done(4 * tb)) return true;
     mid(std::integral_constant<int, 1>{});
+    if (front_done(4 * tb + 1)) return true;
     mid(std::integral_constant<int, 2>{});
+    if (front_done(4 * tb + 2)) return true;
     const int s = 4 * tb + 3;
     const bool more = s + 1 < S;
     if constexpr (R >= 1) {
-      if (!more) return;   // the very last step only concerns the pivot tile (and nobody reads a panel the way back may be replacing)
+      if (!more) return true;   // the very last step only concerns the pivot tile (and nobody reads a panel the way back may be replacing)
     }
     double av, uv[R + 1];
     const bool any = operands(s, col + 3 * PD, rc, av, uv);
@@ -451,18 +530,37 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
         wv_publish(L.flagC, tb + 1);             // ... the slot is free again)
       }
     }
+    return FR && (s + 1 == F.sel);   // (the rotation is complete: the window stands at the tile column of the front's first kept step)
   };
   int role = wave;
   for (int tb = 0; tb < TB; tb++) {
     if (role == 0) __builtin_amdgcn_s_setprio(3);
     else if (role == 1) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(0);
-    if (role == 0) run_column(tb, std::integral_constant<int, 0>{});
-    else if (role == 1) run_column(tb, std::integral_constant<int, 1>{});
-    else if (role == 2 || NT == 3) run_column(tb, std::integral_constant<int, 2>{});
-    else if (role == 3 || NT == 4) run_column(tb, std::integral_constant<int, (NT > 3 ? 3 : 2)>{});
-    else run_column(tb, std::integral_constant<int, NT - 1>{});
-    role = (role == 0) ? NT - 1 : role - 1;
+    bool done;
+    if (role == 0) done = run_column(tb, std::integral_constant<int, 0>{});
+    else if (role == 1) done = run_column(tb, std::integral_constant<int, 1>{});
+    else if (role == 2 || NT == 3) done = run_column(tb, std::integral_constant<int, 2>{});
+    else if (role == 3 || NT == 4) done = run_column(tb, std::integral_constant<int, (NT > 3 ? 3 : 2)>{});
+    else done = run_column(tb, std::integral_constant<int, NT - 1>{});
+    const bool column_over = !FR || !done || ((F.sel & 3) == 0);
+    if (column_over) role = (role == 0) ? NT - 1 : role - 1;
+    if (FR && done) break;
+  }
+  if constexpr (FR) {
+    // what is left of the separator block: this wave holds the tiles (role, 0 .. role) of the window, which stands at tile column
+    // F.sel >> 2; register r of tile j <-> local row 16 (tbw + role) + lk + 4 r, column 16 (tbw + j) + li
+    const int tbw = F.sel >> 2;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if (j <= role) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 16 * (tbw + role) + lk + 4 * r - F.a, c = 16 * (tbw + j) + li - F.a;
+          if (c >= 0 && c <= i && i < F.sep) dump[(size_t)i * F.sep + c] = T[j][r];
+        }
+      }
+    }
   }
   WPROF(wave < 3 ? 1 + wave : 5 + wave);   // (slots 1-3, then 8, 9; the substitution wave's are 4-6)
 }
@@ -481,16 +579,22 @@ __device__ void ba_solve_wave_factor(int n, double *__restrict__ smem, const dou
 //     has finished with when it announces flagB >= TB - (c + K / 4); it reads column c from iteration c + WNT on (its lanes'
 //     pending steps reach 4 WNT - 1 steps below the one it solves) and waits for flagR there: K / 4 - WNT >= 4 columns of
 //     slack, of which a column's round trip to L2 takes about two.
-template <int WNT, bool WRING>
+template <int WNT, bool WRING, bool FR = false>
 __device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const double *__restrict__ H, double lm, double ep, int lane,
-                                     int ring_e, const double *__restrict__ spill) {
-  const WvLayout<WNT, WRING> L(smem, n, ring_e);
+                                     int ring_e, const double *__restrict__ spill, const WvFront F = WvFront{}) {
+  const WvLayout<WNT, WRING> L(smem, FR ? F.nloc : n, ring_e, FR ? ((F.sel + 4) & ~3) : 0);
   constexpr int PD = WvLayout<WNT, WRING>::PD;
   const int TB = L.S >> 2;
   for (int k = 0; k + 1 < TB; k++) {   // (the rotation behind the last tile column brings nothing in)
+    if constexpr (FR) {
+      if (4 * k + 4 > F.sel) break;    // (a front's last rotation is the one behind its step F.sel - 1, if that ends a tile column)
+    }
     wv_d4 t[WNT];
 #pragma unroll
-    for (int j = 0; j < WNT; j++) t[j] = wv_load_tile(H, n, L.np, lm, ep, WNT + k, k + 1 + j, lane);
+    for (int j = 0; j < WNT; j++) {
+      if constexpr (FR) t[j] = wv_load_tile_front(H, n, F, L.np, lm, ep, WNT + k, k + 1 + j, lane);
+      else t[j] = wv_load_tile(H, n, L.np, lm, ep, WNT + k, k + 1 + j, lane);
+    }
     wv_await(L.flagC, k);
     if constexpr (WRING) {
       const int need = 4 * (k + WNT) + 5 - L.K;
@@ -524,25 +628,41 @@ __device__ void ba_solve_wave_loader(int n, double *__restrict__ smem, const dou
 // ---- wave 3: the right-hand side behind the factorisation (z = W b1, b2 -= R z), then the backward substitution,
 // right-looking: lane (slot, k) = (lane >> 2, lane & 3) accumulates v_s[k] = sum_i R_s[i][k] x[i] for the step s = slot
 // (mod 16) that still receives solved unknowns (a window spans at most 4 NT <= 16 steps); x1 = z - W v.
-template <int WNT, bool WRING>
-__device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, float *__restrict__ dx, int *__restrict__ meta,
+// PH 0: the whole solve.  A front (WvFront): PH 1 = the right-hand side behind its F.sel steps, then the separator rows' reduced
+// right-hand side -> rhs_out (global) and the verdict so far -> returned; PH 2 = the way back with the separator's unknowns given
+// (in BV[F.a ..], put there by the caller), then this front's own part of dx (mirrored for the bottom front)
+template <int WNT, bool WRING, int PH = 0>
+__device__ bool ba_solve_wave_subst(const double *__restrict__ bvec, int n, float *__restrict__ dx, int *__restrict__ meta,
                                     double *__restrict__ smem, int lane, int ring_e, double *__restrict__ spill,
-                                    long long *__restrict__ prof) {
+                                    long long *__restrict__ prof, const WvFront F = WvFront{}, double *__restrict__ rhs_out = nullptr,
+                                    bool bad_in = false) {
 #ifdef PROFILE_SOLVE
   long long tprev_ = wall_clock64();
 #endif
-  const WvLayout<WNT, WRING> L(smem, n, ring_e);
+  constexpr bool FR = PH != 0;
+  const WvLayout<WNT, WRING> L(smem, FR ? F.nloc : n, ring_e, FR ? ((F.sel + 4) & ~3) : 0);
   constexpr int PR = WvLayout<WNT, WRING>::PR, PD = WvLayout<WNT, WRING>::PD;
   constexpr int XR = PR > 64 ? PR - 64 : 0;   // rows of the window beyond one per lane (16 with five tile rows)
   static_assert(!WRING || PR >= 64, "the copy to scratch takes a panel row per lane");
   const int np = L.np, S = L.S;
   double *const PAN = L.PAN, *const ZST = L.ZST, *const BV = L.BV;
-  for (int i = lane; i < np + 80; i += 64) {
-    const double bv = bvec[min(i, n - 1)];
-    BV[i] = (i < n) ? bv : 0.0;
+  if constexpr (PH != 2) {
+  if constexpr (FR) {
+    for (int i = lane; i < np + 80; i += 64) {
+      const int oi = F.mirror ? F.n4 - 1 - i : i;   // (negative beyond the local system when mirrored: zero)
+      const bool in = i < F.nloc && oi >= 0 && oi < n;
+      const double bv = bvec[in ? oi : 0];
+      BV[i] = in ? bv : 0.0;
+    }
+  } else {
+    for (int i = lane; i < np + 80; i += 64) {
+      const double bv = bvec[min(i, n - 1)];
+      BV[i] = (i < n) ? bv : 0.0;
+    }
   }
   wv_order();
-  for (int s = 0; s < S; s++) {
+  const int Sfwd = FR ? F.sel : S;
+  for (int s = 0; s < Sfwd; s++) {
     const int tb = s >> 2, cl = 4 * (s & 3);
     const double *pan = L.pan(s);
     wv_await_all<WNT + 1>(L.flagW, s + 1);   // (flagW, flagE[0 .. WNT-1]: adjacent)
@@ -598,7 +718,13 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   }
-  const bool bad = *(wv_lds_vint *)L.fail != 0;
+  }   // PH != 2
+  if constexpr (PH == 1) {
+    wv_order();
+    for (int i = lane; i < F.sep; i += 64) rhs_out[i] = BV[F.a + i];
+    return *(wv_lds_vint *)L.fail != 0;
+  }
+  const bool bad = FR ? bad_in : (*(wv_lds_vint *)L.fail != 0);
   WPROF(4);
   {
     // Lane (slot, k).  Per step: the four v of the step's slot come by v_readlane; EVERY lane forms x1[k] for its own k (row k
@@ -635,11 +761,19 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
       o.w01 = *(const wv_d2 *)(wc + q * (PD + 16)), o.w23 = *(const wv_d2 *)(wc + q * (PD + 16) + 2);
       o.z = zc[4 * q];
       o.valid = (u >= 0) && ((u & 15) <= dmax);
+      if constexpr (FR) {   // steps the front did not eliminate: their unknowns are given (x = z - 0 v), their panels do not exist
+        const bool given = sp >= F.sel;
+        const double xg = BV[4 * max(sp, 0) + kk];
+        o.w01 = given ? wv_d2{0.0, 0.0} : o.w01, o.w23 = given ? wv_d2{0.0, 0.0} : o.w23;
+        o.z = given ? xg : o.z;
+        o.valid = o.valid && (slot + 16 * (u >> 4) < F.sel);
+      }
       const double *ra = o.valid ? rp : rsafe;
 #pragma unroll
       for (int m = 0; m < 4; m++) o.r[m] = ra[4 * m];
       if constexpr (FAR) {   // the same rows of x in the panel 16 steps down: 64 rows further into its window
         o.valid2 = (u >= 16) && ((u & 15) <= dmax - 16);
+        if constexpr (FR) o.valid2 = o.valid2 && (slot + 16 * (u >> 4) - 16 < F.sel);
         const double *rb = rp - 16 * PD + 256;
         if constexpr (WRING) rb += ((u >> 4) == seam_m) ? seam_jump : 0;   // (that panel lies below the seam, this one above)
         rb = o.valid2 ? rb : rsafe;
@@ -696,7 +830,10 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
     using Q3 = std::integral_constant<int, 3>;
-    auto wcol = [&](int c) { return L.pan(4 * c) + 4 * kk; };   // row k of W of the column's first step
+    auto wcol = [&](int c) {   // row k of W of the column's first step (a front: only panels it has; the others' W reads are discarded)
+      if constexpr (FR) return L.pan(min(4 * c, (F.sel - 1) & ~3)) + 4 * kk;
+      else return L.pan(4 * c) + 4 * kk;
+    };
     Ops oa, ob;
     const int TBs = S >> 2;   // (S is a multiple of 4: np is a multiple of 16)
     const double *wc = wcol(TBs - 1), *zc = ZST + 16 * (TBs - 1) + kk;
@@ -724,12 +861,26 @@ __device__ void ba_solve_wave_subst(const double *__restrict__ bvec, int n, floa
   __builtin_amdgcn_s_waitcnt(0xc07f);
   WPROF(5);
   // non-finite results count as failure too; failure => zero update (:1263-1266)
+  if constexpr (FR) {
+    // this front's part of dx: its own unknowns (the bottom front's mirrored back) and, from the top front, the separator's
+    bool nf = false;
+    const int nout = F.mirror ? F.a : F.nloc;
+    for (int j = lane; j < nout; j += 64) nf |= !isfinite(BV[j]);
+    const bool failed = bad || (__ballot(nf) != 0ull);
+    for (int j = lane; j < nout; j += 64) {
+      const int oj = F.mirror ? F.n4 - 1 - j : j;
+      if (oj >= 0 && oj < n) dx[oj] = failed ? 0.f : (float)BV[j];
+    }
+    return failed;
+  } else {
   bool nf = false;
   for (int j = lane; j < n; j += 64) nf |= !isfinite(BV[j]);
   const bool failed = bad || (__ballot(nf) != 0ull);
   for (int j = lane; j < n; j += 64) dx[j] = failed ? 0.f : (float)BV[j];
   if (lane == 0) meta[1] = failed ? 1 : 0;
   WPROF(6);
+  return failed;
+  }
 }
 
 // the kernel: NT + 2 waves (NT for the factorisation, one for the substitution, one that brings tile rows in; launched with six,
@@ -763,15 +914,215 @@ __device__ __forceinline__ void ba_solve_wave_run(const double *__restrict__ H, 
   } else if (part == NT + 1) ba_solve_wave_loader<NT, RING>(n, smem, H, lm, ep, lane, ring_e, spill);
 }
 
+// ---- the two-front solve: plan, hand-shake, separator, way back ---------------------------------------------------------------
+constexpr int WV_XCH_STRIDE = 5120;   // doubles per front in the exchange area: [0, 68^2) its separator block, [4700, 4768) its
+                                      // separator right-hand side, [4800] its verdict so far; then, per front, the assembled system
+
+// The cut (tests/wave_solver_model.py::split_plan, by every wave for itself): the system padded to n4 = n + (n & 2) unknowns; the
+// smallest separator (a multiple of 4) such that no column of the top part reaches the bottom part, the block [a, a + sep) lies
+// inside the window a front stops in, and the bottom part -- eliminated in REVERSE order -- passes the window test too.
+// Returns 0 or the window height NT in 3..5 both fronts can use; a_t, sep, a_b through the pointers.
+__device__ __forceinline__ int wv_front_plan(const int *__restrict__ fpose, int n, int lane, int nt_min, int *a_t, int *sep_o, int *a_b) {
+  const int P = n / 6;
+  if (!fpose || P > 64 || n != 6 * P || nt_min < 3) return 0;
+  int g = (lane < P) ? fpose[lane] : 0x7fffffff;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_down(g, off, 64);
+    if (lane + off < 64) g = min(g, o);
+  }
+  int last = lane;
+  for (int p = 0; p < P; p++) {
+    const int gp = __builtin_amdgcn_readlane(g, p);
+    if (gp <= lane) last = max(last, p);
+  }
+  const int n4 = n + (n & 2);
+  for (int nt = nt_min; nt <= 5; nt++) {
+    const int rows = 16 * nt;
+    for (int sep = 4; sep <= min(rows - 12, 64); sep += 4) {   // (64: the separator's own dense solve runs in the 64-row window)
+      const int at = ((n4 - sep) / 2) & ~3, ab = n4 - sep - at;
+      if (at < 16 || ab < 16) break;
+      const int qt = (at - 1) / 6;
+      if (6 * __shfl(last, qt, 64) + 5 >= at + sep) continue;               // a top column reaches past the separator
+      if (4 * ((at / 4) % 4) + sep > rows || 4 * ((ab / 4) % 4) + sep > rows) continue;
+      bool ok = true;
+      for (int base = 0; base < ab / 4; base += 64) {                        // the bottom part's own window test, reversed order
+        const int sb = base + lane;
+        const int omin = n4 - 1 - (4 * sb + 3);
+        const int gq = __shfl(g, min(max(omin, 0) / 6, P - 1), 64);
+        const int first = (omin < n) ? 6 * gq : omin;
+        ok = ok && (sb >= ab / 4 || (n4 - 1 - first) <= 16 * (sb >> 2) + rows - 1);
+      }
+      // ... and the top part's (the whole system need not have passed at this height)
+      for (int base = 0; base < at / 4; base += 64) {
+        const int st = base + lane, c = 4 * st;
+        const int q3 = min(min(c + 3, n - 1) / 6, P - 1);
+        const int lastrow = min(6 * __shfl(last, q3, 64) + 5, at + sep - 1);
+        ok = ok && (st >= at / 4 || lastrow <= 16 * (st >> 2) + rows - 1);
+      }
+      if (__ballot(!ok) == 0ull) {
+        *a_t = at, *sep_o = sep, *a_b = ab;
+        return nt;
+      }
+    }
+  }
+  return 0;
+}
+
+// LDS of a front, in doubles: its own layout, the separator's solve from its (then idle) ring slot on, the separator's dx / verdict
+__device__ __host__ __forceinline__ size_t wv_front_lds_doubles(int nloc, int sel, int nt) {
+  const int np = (nloc + 15) & ~15, S = np >> 2, K = (sel + 4) & ~3;
+  const size_t front = (size_t)K * (16 * nt * 4) + (size_t)S * 4 + np + 88;   // (without its ring slot)
+  return front + wv_lds_doubles_k(64, 4, 16) + 64;
+}
+
+template <int NT>
+__device__ void ba_solve_wave_run_front(const double *__restrict__ H, const double *__restrict__ bvec, int n, double lm, double ep,
+                                        float *__restrict__ dx, int *__restrict__ meta, double *__restrict__ smem, int lane, int wave,
+                                        const WvFront F, int front, double *__restrict__ xch, unsigned gen) {
+  const WvLayout<NT, false> L(smem, F.nloc, 0, (F.sel + 4) & ~3);
+  double *const own = xch + (size_t)front * WV_XCH_STRIDE, *const oth = xch + (size_t)(1 - front) * WV_XCH_STRIDE;
+  double *const ssep = xch + (size_t)(2 + front) * WV_XCH_STRIDE, *const bsep = ssep + 68 * 68;
+  int *const xflag = meta + 8;
+  double *const smem2 = L.RING;                                   // the separator's solve: from the front's ring slot on
+  double *const tail = smem2 + wv_lds_doubles_k(64, 4, 16);       // [0, 32): its dx (float), [32]: its meta (ints), [40]: this front's words
+  float *const dx_sep = reinterpret_cast<float *>(tail);
+  int *const meta_sep = reinterpret_cast<int *>(tail + 32);
+  int *const words = reinterpret_cast<int *>(tail + 40);         // [0] this front's verdict after its steps, [1] the partner did not show up
+#ifdef WV_FRONT_PROF   // scratch builds: wall-clock stamps of the phases, per front (10 ns ticks), behind the exchange area
+  long long *const stamps = reinterpret_cast<long long *>(xch + 4 * (size_t)WV_XCH_STRIDE) + 16 * front;
+#define FSTAMP(k) do { if (threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(k)
+#endif
+  FSTAMP(0);
+  if (threadIdx.x < 16) L.flagW[threadIdx.x] = 0;
+  if (threadIdx.x < 8) meta_sep[threadIdx.x] = 0, words[threadIdx.x] = 0;
+  __syncthreads();
+  int part = wave;
+  if constexpr (NT == 5) part = wave == 2 ? 3 : wave == 3 ? 4 : wave == 4 ? 2 : wave == 5 ? 6 : wave == 6 ? 5 : wave;
+  if (part < NT) ba_solve_wave_factor<NT, false, true>(n, smem, H, lm, ep, lane, part, 0, nullptr, F, own);
+  else if (part == NT) {
+    const bool bad = ba_solve_wave_subst<NT, false, 1>(bvec, n, dx, meta, smem, lane, 0, nullptr, nullptr, F, own + 4700);
+    if (lane == 0) words[0] = bad ? 1 : 0, own[4800] = bad ? 1.0 : 0.0;
+  } else if (part == NT + 1) ba_solve_wave_loader<NT, false, true>(n, smem, H, lm, ep, lane, 0, nullptr, F);
+  __builtin_amdgcn_s_setprio(0);
+  // ---- both fronts have left their share of the separator block in the exchange area: meet
+  FSTAMP(1);
+  __threadfence();
+  __syncthreads();
+  FSTAMP(2);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(xflag + front, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(xflag + (1 - front), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int)gen) {
+      if (wall_clock64() - t0 > 20000000ll) {   // 0.2 s: the partner workgroup never came (both then give the solve up: zero update)
+        words[1] = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  FSTAMP(3);
+  const bool lost = words[1] != 0;
+  // ---- the separator's system in this front's orientation: own + partner (mirrored) - the block's own entries, which both carry
+  {
+    const int sep = F.sep;
+    // (every thread's entries at once: all their loads in flight together -- one entry after the other this was 5 us)
+    constexpr int PER = (64 * 64 + WV_THREADS - 1) / WV_THREADS;
+    double va[PER], vb[PER], vc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int idx = min((int)threadIdx.x + k * WV_THREADS, sep * sep - 1);
+      const int i = idx / sep, j = idx - i * sep;
+      const int il = max(i, j), jl = min(i, j);   // (the upper triangle's threads load the mirrored entry: discarded)
+      va[k] = own[il * sep + jl];
+      vb[k] = oth[(sep - 1 - jl) * sep + (sep - 1 - il)];
+      vc[k] = wv_front_elem(H, n, F, lm, ep, F.a + il, F.a + jl);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int idx = (int)threadIdx.x + k * WV_THREADS;
+      const int i = idx / sep, j = idx - i * sep;
+      if (idx < sep * sep && j <= i) ssep[idx] = lost ? ((i == j) ? 1.0 : 0.0) : (va[k] + vb[k]) - vc[k];
+    }
+    for (int i = threadIdx.x; i < sep; i += blockDim.x) {
+      const int oi = F.mirror ? F.n4 - 1 - (F.a + i) : F.a + i;
+      const double b0 = (oi >= 0 && oi < n) ? bvec[oi] : 0.0;
+      bsep[i] = lost ? 0.0 : (own + 4700)[i] + (oth + 4700)[sep - 1 - i] - b0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  FSTAMP(4);
+  // ... solved by the one-front code in the 64-row window (dense, up to 64 unknowns), by both workgroups alike
+  ba_solve_wave_run<4, false>(ssep, bsep, F.sep, 0.0, 0.0, dx_sep, meta_sep, smem2, lane, wave, 0, nullptr, nullptr);
+  __syncthreads();
+  FSTAMP(5);
+  if (part != NT) return;
+  // ---- the way back, the separator's unknowns given
+  {
+    const WvLayout<4, false> Ls(smem2, F.sep, 0);
+    for (int i = lane; i < F.sep; i += 64) L.BV[F.a + i] = Ls.BV[i];
+    wv_order();
+  }
+  const bool bad = lost || words[0] != 0 || oth[4800] != 0.0 || meta_sep[1] != 0;
+  const bool failed = ba_solve_wave_subst<NT, false, 2>(bvec, n, dx, meta, smem, lane, 0, nullptr, nullptr, F, nullptr, bad);
+#ifdef WV_FRONT_PROF
+  if (lane == 0) stamps[6] = wall_clock64();
+#endif
+  // one verdict for both parts of dx
+  bool all_failed = failed;
+  if (lane == 0) {
+    __threadfence();
+    const int mine = (int)gen | (failed ? 0x10000000 : 0);
+    __hip_atomic_store(xflag + 4 + front, mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int theirs;
+    for (;;) {
+      theirs = __hip_atomic_load(xflag + 4 + (1 - front), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if ((theirs & ~0x10000000) == (int)gen) break;
+      if (lost || wall_clock64() - t0 > 20000000ll) {
+        theirs = (int)gen | 0x10000000;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    all_failed = failed || (theirs & 0x10000000) != 0;
+  }
+  all_failed = __builtin_amdgcn_readfirstlane(all_failed ? 1 : 0) != 0;
+  if (all_failed && !failed) {   // the partner's part is zero: so is this one
+    const int nout = F.mirror ? F.a : F.nloc;
+    for (int j = lane; j < nout; j += 64) {
+      const int oj = F.mirror ? F.n4 - 1 - j : j;
+      if (oj >= 0 && oj < n) dx[oj] = 0.f;
+    }
+  }
+  if (lane == 0) meta[1] = all_failed ? 1 : 0;
+#ifdef WV_FRONT_PROF
+  if (lane == 0) stamps[7] = wall_clock64();
+#endif
+}
+
 template <bool GENERAL_IN_LDS>
 __global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
                                                             const int *__restrict__ fpose, int n, double lm, double ep,
                                                             float *__restrict__ dx, int *__restrict__ meta,
                                                             double *__restrict__ Lglobal, int *__restrict__ verdict, int max_nt,
-                                                            int ring_e4, int ring_e5, long long *__restrict__ prof) {
+                                                            int ring_e4, int ring_e5, long long *__restrict__ prof,
+                                                            int *__restrict__ splan) {
   extern __shared__ __attribute__((aligned(16))) double wv_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nt = ba_solve_wave_admits(fpose, n, lane, max_nt);
+  // the window height this graph's skyline admits: derived once per graph (stage 0 clears the record when the graph changes)
+  const int tag = splan ? __builtin_amdgcn_readfirstlane(splan[0]) : 0;
+  int nt;
+  if ((tag & ~7) == WV_PLAN_TAG) nt = tag & 7;
+  else {
+    nt = ba_solve_wave_admits(fpose, n, lane, max_nt);
+    if (splan && threadIdx.x == 0) splan[1] = -1, splan[0] = WV_PLAN_TAG | nt;   // ([1] = -1: the cut for two fronts is not known)
+  }
   if (threadIdx.x == 0) {
     meta[3] = 1;   // (solved either way: a kernel queued behind with `skip_if_solved` returns at once)
     if (verdict) __hip_atomic_store(verdict, nt ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -783,6 +1134,61 @@ __global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_kernel(const double 
   else if (nt == 5 && ring_e5 == 0) ba_solve_wave_run<5, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, prof);
   else if (nt == 5) ba_solve_wave_run<5, true>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, ring_e5, Lglobal, prof);
   else ba_solve_general_body<GENERAL_IN_LDS>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
+}
+
+// Two workgroups: workgroup f eliminates front f when the cut exists (wv_front_plan) and a front fits LDS; otherwise workgroup 0
+// solves the whole system as the one-front kernel does and workgroup 1 leaves.  Only systems the general fall-back keeps in global
+// scratch get here (n > 199), so one instantiation serves.
+__global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_fronts_kernel(const double *__restrict__ H, const double *__restrict__ bvec,
+                                                                   const int *__restrict__ fpose, int n, double lm, double ep,
+                                                                   float *__restrict__ dx, int *__restrict__ meta,
+                                                                   double *__restrict__ Lglobal, int *__restrict__ verdict, int max_nt,
+                                                                   int ring_e4, int ring_e5, unsigned gen, double *__restrict__ xch,
+                                                                   int *__restrict__ splan) {
+  extern __shared__ __attribute__((aligned(16))) double wv_smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef WV_FRONT_PROF
+  if (threadIdx.x == 0) (reinterpret_cast<long long *>(xch + 4 * (size_t)WV_XCH_STRIDE) + 16 * blockIdx.x)[8] = wall_clock64();
+#endif
+  int nt, ntf, at = 0, sep = 0, ab = 0;
+  const int tag = splan ? __builtin_amdgcn_readfirstlane(splan[0]) : 0;
+  const int tag1 = splan ? __builtin_amdgcn_readfirstlane(splan[1]) : -1;
+  if ((tag & ~7) == WV_PLAN_TAG && tag1 >= 0) {   // what an earlier solve of this graph found
+    nt = tag & 7, ntf = tag1;
+    at = __builtin_amdgcn_readfirstlane(splan[2]), sep = __builtin_amdgcn_readfirstlane(splan[3]);
+    ab = __builtin_amdgcn_readfirstlane(splan[4]);
+  } else {
+    nt = ba_solve_wave_admits(fpose, n, lane, max_nt);
+    ntf = nt ? wv_front_plan(fpose, n, lane, nt, &at, &sep, &ab) : 0;
+    if (ntf && wv_front_lds_doubles(max(at, ab) + sep, max(at, ab) / 4, ntf) * sizeof(double) > (size_t)SOLVE_MAX_LDS_BYTES) ntf = 0;
+    if (splan && blockIdx.x == 0 && threadIdx.x == 0) {
+      splan[2] = at, splan[3] = sep, splan[4] = ab, splan[1] = ntf;
+      __threadfence();
+      splan[0] = WV_PLAN_TAG | nt;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    meta[3] = 1;
+    meta[4] = ntf ? 1 : 0, meta[5] = at / 4, meta[6] = ab / 4;   // (as the skyline kernel reports its split: taken?, top / bottom steps)
+    if (verdict) __hip_atomic_store(verdict, nt ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (ntf) {
+    const int front = (int)blockIdx.x;
+    WvFront F;
+    F.sep = sep, F.n4 = n + (n & 2), F.mirror = front;
+    F.a = front ? ab : at, F.sel = F.a / 4, F.nloc = F.a + sep;
+    if (ntf == 3) ba_solve_wave_run_front<3>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
+    else if (ntf == 4) ba_solve_wave_run_front<4>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
+    else ba_solve_wave_run_front<5>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  if (nt == 3) ba_solve_wave_run<3, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, nullptr);
+  else if (nt == 4 && ring_e4 == 0) ba_solve_wave_run<4, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, nullptr);
+  else if (nt == 4) ba_solve_wave_run<4, true>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, ring_e4, Lglobal, nullptr);
+  else if (nt == 5 && ring_e5 == 0) ba_solve_wave_run<5, false>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, 0, nullptr, nullptr);
+  else if (nt == 5) ba_solve_wave_run<5, true>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, ring_e5, Lglobal, nullptr);
+  else ba_solve_general_body<false>(H, bvec, n, lm, ep, dx, meta, Lglobal, nullptr, wv_smem);
 }
 
 int ba_solve_wave_max_nt(int n) {   // the tallest window whose panel store (or a ring of it) fits LDS for n unknowns (0: none)
@@ -797,7 +1203,7 @@ bool ba_solve_wave_supported(int n) { return ba_solve_wave_max_nt(n) != 0; }
 
 // Lscratch: the workspace's packed-triangle scratch (needed by the fall-back when the system does not fit LDS: n > 199)
 int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int n, double lm, double ep, float *dx, int *meta,
-                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof) {
+                         double *Lscratch, int *verdict, hipStream_t stream, long long *prof, int *splan) {
   int max_nt = ba_solve_wave_max_nt(n);
   if (!max_nt || !fpose) return DBA_ERR_UNSUPPORTED;
   const int S = ((n + 15) & ~15) >> 2;
@@ -819,13 +1225,33 @@ int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int
   size_t wave_lds = 0;
   for (int nt = 3; nt <= max_nt; nt++) wave_lds = std::max(wave_lds, wv_lds_doubles_k(n, nt, S - ring_e[nt]) * sizeof(double));
   const size_t gen_lds = solve_packed_bytes(n) + solve_small_bytes(n);
+  // two fronts on two workgroups: systems of 50 poses and more (DBA_SOLVE_FRONTS=0 keeps one front, =1 also tries it from 34 poses;
+  // the exchange area lies behind the early panels' room in the scratch)
+  static const int fronts_mode = [] { const char *e = getenv("DBA_SOLVE_FRONTS"); return e ? atoi(e) : -1; }();
+  const int fronts_min_n = fronts_mode == 1 ? 204 : 270;
+  const size_t xch_off = 16384;   // doubles: past the largest ring's early panels (40 x 320)
+  if (fronts_mode != 0 && !prof && n >= fronts_min_n && gen_lds > (size_t)SOLVE_MAX_LDS_BYTES && Lscratch &&
+      scratch >= xch_off + 4 * (size_t)WV_XCH_STRIDE) {
+    static DeviceOnce attr2_once;
+    if (attr2_once.needed()) {
+      DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_solve_wave_fronts_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
+      attr2_once.done();
+    }
+    static std::atomic<unsigned> generation{1};
+    const unsigned gen = (generation.fetch_add(1) & 0x0fffffffu) | 0x20000000u;
+    hipLaunchKernelGGL(ba_solve_wave_fronts_kernel, dim3(2), dim3(WV_THREADS), (size_t)SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
+                       dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], gen, Lscratch + xch_off, splan);
+    DBA_LAUNCH_CHECK();
+    return DBA_OK;
+  }
   if (gen_lds <= (size_t)SOLVE_MAX_LDS_BYTES) {
     hipLaunchKernelGGL(ba_solve_wave_kernel<true>, dim3(1), dim3(WV_THREADS), std::max(wave_lds, gen_lds), stream, H, b, fpose, n, lm,
-                       ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof);
+                       ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof, splan);
   } else {
     if (!Lscratch) return DBA_ERR_WORKSPACE;
     hipLaunchKernelGGL(ba_solve_wave_kernel<false>, dim3(1), dim3(WV_THREADS), std::max(wave_lds, solve_small_bytes(n)), stream, H, b,
-                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof);
+                       fpose, n, lm, ep, dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], prof, splan);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

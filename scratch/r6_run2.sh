@@ -1,7 +1,7 @@
 #!/bin/bash
 OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-for w in 25_96 64_512; do
+for w in 64_512; do
 rm -rf $OUT/r6_trace_x
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r6_trace_x -- python $REPO/bench.py --window $w --steps 30 --warmup 6 --no-cpu-baseline --no-extras > $OUT/r6_trace_x.log 2>&1
 cp $(ls -t $(find $OUT/r6_trace_x -name "*kernel_stats.csv") | head -1) $OUT/r6_kernel_stats_${w}_b.csv

@@ -54,15 +54,15 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
   // the device reads the lower triangle only: poison the upper one
   std::vector<double> Hl = H; for (int i = 0; i < n; i++) for (int j = i+1; j < n; j++) Hl[i*n+j] = 1e300;
   double *dH, *db; float* dx; int* meta; int *dfp;
-  hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 64); hipMalloc(&dfp, P*4);
+  hipMalloc(&dH, n*n*8); hipMalloc(&db, n*8); hipMalloc(&dx, n*4); hipMalloc(&meta, 256); hipMalloc(&dfp, P*4);
   hipMemcpy(dH, Hl.data(), n*n*8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n*8, hipMemcpyHostToDevice);
-  hipMemcpy(dfp, fpose.data(), P*4, hipMemcpyHostToDevice); hipMemset(meta, 0, 64); hipMemset(dx, 0xff, n*4);
-  int rc = dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr);
+  hipMemcpy(dfp, fpose.data(), P*4, hipMemcpyHostToDevice); hipMemset(meta, 0, 256); hipMemset(dx, 0xff, n*4);
+  int rc = dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr, getenv("HARNESS_NO_PLAN_CACHE") ? nullptr : meta + 16);
   hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess || rc) { printf("P=%d launch error %s rc=%d\n", P, hipGetErrorString(e), rc); return 1; }
   std::vector<float> x(n); int hm[8]; hipMemcpy(x.data(), dx, n*4, hipMemcpyDeviceToHost); hipMemcpy(hm, meta, 32, hipMemcpyDeviceToHost);
 
   double maxe = 0, maxx = 0; for (int i = 0; i < n; i++) { double r = ok ? xr[i] : 0.0; maxe = fmax(maxe, fabs(x[i]-r)); maxx = fmax(maxx, fabs(r)); }
-  printf("wave P=%2d n=%3d w=%d extra=(%d,%d) spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e %s\n", P, n, w, ex_p, ex_q, spd, ok, hm[1], maxx, maxe, (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
+  printf("wave P=%2d n=%3d w=%d extra=(%d,%d) spd=%d host_ok=%d dev_failed=%d max|x|=%.3e max err=%.3e fronts=(%d,%d,%d) %s\n", P, n, w, ex_p, ex_q, spd, ok, hm[1], maxx, maxe, hm[4], hm[5], hm[6], (maxe <= 2e-7*fmax(maxx,1e-30)+1e-30 && hm[1] == !ok) ? "OK" : "MISMATCH");
   if (getenv("HARNESS_DUMP")) { for (int i = 0; i < n; i++) if (fabs(x[i] - (ok ? xr[i] : 0.0)) > 1e-6) printf("    x[%3d] dev % .6e ref % .6e\n", i, x[i], ok ? xr[i] : 0.0); }
   if (timeit) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -71,9 +71,16 @@ int run(int P, int w, bool spd, bool timeit, int ex_p = -1, int ex_q = -1) {
     for (int mode = 0; mode < 2; mode++) {
       if (mode == 1 && !dba::ba_solve_tile_supported(n)) continue;
       hipEventRecord(e0);
-      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
+      for (int it = 0; it < 200; it++) { if (mode == 0) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, nullptr, getenv("HARNESS_NO_PLAN_CACHE") ? nullptr : meta + 16); else dba::launch_ba_solve_tile(dH, db, n, lm, ep, dx, meta, 0); }
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("   %s: %.2f us per solve\n", mode == 0 ? "wave" : "tile", ms*1000/200);
+      if (mode == 0) {
+#ifdef WV_FRONT_PROF
+  if (hm[4]) { long long st[32]; hipMemcpy(st, gscr + 16384 + 4 * 5120, sizeof(st), hipMemcpyDeviceToHost);
+    for (int f = 0; f < 2; f++) { long long *t = st + 16 * f; printf("   front %d (kernel entry -> plan done %.2f us; us from there; start offset %.2f): steps done %.2f | fence+barrier %.2f | met %.2f | assembled %.2f | separator solved %.2f | back %.2f | verdict %.2f\n", f, (t[0] - t[8]) * 0.01, (t[0] - st[0]) * 0.01, (t[1]-t[0])*0.01, (t[2]-t[0])*0.01, (t[3]-t[0])*0.01, (t[4]-t[0])*0.01, (t[5]-t[0])*0.01, (t[6]-t[0])*0.01, (t[7]-t[0])*0.01); } }
+#endif
+      }
+
       if (mode == 0 && getenv("HARNESS_STEPS_OLD")) { long long hp[16]; hipMemcpy(hp, g_wprof, 128, hipMemcpyDeviceToHost); const double S_ = ((n + 15) / 16 * 4) * 200.0; printf("   wave step phases, shader cycles per step (drained at every mark): sync %.0f reads %.0f inverse %.0f operands+mfma %.0f W+rhs %.0f rotate %.0f extract %.0f\n", hp[8]/S_, hp[9]/S_, hp[10]/S_, hp[11]/S_, hp[12]/S_, hp[13]/S_, hp[14]/S_); }
       if (mode == 0) { for (int it = 0; it < 200; it++) dba::launch_ba_solve_wave(dH, db, dfp, n, lm, ep, dx, meta, gscr, nullptr, 0, g_wprof); (void)hipDeviceSynchronize(); long long hp[32]; hipMemcpy(hp, g_wprof, 256, hipMemcpyDeviceToHost); auto u = [&](int i) { return hp[i]/200.0/100; };
 #ifdef TWO_FRONTS

@@ -260,7 +260,9 @@ class _SkylineSolver:
                                                  ctypes.c_void_p(ws.data_ptr()), self.nbytes, stream), "dba_ba_solve_skyline")
         torch.cuda.synchronize()
         dx = ws[lay.dx:lay.dx + 4 * n].view(torch.float32).cpu().numpy().copy()
-        return dx, int(ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()[1])
+        meta = ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()
+        self.fronts = (int(meta[4]), 4 * int(meta[5]), 4 * int(meta[6]))   # two fronts taken?, top / bottom unknowns (window kernel, round 6)
+        return dx, int(meta[1])
 
 
 def _ref(H, b, lm=1e-4, ep=0.1):
@@ -323,6 +325,11 @@ def test_window_kernel_with_the_ring_of_panels_takes_wide_bands_up_to_64_poses(P
     assert failed == 0
     np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
     assert S.lib.dba_ba_solver_verdict(*S.dims, ctypes.c_void_p(S.ws.data_ptr()), S.nbytes) == 1
+    # from 46 poses on the system is cut in two: top part | separator | bottom part, a workgroup per part, each chain half as long
+    if 6 * P >= 276 and os.environ.get("DBA_SOLVE_FRONTS") != "0":
+        taken, top, bottom = S.fronts
+        n4 = 6 * P + ((6 * P) & 2)
+        assert taken == 1 and min(top, bottom) >= 96 and abs(top - bottom) <= 8 and 6 * (w - 1) <= n4 - top - bottom <= 64, S.fronts
     first = dx
     for rep in range(40):
         dx, failed = S.solve(H, b, fpose)
@@ -433,3 +440,31 @@ def test_opt_in_residual_check_turns_a_wrong_solve_into_a_zero_update():
     torch.cuda.synchronize()
     assert int(ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()[1]) == 1
     assert not ws[lay.dx:lay.dx + 4 * n].view(torch.float32).any()
+
+
+@pytest.mark.parametrize("P,w", [(46, 4), (50, 3), (63, 4), (64, 4), (63, 8), (55, 6)])
+def test_two_fronts_on_two_workgroups_equal_one_front(P, w):
+    """round 6: systems of 46+ poses are cut into top | separator | bottom; workgroup 0 eliminates the top part, workgroup 1 the
+    bottom part in reverse order (the same code on the mirrored matrix), both add up what they leave of the separator block, solve
+    it redundantly and back-substitute their part.  Against the host Cholesky, through the workspace's own skyline path too (the
+    plan is then kept in the workspace between the solves of one graph), alternating systems, and a failing pivot in either part
+    or in the separator gives a zero update of ALL unknowns"""
+    rng = np.random.default_rng(5 * P + w)
+    S = _SkylineSolver(P)
+    systems = [_pose_system(rng, P, w) for _ in range(2)]
+    for rep in range(6):
+        H, b, fpose = systems[rep & 1]
+        dx, failed = S.solve(H, b, fpose)
+        ref = _ref(H, b)
+        assert failed == 0 and S.fronts[0] == 1, (rep, S.fronts)
+        np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+    n = 6 * P
+    top, bottom = S.fronts[1], S.fronts[2]
+    for where in (5, top - 3, top + 2, n - bottom + 1, n - 4, n // 2):
+        H, b, fpose = systems[0]
+        Hb = H.copy()
+        Hb[where, where] = -1.0
+        dx, failed = S.solve(Hb, b, fpose)
+        assert failed == 1 and np.all(dx == 0.0), where
+    dx, failed = S.solve(*systems[0])
+    assert failed == 0

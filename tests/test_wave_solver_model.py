@@ -290,3 +290,19 @@ def test_backward_address_recurrence_with_the_far_accumulator(S, E):
         idx = idx - np.where(slot == ((sp - 1) & 15), 16 * (PD - 15), 16)
         if E:
             idx = idx + np.where(u == 16 * ((E - slot + 15) >> 4) - 1, K * PD, 0)
+
+
+def test_two_front_plan_of_the_literal_64_512_skyline():
+    """what the two-workgroup kernel (csrc/ba_solve_wave.hip::wv_front_plan) must find for BASELINE configs[3]: 41 steps per front
+    around a separator of 52 unknowns in the 80-row window; the two-front arithmetic solves it"""
+    pairs = _skyline_64_512()
+    H, b, fpose = _system(63, 0, 5, extra=pairs)
+    wsm.set_window(5)
+    try:
+        assert wsm.split_plan(fpose, 378) == (164, 52, 164)
+        ref = np.linalg.solve(H + np.diag(0.1 + 1e-4 * np.diag(H)), b)
+        x, failed = wsm.TwoFrontSolver(np.tril(H), b, 1e-4, 0.1, fpose).solve()
+        assert not failed
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    finally:
+        wsm.set_window(3)
