@@ -121,7 +121,8 @@ int ba_plan(int N, int B, int ht, int wd, int t0, int t1, void *ws, size_t ws_by
   dba_ba_layout L;
   memset(&L, 0, sizeof(L));
   L.meta = take(sizeof(int) * 32);  // [8..15]: handshake flags of the solver's two workgroups (nothing else writes there);
-                                    // [16..23]: the window solver's plan for this graph (launch_ba_solve's splan)
+                                    // [16..23]: the window solver's plan for this graph (launch_ba_solve's splan);
+                                    // [24..27]: launch counters / generation numbers of its two-workgroup form, [28..31]: the skyline kernel's
   const size_t o_gkey = take(sizeof(int) * (8 + 2 * (size_t)N));   // (right behind meta: dba_ba_workspace_init clears both)
   L.kx = take(sizeof(int) * (size_t)(Mmax > 0 ? Mmax : 1));
   const size_t o_fslot = take(sizeof(int) * (size_t)B);
@@ -671,10 +672,12 @@ struct BacoreStage {
   int seq = 0;
 };
 std::mutex g_stage_mu;
-std::unordered_map<const void *, BacoreStage> &stage_map() {
-  static auto &m = *new std::unordered_map<const void *, BacoreStage>;
+typedef std::unordered_map<const void *, BacoreStage> BacoreStageMap;
+BacoreStageMap *stage_map_ptr() {   // (never destroyed: calls may still arrive at exit)
+  static BacoreStageMap *m = new BacoreStageMap;
   return m;
 }
+#define stage_map() (*stage_map_ptr())
 int *stage_flag(const BacoreStage &st) { return reinterpret_cast<int *>(st.host + st.doubles + 8); }
 }  // namespace
 

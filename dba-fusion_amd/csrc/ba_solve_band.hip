@@ -75,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
                                                                 const int *__restrict__ fpose, int ng,
                                                                 double lm, double ep, float *__restrict__ dx,
                                                                 int *__restrict__ meta, double *__restrict__ G,
-                                                                int gcap, unsigned gen, int nofb
+                                                                int gcap, int nofb
 #ifdef PROFILE_SOLVE
                                                                    , long long *__restrict__ prof
 #endif
@@ -105,6 +105,14 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
   const int wave = tid >> 6, lane = tid & 63;
   constexpr bool SPLIT = (SLOTS == 1 && !GP);
   const int role = SPLIT ? (int)blockIdx.x : 0;  // 1: the workgroup of the bottom block (only launched with SPLIT)
+  // The hand-shake words carry a per-launch generation number, counted ON THE DEVICE: a counter per workgroup in the workspace
+  // (meta[28], meta[29]; the number itself in meta[30 + workgroup], read back behind the barriers below) -- a launch replayed from
+  // a hipGraph gets a new number like any other (as the window solver's two-workgroup form does with meta[24..27])
+  if (SPLIT && gridDim.x == 2 && tid == 0) {   // (one workgroup: no hand-shake)
+    const unsigned g = (unsigned)atomicAdd(meta + 28 + role, 1) + 1u;
+    __hip_atomic_store(meta + 30 + role, (int)((g & 0x0fffffffu) | 0x40000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  auto generation = [&]() { return __hip_atomic_load(meta + 30 + role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
   // ---- skyline of the whole system at tile level (first non-zero column tile of every row tile)
   // local index -> index in H / b / dx.  mode 0: identity; mode 1 (bottom workgroup): own block mirrored, then S
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
       if (split) {  // the partner learns it at the exchange and leaves as well
         xflag[2 + role] = 2;
         __threadfence();
-        __hip_atomic_store(xflag + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(xflag + role, generation(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -459,10 +467,10 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
         if (tid == 0) {
           xflag[2 + role] = (*fail != 0) ? 1 : 0;  // (a non-SPD pivot in either block fails the whole solve)
           __threadfence();
-          __hip_atomic_store(xflag + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(xflag + role, generation(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           const long long t0 = wall_clock64();
           int st = 0;
-          while (__hip_atomic_load(xflag + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int)gen) {
+          while (__hip_atomic_load(xflag + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != generation()) {
             if (wall_clock64() - t0 > 100000000ll) {  // ~1 s: the partner never came; leave the system to the next kernel
               st = 2;
               break;
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
             if (tid == 0) {
               xflag[6 + role] = 1;
               __threadfence();
-              __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(xflag + 4 + role, generation(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
               meta[1] = 1;
               meta[3] = 1;
             }
@@ -671,12 +679,12 @@ __global__ __launch_bounds__(THREADS) void ba_solve_band_kernel(const double *__
     if (lane == 0) {
       xflag[6 + role] = failed;
       __threadfence();
-      __hip_atomic_store(xflag + 4 + role, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xflag + 4 + role, generation(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
       other = 2;  // (2 = the partner never reported: its block of dx is unknown)
       // (it has passed the exchange, so it is resident and running; with nothing queued behind, the wait is 30x longer)
       while (wall_clock64() - t0 < (nofb ? 3000000000ll : 100000000ll)) {
-        if (__hip_atomic_load(xflag + 4 + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gen) {
+        if (__hip_atomic_load(xflag + 4 + (1 - role), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == generation()) {
           other = __hip_atomic_load(xflag + 6 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
@@ -730,16 +738,11 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
   }
   if (!big) {
     // two workgroups: the second one only works when the band lets the system be split (decided on the device).
-    // The hand-shake flags carry a per-LAUNCH generation number that is a kernel argument: a launch captured into a
-    // hipGraph would replay with the same number and take the previous replay's flags for this one's -- the two-workgroup
-    // form must not be graph-captured (capture with DBA_SOLVE_SPLIT=0, which keeps one workgroup and no flags).
-    static std::atomic<unsigned> generation{1};
-    const unsigned gen = generation.fetch_add(1) | 0x40000000u;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
     static const bool one_wg = [] { const char *e = getenv("DBA_SOLVE_SPLIT"); return e && e[0] == '0'; }();
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 1, false>), dim3((scratch && !one_wg) ? 2 : 1), dim3(BD_THREADS),
                        SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, scratch ? gcap : 0,
-                       gen, last ? 1 : 0 BD_PROF_ARG);
+                       last ? 1 : 0 BD_PROF_ARG);
   } else {
     if (!scratch) return DBA_ERR_WORKSPACE;
     const int gcap = (int)(scratch_doubles > 0x7fffffff ? 0x7fffffff : scratch_doubles);
@@ -748,11 +751,11 @@ int launch_ba_solve_band(const double *H, const double *b, const int *fpose, int
     // first one left: it is no longer queued (4.6 us per solve even when it returns at once), only kept for
     // DBA_SOLVE_BAND_BIG=512
     hipLaunchKernelGGL((ba_solve_band_kernel<BD_THREADS, 2, true>), dim3(1), dim3(BD_THREADS), SOLVE_MAX_LDS_BYTES, stream,
-                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u, 0 BD_PROF_ARG);
+                       H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0 BD_PROF_ARG);
     static const bool also512 = [] { const char *e = getenv("DBA_SOLVE_BAND_BIG"); return e && e[0] == '5'; }();
     if (also512)
       hipLaunchKernelGGL((ba_solve_band_kernel<BD_BIG_THREADS, BD_BIG_SLOTS, true>), dim3(1), dim3(BD_BIG_THREADS),
-                         SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0u, 0 BD_PROF_ARG);
+                         SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep, dx, meta, scratch, gcap, 0 BD_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
   return DBA_OK;

@@ -979,7 +979,7 @@ __device__ __host__ __forceinline__ size_t wv_front_lds_doubles(int nloc, int se
 template <int NT>
 __device__ void ba_solve_wave_run_front(const double *__restrict__ H, const double *__restrict__ bvec, int n, double lm, double ep,
                                         float *__restrict__ dx, int *__restrict__ meta, double *__restrict__ smem, int lane, int wave,
-                                        const WvFront F, int front, double *__restrict__ xch, unsigned gen) {
+                                        const WvFront F, int front, double *__restrict__ xch) {
   const WvLayout<NT, false> L(smem, F.nloc, 0, (F.sel + 4) & ~3);
   double *const own = xch + (size_t)front * WV_XCH_STRIDE, *const oth = xch + (size_t)(1 - front) * WV_XCH_STRIDE;
   double *const ssep = xch + (size_t)(2 + front) * WV_XCH_STRIDE, *const bsep = ssep + 68 * 68;
@@ -999,6 +999,8 @@ __device__ void ba_solve_wave_run_front(const double *__restrict__ H, const doub
   if (threadIdx.x < 16) L.flagW[threadIdx.x] = 0;
   if (threadIdx.x < 8) meta_sep[threadIdx.x] = 0, words[threadIdx.x] = 0;
   __syncthreads();
+  // (this launch's generation number was counted at the kernel's entry, ba_solve_wave_fronts_kernel: read where it is needed)
+  auto generation = [&]() { return (unsigned)__hip_atomic_load(meta + 26 + front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   int part = wave;
   if constexpr (NT == 5) part = wave == 2 ? 3 : wave == 3 ? 4 : wave == 4 ? 2 : wave == 5 ? 6 : wave == 6 ? 5 : wave;
   if (part < NT) ba_solve_wave_factor<NT, false, true>(n, smem, H, lm, ep, lane, part, 0, nullptr, F, own);
@@ -1013,10 +1015,11 @@ __device__ void ba_solve_wave_run_front(const double *__restrict__ H, const doub
   __syncthreads();
   FSTAMP(2);
   if (threadIdx.x == 0) {
+    const unsigned gen = generation();
     __hip_atomic_store(xflag + front, (int)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(xflag + (1 - front), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (int)gen) {
-      if (wall_clock64() - t0 > 20000000ll) {   // 0.2 s: the partner workgroup never came (both then give the solve up: zero update)
+      if (wall_clock64() - t0 > 100000000ll) {   // 1 s: the partner workgroup never came (both then give the solve up: zero update)
         words[1] = 1;
         break;
       }
@@ -1077,6 +1080,7 @@ __device__ void ba_solve_wave_run_front(const double *__restrict__ H, const doub
   bool all_failed = failed;
   if (lane == 0) {
     __threadfence();
+    const unsigned gen = generation();
     const int mine = (int)gen | (failed ? 0x10000000 : 0);
     __hip_atomic_store(xflag + 4 + front, mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
@@ -1084,7 +1088,7 @@ __device__ void ba_solve_wave_run_front(const double *__restrict__ H, const doub
     for (;;) {
       theirs = __hip_atomic_load(xflag + 4 + (1 - front), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if ((theirs & ~0x10000000) == (int)gen) break;
-      if (lost || wall_clock64() - t0 > 20000000ll) {
+      if (lost || wall_clock64() - t0 > 100000000ll) {
         theirs = (int)gen | 0x10000000;
         break;
       }
@@ -1143,10 +1147,18 @@ __global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_fronts_kernel(const 
                                                                    const int *__restrict__ fpose, int n, double lm, double ep,
                                                                    float *__restrict__ dx, int *__restrict__ meta,
                                                                    double *__restrict__ Lglobal, int *__restrict__ verdict, int max_nt,
-                                                                   int ring_e4, int ring_e5, unsigned gen, double *__restrict__ xch,
+                                                                   int ring_e4, int ring_e5, double *__restrict__ xch,
                                                                    int *__restrict__ splan) {
   extern __shared__ __attribute__((aligned(16))) double wv_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // The hand-shake words carry a per-launch generation number.  It is counted ON THE DEVICE -- a counter per workgroup in the
+  // workspace (meta[24], meta[25]: both advance by one per launch, whatever path the launch takes) -- so that a launch replayed
+  // from a hipGraph gets a new number too (the skyline kernel's comes as a kernel argument and must not be captured).
+  // (one thread counts and leaves the number in meta[26 + workgroup]; the threads that need it read it back behind a barrier)
+  if (threadIdx.x == WV_THREADS - 64) {   // (the last wave: off the chain at the start, whatever the window height)
+    const unsigned g = (unsigned)atomicAdd(meta + 24 + blockIdx.x, 1) + 1u;
+    __hip_atomic_store(meta + 26 + blockIdx.x, (int)((g & 0x0fffffffu) | 0x20000000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef WV_FRONT_PROF
   if (threadIdx.x == 0) (reinterpret_cast<long long *>(xch + 4 * (size_t)WV_XCH_STRIDE) + 16 * blockIdx.x)[8] = wall_clock64();
 #endif
@@ -1177,9 +1189,9 @@ __global__ __launch_bounds__(WV_THREADS) void ba_solve_wave_fronts_kernel(const 
     WvFront F;
     F.sep = sep, F.n4 = n + (n & 2), F.mirror = front;
     F.a = front ? ab : at, F.sel = F.a / 4, F.nloc = F.a + sep;
-    if (ntf == 3) ba_solve_wave_run_front<3>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
-    else if (ntf == 4) ba_solve_wave_run_front<4>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
-    else ba_solve_wave_run_front<5>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch, gen);
+    if (ntf == 3) ba_solve_wave_run_front<3>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch);
+    else if (ntf == 4) ba_solve_wave_run_front<4>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch);
+    else ba_solve_wave_run_front<5>(H, bvec, n, lm, ep, dx, meta, wv_smem, lane, wave, F, front, xch);
     return;
   }
   if (blockIdx.x != 0) return;
@@ -1238,10 +1250,8 @@ int launch_ba_solve_wave(const double *H, const double *b, const int *fpose, int
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_MAX_LDS_BYTES));
       attr2_once.done();
     }
-    static std::atomic<unsigned> generation{1};
-    const unsigned gen = (generation.fetch_add(1) & 0x0fffffffu) | 0x20000000u;
     hipLaunchKernelGGL(ba_solve_wave_fronts_kernel, dim3(2), dim3(WV_THREADS), (size_t)SOLVE_MAX_LDS_BYTES, stream, H, b, fpose, n, lm, ep,
-                       dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], gen, Lscratch + xch_off, splan);
+                       dx, meta, Lscratch, verdict, max_nt, ring_e[4], ring_e[5], Lscratch + xch_off, splan);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }

@@ -1,3 +1,3 @@
 #!/bin/bash
-OUT=$PWD/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_solve.py -q -m gpu -x 2>&1 | tail -8
+timeout 200 ./scratch/bin/solve_wave_test 2>&1 | grep -c "MISMATCH\|launch error"
+timeout 200 ./scratch/bin/solve_wave_test 2>&1 | grep -A1 "P=63 n=378 w=4 extra\|P=63 n=378 w=6\|P=49" | grep "wave:"

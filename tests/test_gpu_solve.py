@@ -239,7 +239,7 @@ def _pose_system(rng, P, w, spd=True, extra=()):
 class _SkylineSolver:
     """one workspace, several solves: the solver's choice of kernel for a workspace depends on what its previous system was"""
 
-    def __init__(self, P):
+    def __init__(self, P, init=False):
         self.lib = _lib.load()
         self.P = P
         self.dims = (1, P + 2, 8, 8, 1, 1 + P)
@@ -247,6 +247,9 @@ class _SkylineSolver:
         self.ws = torch.zeros(self.nbytes, dtype=torch.uint8, device="cuda")
         self.lay = _lib.BaLayout()
         _lib.check(self.lib.dba_ba_get_layout(*self.dims, ctypes.byref(self.lay)), "dba_ba_get_layout")
+        if init:   # forget what the library was told about an earlier workspace at this address
+            _lib.check(self.lib.dba_ba_workspace_init(*self.dims, ctypes.c_void_p(self.ws.data_ptr()), self.nbytes,
+                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dba_ba_workspace_init")
 
     def solve(self, H, b, fpose, lm=1e-4, ep=0.1):
         n, lay, ws = 6 * self.P, self.lay, self.ws
@@ -468,3 +471,65 @@ def test_two_fronts_on_two_workgroups_equal_one_front(P, w):
         assert failed == 1 and np.all(dx == 0.0), where
     dx, failed = S.solve(*systems[0])
     assert failed == 0
+
+
+@pytest.mark.parametrize("kernel", ["window", "skyline"])
+def test_two_workgroup_solves_replay_from_a_captured_graph(kernel):
+    """the hand-shake words of the two-workgroup kernels carry a generation number counted ON THE DEVICE (meta[24..27] for the
+    window kernel's two fronts, meta[28..31] for the skyline kernel), not a kernel argument: a launch captured into a hipGraph gets
+    a new number on every replay.  The same launch is replayed over alternating systems (and a failing one in between); every
+    replay must give that system's solution -- a replay that took the previous replay's flags for its own would read the partner's
+    separator block before it is written.  Which kernel a fresh workspace gets follows the verdict on the last workspace that had
+    one (launch_ba_solve): a banded system in another workspace first -> the window kernel; one with a long coupling -> skyline"""
+    P, w = (63, 8) if kernel == "window" else (63, 4)
+    rng = np.random.default_rng(99)
+    prime = _SkylineSolver(40, init=True)
+    Hp, bp, fpp = _pose_system(rng, 40, 4, extra=() if kernel == "window" else [(39, 0)])
+    prime.solve(Hp, bp, fpp)
+    fpd = torch.from_numpy(fpp).cuda()
+    want = 1 if kernel == "window" else 2
+    for _ in range(1100):     # (a workspace sent to the skyline kernel is offered to the window kernel again every 1024th solve)
+        if prime.lib.dba_ba_solver_verdict(*prime.dims, ctypes.c_void_p(prime.ws.data_ptr()), prime.nbytes) == want:
+            break
+        _lib.check(prime.lib.dba_ba_solve_skyline(*prime.dims, 1e-4, 0.1, ctypes.c_void_p(fpd.data_ptr()), ctypes.c_void_p(prime.ws.data_ptr()),
+                                                  prime.nbytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "prime")
+        torch.cuda.synchronize()
+    assert prime.lib.dba_ba_solver_verdict(*prime.dims, ctypes.c_void_p(prime.ws.data_ptr()), prime.nbytes) == want
+    prime.solve(Hp, bp, fpp)  # (launch_ba_solve notes the verdict it finds)
+    S = _SkylineSolver(P, init=True)
+    systems = [_pose_system(rng, P, w) for _ in range(3)]
+    dx, failed = S.solve(*systems[0])          # eager once: the plan for this structure is in the workspace, attributes are set
+    assert failed == 0 and S.fronts[0] == 1
+    n, lay, ws = 6 * P, S.lay, S.ws
+    fp = torch.from_numpy(systems[0][2]).cuda()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(S.lib.dba_ba_solve_skyline(*S.dims, 1e-4, 0.1, ctypes.c_void_p(fp.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                  S.nbytes, stream), "dba_ba_solve_skyline (capture)")
+    torch.cuda.synchronize()
+    for rep in range(24):
+        H, b, _ = systems[rep % 3]
+        bad = rep % 7 == 5
+        Hl = np.tril(H) + np.triu(np.full_like(H, 1e300), 1)
+        if bad:
+            Hl[200, 200] = -1.0
+        ws[lay.H:lay.H + 8 * n * n].view(torch.float64).copy_(torch.from_numpy(Hl.reshape(-1)).cuda())
+        ws[lay.b:lay.b + 8 * n].view(torch.float64).copy_(torch.from_numpy(b).cuda())
+        ws[lay.dx:lay.dx + 4 * n].view(torch.float32).fill_(7.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        dx = ws[lay.dx:lay.dx + 4 * n].view(torch.float32).cpu().numpy()
+        meta = ws[lay.meta:lay.meta + 32].view(torch.int32).cpu().numpy()
+        if bad:
+            assert int(meta[1]) == 1 and np.all(dx == 0.0), rep
+            continue
+        ref = _ref(H, b)
+        assert int(meta[1]) == 0 and int(meta[4]) == 1, (rep, meta[:8])
+        np.testing.assert_allclose(dx, ref, rtol=0, atol=3e-7 * max(1.0, np.abs(ref).max()))
+    meta = ws[lay.meta:lay.meta + 128].view(torch.int32).cpu().numpy()
+    c = 24 if kernel == "window" else 28
+    assert int(meta[c]) == int(meta[c + 1]) >= 25 and int(meta[52 - c]) == 0, meta[24:32]   # both workgroups counted every launch
