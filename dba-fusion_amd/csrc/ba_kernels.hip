@@ -955,6 +955,17 @@ extern "C" void dba_lin_prof_dump() {
     }
   fprintf(stderr, "LIN_PROF (10 ns ticks, wave 0 of slice-block 3, summed over frames): prologue %llu, sync %llu, resolve %llu, edges %llu, tail-of-loop %llu, epilogue %llu | last launch: %llu waves, first start -> last end %llu ticks, last start at +%llu, mean life %.1f, longest %llu\n",
           h[0], h[1], h[2], h[3], h[4], h[5], cnt, hi - lo, laststart - lo, cnt ? (double)sum / cnt : 0.0, maxlife);
+  {  // how many waves are alive at each tenth of the launch, and how many have started by then
+    fprintf(stderr, "LIN_PROF residency (t in ticks: alive / started):");
+    for (int d = 0; d <= 10; d++) {
+      const unsigned long long t = lo + (hi - lo) * d / 10;
+      int alive = 0, started = 0;
+      for (int i = 0; i < 8192; i++)
+        if (sp[2 * i]) started += sp[2 * i] <= t, alive += (sp[2 * i] <= t && sp[2 * i + 1] > t);
+      fprintf(stderr, " %llu: %d / %d;", t - lo, alive, started);
+    }
+    fprintf(stderr, "\n");
+  }
   memset(h, 0, sizeof(h));
   memset(sp, 0, sizeof(sp));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lin_span), sp, sizeof(sp));
