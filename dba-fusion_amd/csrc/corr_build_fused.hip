@@ -67,6 +67,9 @@ struct FusedLevels {
 };
 
 constexpr int FT_ROWS = 8;  // target rows per tile
+#ifndef FB_STORE_AUX
+#define FB_STORE_AUX 0   // cache policy bits of the level stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1); measured, see profiles/
+#endif
 
 __device__ __forceinline__ _Float16 pool4(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
   // ATen avg_pool2d on half: float accumulate, one rounding
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
             u2v d;
             d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
             d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
-            __builtin_amdgcn_raw_buffer_store_b64(d, r0, (dx0 + 4 * b + g < w2) ? voff : OOR, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r0, (dx0 + 4 * b + g < w2) ? voff : OOR, 0, FB_STORE_AUX);
             voff += 4u * plane_bytes;
           }
         }
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           tx = min(tx, w2 - 1);  // (dx beyond the map in the last group: read something valid, store nothing)
           const _Float16 v = row[tx];
           __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r0,
-                                                (pok && dx < w2) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, 0);
+                                                (pok && dx < w2) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
         }
       }
     }
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           u2v d;
           d.x = (unsigned)a0 | ((unsigned)a1 << 16);
           d.y = (unsigned)a2 | ((unsigned)a3 << 16);
-          __builtin_amdgcn_raw_buffer_store_b64(d, rl, (dx0 + g < w2l) ? voff : OOR, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(d, rl, (dx0 + g < w2l) ? voff : OOR, 0, FB_STORE_AUX);
           voff += 8u * plane_bytes;
           t += 8;
           t -= (t >= w2l) ? w2l : 0;
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
           tx = min(tx, w2l - 1);
           const _Float16 v = row[tx];
           __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
-                                                (pok && dx < w2l) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, 0);
+                                                (pok && dx < w2l) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
         }
       }
     }
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
       tx -= (tx >= w2l) ? w2l : 0;
       const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
       const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
-      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, FB_STORE_AUX);
     }
   };
   store_level(2, P2, 2, W2P / 4);
