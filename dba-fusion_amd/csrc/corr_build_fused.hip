@@ -622,6 +622,276 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 #endif
 }
 
+
+// =====================================================================================================================
+// The strip walk on SIXTEEN waves (round 6): tiled planes, 64 target columns, the caller's maps read as they lie.
+//
+// The eight-wave walk above is a chain of phases whose costs add up (profiles/r06_late_experiments.txt, item 5: products 2.9,
+// level-0 store loop 5.0, pooled stores 4.8, pooling 2.1, the rest 5.5 us per edge): each phase is a short chain of dependent
+// latencies (LDS -> VALU -> store issue), a workgroup's waves are all in the same phase, and with two waves per SIMD nothing hides
+// anything -- not HBM (the stores' memory share is ~3 of 10 us), not the vector ALU (vector work in the matrix instructions' shadow
+// buys nothing).  What it lacks is waves.  Here a target row is shared by TWO waves -- wave (r, hf) owns targets 32 hf .. 32 hf + 31
+// of row ty0 + r: 32 fragment registers + 32 accumulators instead of 64 + 64 -- so a workgroup is 16 waves, four per SIMD, in the
+// same LDS (tile + two operand buffers + the pooled region: 126 KB, one workgroup per CU as before).  Same arithmetic in the same
+// order: bit-identical to the eight-wave walk.
+// Restricted to what the headline shapes are: tiled planes (h1 % 4 == 0, w1 % 64 == 0), w2 == 64, h2 % 8 == 0, C == 128, maps whose
+// 16-byte pieces are aligned; everything else keeps the kernel above.
+__global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
+                                                                  FusedLevels L, int h1, int w1, int h2, int HW1p, int strips_per_wg,
+                                                                  const int *__restrict__ oslots) {
+  constexpr int C = 128, W2 = 64, KSL = 8;
+  constexpr int RP = W2 + 4, PITCH = FT_ROWS * RP + 4, RP1 = W2 / 2 + 4;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  _Float16 *T = smem;                          // [64][PITCH]   level 0 of the current strip, rounded
+  _Float16 *Ab0 = smem + 64 * PITCH;           // two source-operand buffers of 16 KB
+  _Float16 *P1 = Ab0 + 2 * 64 * 128;           // [64][4][RP1]  pooled levels of the current strip
+  _Float16 *P2 = P1 + 64 * 4 * RP1;            // [64][2][16]
+  _Float16 *P3 = P2 + 64 * 2 * (W2 / 4);       // [64][8]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = wave & 7, hf = wave >> 3;      // this wave's target row of the tile, its half of the row's targets
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {  // all row tiles of a (strip group, edge) on one XCD, side by side (see the kernel above)
+    const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+    const int lin = bx + (int)gridDim.x * (by + (int)gridDim.y * bz);
+    const int q8 = total >> 3, r8 = total & 7, xk = lin & 7;
+    const int logical = xk * q8 + min(xk, r8) + (lin >> 3);
+    by = logical % (int)gridDim.y;
+    const int rest = logical / (int)gridDim.y;
+    bx = rest % (int)gridDim.x;
+    bz = rest / (int)gridDim.x;
+  }
+  const int ty0 = by * FT_ROWS, e = bz;
+  const int HW1 = h1 * w1, HW2 = h2 * W2, tiles_x = w1 >> 4;
+  const int l31 = lane & 31, kh = (lane >> 5) * 8;
+  const int nstrips = HW1p >> 6;
+  const int s_begin = bx * strips_per_wg, s_end = min(nstrips, s_begin + strips_per_wg);
+  if (s_begin >= s_end) return;   // (workgroup-uniform)
+  const int eo = oslots ? oslots[e] : e;
+  auto level_rsrc = [&](int lvl) {
+    const size_t elems = (size_t)(h2 >> lvl) * (W2 >> lvl) * HW1p;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)eo * elems), 0, (int)(2 * elems), 0x00020000);
+  };
+  const unsigned plane_bytes = 2u * (unsigned)HW1p;
+
+  // ---- source operand of a strip (= a 4 x 16 tile of the map): threads 0..255 read 8 pixels x 4 channels each ------------------
+  half8 anat[4];
+  auto request_a = [&](int strip) {
+    if (tid < 256) {
+      const int kg = tid >> 3, pg = tid & 7;
+      const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
+      const int yy = 4 * tyi + (pg >> 1), xx = 16 * txi + 8 * (pg & 1);
+      const _Float16 *src = A + (size_t)e * HW1 * C + (size_t)(4 * kg) * HW1 + yy * w1 + xx;
+#pragma unroll
+      for (int c = 0; c < 4; c++) anat[c] = *reinterpret_cast<const half8 *>(src + (size_t)c * HW1);
+    }
+  };
+  auto stage_a = [&](_Float16 *dst) {   // -> LDS, fragment layout [k-step][q][32-pixel block][k-half][pixel][4 halves], scaled
+    if (tid < 256) {
+      const int kg = tid >> 3, pg = tid & 7, kbk = kg >> 2, qq = kg & 1, hfk = (kg >> 1) & 1, px = 8 * pg;
+      _Float16 *d = dst + (((((kbk * 2 + qq) * 2 + (px >> 5)) * 2 + hfk) * 32 + (px & 31)) * 4);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        half4 o;
+#pragma unroll
+        for (int c = 0; c < 4; c++) o[c] = anat[c][j];
+        *reinterpret_cast<half4 *>(d + 4 * j) = o * (_Float16)0.25f;   // (corr.py:67-68: both maps / 4, one rounding to half)
+      }
+    }
+  };
+  // ---- this wave's target fragments, resident for the whole walk: 32 targets x 128 channels ------------------------------------
+  half8 bres[KSL];
+  {
+    const _Float16 *Be = Bm + (size_t)e * HW2 * C + (size_t)(ty0 + r) * W2;
+    const int kq = lane >> 2, tx0 = 32 * hf + 8 * (lane & 3);
+    half8 raw[KSL];
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) raw[ks] = *reinterpret_cast<const half8 *>(Be + (size_t)(16 * ks + kq) * HW2 + tx0);
+    _Float16 *scr = T + wave * (32 * 16);   // (the tile's LDS: nothing lives there before the first strip)
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) scr[(8 * (lane & 3) + j) * 16 + kq] = raw[ks][j] * (_Float16)0.25f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bres[ks] = *reinterpret_cast<const half8 *>(scr + l31 * 16 + kh);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) asm volatile("" : "+v"(bres[ks]));   // (pinned: not re-read per strip)
+  }
+  request_a(s_begin);
+  stage_a(Ab0);
+
+  constexpr unsigned OOR = 0x80000000u;
+  const int q = lane & 15, g = lane >> 4, q4 = 4 * q, rr = q >> 2;   // the lane's quad of pixels: tile row rr, columns 4 (q & 3) ..
+  for (int strip = s_begin; strip < s_end; strip++) {
+    const int p0 = strip * 64;
+    _Float16 *Ab = Ab0 + ((strip - s_begin) & 1) * (64 * 128);
+    if (strip + 1 < s_end) request_a(strip + 1);   // consumed behind the tile write, BEFORE this strip's stores are issued
+    lds_barrier();
+
+    // ---- products: acc[i] = 32 x 32 tile (targets 32 hf .., sources 32 i ..) of target row ty0 + r -----------------------------
+    float16v acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[i][k] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) {
+      half8 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const _Float16 *fp = Ab + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
+        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bres[ks], a[i], acc[i], 0, 0, 0);  // targets x sources
+    }
+    lds_barrier();  // every wave is done with the source operand and with the previous strip's tile
+    // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        half4 v;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
+        *reinterpret_cast<half4 *>(T + (i * 32 + l31) * PITCH + r * RP + 32 * hf + 8 * rq + 4 * (lane >> 5)) = v;
+      }
+    if (hf == 0 && lane < 32) {   // columns 0..3 once more behind column 63: a store lane's diagonal reads never wrap inside a quad
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        _Float16 *wr = T + (i * 32 + l31) * PITCH + r * RP + W2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wr[k] = (_Float16)acc[i][k];
+      }
+    }
+    lds_barrier();
+    if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));
+
+    // ---- the strip's pixels: tile (tyi, txi) of the map; the lane's quad on tile row rr --------------------------------------
+    const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
+    const int ybase = 4 * tyi, xbase = 16 * txi;
+    const int qx0 = xbase + 4 * (q & 3), qy = ybase + rr;
+    // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod 64]; the quads of tile row rr take the target
+    // row (r + rr) mod 8 of the tile (whole lines per store instruction, see the kernel above); this wave: dx = 32 hf .. 32 hf + 31
+    {
+      const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
+      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+      int t = (qx0 + 32 * hf + g) & (W2 - 1);
+      int dy = tyq - qy;
+      dy += (dy < 0) ? h2 : 0;
+      unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)(32 * hf + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      const _Float16 *lb = T + q4 * PITCH + wrow * RP;
+#pragma unroll
+      for (int bt = 0; bt < 2; bt++) {  // four lines per store instruction, four instructions per batch: 16 LDS reads in flight
+        unsigned short a[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const _Float16 *pp = lb + t;
+#pragma unroll
+          for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
+          t = (t + 4) & (W2 - 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          u2v d;
+          d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
+          d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, 0, FB_STORE_AUX);
+          voff += 4u * plane_bytes;
+        }
+      }
+    }
+    // ---- levels 1..3: threads 0..511 pool one 8 x 8 block each (from the ROUNDED level below each time) into the pooled region
+    if (tid < 512) {
+      const int src = tid >> 3, cb = tid & 7;
+      const _Float16 *tb = T + src * PITCH + 8 * cb;
+      _Float16 t8[8][8], q1[4][4], q2[2][2];
+#pragma unroll
+      for (int rw = 0; rw < 8; rw++) {
+        const half4 lo = *reinterpret_cast<const half4 *>(tb + rw * RP), hi = *reinterpret_cast<const half4 *>(tb + rw * RP + 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) t8[rw][c] = lo[c], t8[rw][4 + c] = hi[c];
+      }
+#pragma unroll
+      for (int rw = 0; rw < 4; rw++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) q1[rw][c] = pool4(t8[2 * rw][2 * c], t8[2 * rw][2 * c + 1], t8[2 * rw + 1][2 * c], t8[2 * rw + 1][2 * c + 1]);
+#pragma unroll
+      for (int rw = 0; rw < 2; rw++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) q2[rw][c] = pool4(q1[2 * rw][2 * c], q1[2 * rw][2 * c + 1], q1[2 * rw + 1][2 * c], q1[2 * rw + 1][2 * c + 1]);
+      const _Float16 q3 = pool4(q2[0][0], q2[0][1], q2[1][0], q2[1][1]);
+#pragma unroll
+      for (int rw = 0; rw < 4; rw++) {
+        half4 v;
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = q1[rw][c];
+        _Float16 *row1 = P1 + (src * 4 + rw) * RP1;
+        *reinterpret_cast<half4 *>(row1 + 4 * cb) = v;
+        if (cb == 0) *reinterpret_cast<half4 *>(row1 + W2 / 2) = v;   // columns 0..3 once more behind column 31
+      }
+#pragma unroll
+      for (int rw = 0; rw < 2; rw++) {
+        half2v v;
+        v.x = q2[rw][0], v.y = q2[rw][1];
+        *reinterpret_cast<half2v *>(P2 + (src * 2 + rw) * (W2 / 4) + 2 * cb) = v;
+      }
+      P3[src * (W2 / 8) + cb] = q3;
+    }
+    lds_barrier();
+    {  // level 1: wave w takes pooled row w & 3 and the groups of four offsets (w >> 2) + 4 k; a quad's columns (x >> 1) - (x0 >> 1)
+      const int w2l = W2 >> 1, h2l = h2 >> 1;
+      const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
+      const int tyl = wave & 3, grp = wave >> 2;
+      const int tylq = (tyl + (rr >> 1)) & 3, tygq = (ty0 >> 1) + tylq;   // (the quads of tile rows 2, 3 take the next pooled row)
+      const int xh = qx0 >> 1;
+      const int o1 = ((qx0 + 1) >> 1) - xh, o2 = ((qx0 + 2) >> 1) - xh, o3 = ((qx0 + 3) >> 1) - xh;
+      int t = (xh + 4 * grp + g) & (w2l - 1);
+      int dy = tygq - (qy >> 1);
+      dy += (dy < 0) ? h2l : 0;
+      unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      const _Float16 *lb = P1 + (q4 * 4 + tylq) * RP1;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const _Float16 *pp = lb + t;
+        const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
+        const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v d;
+        d.x = (unsigned)a0 | ((unsigned)a1 << 16);
+        d.y = (unsigned)a2 | ((unsigned)a3 << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff, 0, FB_STORE_AUX);
+        voff += 16u * plane_bytes;
+        t = (t + 16) & (w2l - 1);
+      }
+    }
+    {  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
+      const int x1 = xbase + (lane & 15), y1 = ybase + (lane >> 4);
+      auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
+        const int h2l = h2 >> lvl, w2l = W2 >> lvl;
+        const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
+        const int x1l = x1 >> lvl, y1l = y1 >> lvl;
+        for (int seg = wave; seg < rows * w2l; seg += 16) {  // (wave-uniform)
+          const int tyl = seg / w2l, dx = seg - tyl * w2l;
+          int dy = (ty0 >> lvl) + tyl - y1l;
+          dy += (dy < 0) ? h2l : 0;
+          const int tx = (x1l + dx) & (w2l - 1);
+          const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
+                                                ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + lane), 0, FB_STORE_AUX);
+        }
+      };
+      store_level(2, P2, 2, W2 / 4);
+      store_level(3, P3, 1, W2 / 8);
+    }
+    (void)OOR;
+  }
+}
+
 // defined in corr_build.hip
 __global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
 
@@ -720,7 +990,20 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     if (force == 2 && spw < 2) spw = 2;
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
-    if (native)
+    // sixteen waves per workgroup on the shapes the headline runs on (DBA_BUILD_WAVES=8 keeps the eight-wave walk: A/B runs)
+    static const bool waves16 = [] { const char *e = getenv("DBA_BUILD_WAVES"); return !(e && atoi(e) == 8); }();
+    if (native && tiled && w2 == 64 && (h2 % 8) == 0 && waves16) {
+      static DeviceOnce attr16_once;
+      if (attr16_once.needed()) {
+        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr16_once.done();
+      }
+      const size_t lds16 = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128 +
+                                               (size_t)64 * (4 * (32 + 4) + 2 * 16 + 8));   // tile, two operand buffers, pooled region
+      hipLaunchKernelGGL(corr_build_fused16_kernel, lgrid, dim3(1024), lds16, s, static_cast<const _Float16 *>(fmap1),
+                         static_cast<const _Float16 *>(fmap2), L, h1, w1, h2, HW1p, spw, out_slots);
+    } else if (native)
       hipLaunchKernelGGL((corr_build_fused_kernel<2, true, true>), lgrid, dim3(512), lds, s, static_cast<const _Float16 *>(fmap1),
                          static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
                          tiled FB_PROF_ARG);
