@@ -636,6 +636,9 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 // order: bit-identical to the eight-wave walk.
 // Restricted to what the headline shapes are: tiled planes (h1 % 4 == 0, w1 % 64 == 0), w2 == 64, h2 % 8 == 0, C == 128, maps whose
 // 16-byte pieces are aligned; everything else keeps the kernel above.
+#ifndef F16_L0_LOW
+#define F16_L0_LOW 2
+#endif
 __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
                                                                   FusedLevels L, int h1, int w1, int h2, int HW1p, int strips_per_wg,
                                                                   const int *__restrict__ oslots) {
@@ -779,13 +782,14 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
     {
       const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
       const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
-      int t = (qx0 + 32 * hf + g) & (W2 - 1);
+      // (the waves that also pool -- hf == 0 -- take F16_L0_LOW of the row's four batches of 16 offsets, their partners the rest)
+      const int bt0 = hf ? F16_L0_LOW : 0, bt1 = hf ? 4 : F16_L0_LOW;
+      int t = (qx0 + 16 * bt0 + g) & (W2 - 1);
       int dy = tyq - qy;
       dy += (dy < 0) ? h2 : 0;
-      unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)(32 * hf + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)(16 * bt0 + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
       const _Float16 *lb = T + q4 * PITCH + wrow * RP;
-#pragma unroll
-      for (int bt = 0; bt < 2; bt++) {  // four lines per store instruction, four instructions per batch: 16 LDS reads in flight
+      for (int bt = bt0; bt < bt1; bt++) {  // four lines per store instruction, four instructions per batch: 16 LDS reads in flight
         unsigned short a[4][4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -986,7 +990,8 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     const long long rows = (long long)grid.y * n;
     static const int wg_target = [] { const char *e = getenv("DBA_BUILD_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     int spw = (int)(((long long)nstrips * rows + wg_target - 1) / wg_target);
-    spw = spw < 1 ? 1 : (spw > 16 ? 16 : spw);
+    static const int spw_cap = [] { const char *e = getenv("DBA_BUILD_SPW_CAP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    spw = spw < 1 ? 1 : (spw > spw_cap ? spw_cap : spw);
     if (force == 2 && spw < 2) spw = 2;
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
