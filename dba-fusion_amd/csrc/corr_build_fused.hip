@@ -641,8 +641,18 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 #endif
 __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
                                                                   FusedLevels L, int h1, int w1, int h2, int HW1p, int strips_per_wg,
-                                                                  const int *__restrict__ oslots) {
+                                                                  const int *__restrict__ oslots
+#ifdef F16_PROF
+                                                                  , unsigned long long *prof
+#endif
+                                                                  ) {
   constexpr int C = 128, W2 = 64, KSL = 8;
+#ifdef F16_PROF   // scratch builds: time per phase of the walk, summed per wave (s_memtime ticks)
+  unsigned long long f16_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, f16_last_ = __builtin_amdgcn_s_memtime();
+#define F16_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); f16_acc_[i] += t_ - f16_last_; f16_last_ = t_; } while (0)
+#else
+#define F16_STAMP(i) (void)0
+#endif
   constexpr int RP = W2 + 4, PITCH = FT_ROWS * RP + 4, RP1 = W2 / 2 + 4;
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   _Float16 *T = smem;                          // [64][PITCH]   level 0 of the current strip, rounded
@@ -688,10 +698,15 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       for (int c = 0; c < 4; c++) anat[c] = *reinterpret_cast<const half8 *>(src + (size_t)c * HW1);
     }
   };
-  auto stage_a = [&](_Float16 *dst) {   // -> LDS, fragment layout [k-step][q][32-pixel block][k-half][pixel][4 halves], scaled
+  auto stage_a = [&](_Float16 *dst) {   // -> LDS, fragment layout [k-step][32-pixel block][q][k-half][pixel][4 halves], scaled
     if (tid < 256) {
       const int kg = tid >> 3, pg = tid & 7, kbk = kg >> 2, qq = kg & 1, hfk = (kg >> 1) & 1, px = 8 * pg;
+#ifndef F16_A_QT   // [k-step][32-pixel block][q][k-half]..: a lane's two halves of a fragment are 512 B apart and pair up into ONE
+      // two-address read whose registers are the fragment (with q outside the block the pairs were (block 0, block 1): six moves per k-step)
+      _Float16 *d = dst + (((((kbk * 2 + (px >> 5)) * 2 + qq) * 2 + hfk) * 32 + (px & 31)) * 4);
+#else
       _Float16 *d = dst + (((((kbk * 2 + qq) * 2 + (px >> 5)) * 2 + hfk) * 32 + (px & 31)) * 4);
+#endif
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         half4 o;
@@ -723,14 +738,85 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
   }
   request_a(s_begin);
   stage_a(Ab0);
+  F16_STAMP(0);
 
   constexpr unsigned OOR = 0x80000000u;
   const int q = lane & 15, g = lane >> 4, q4 = 4 * q, rr = q >> 2;   // the lane's quad of pixels: tile row rr, columns 4 (q & 3) ..
+  // ---- levels 1..3 of a strip from the pooled region, behind the strip's pooling and a barrier.  -DF16_DEFER (measured, not faster:
+  // 13.3-13.9 against 13.0-13.4 us per edge at 64x64, profiles/r06_build16.txt) issues the stores of strip s in strip s + 1's product
+  // phase instead -- half of the waves in front of their matrix instructions, half behind them -- with the next strip's first
+  // barrier in place of this one.
+  auto pooled_stores = [&](int strip) {
+    const int p0 = strip * 64;
+    const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
+    const int ybase = 4 * tyi, xbase = 16 * txi;
+    const int qx0 = xbase + 4 * (q & 3), qy = ybase + rr;
+    {  // level 1: wave w takes pooled row w & 3 and the groups of four offsets (w >> 2) + 4 k; a quad's columns (x >> 1) - (x0 >> 1)
+      const int w2l = W2 >> 1, h2l = h2 >> 1;
+      const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
+      const int tyl = wave & 3, grp = wave >> 2;
+      const int tylq = (tyl + (rr >> 1)) & 3, tygq = (ty0 >> 1) + tylq;   // (the quads of tile rows 2, 3 take the next pooled row)
+      const int xh = qx0 >> 1;
+      const int o1 = ((qx0 + 1) >> 1) - xh, o2 = ((qx0 + 2) >> 1) - xh, o3 = ((qx0 + 3) >> 1) - xh;
+      int t = (xh + 4 * grp + g) & (w2l - 1);
+      int dy = tygq - (qy >> 1);
+      dy += (dy < 0) ? h2l : 0;
+      unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      const _Float16 *lb = P1 + (q4 * 4 + tylq) * RP1;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const _Float16 *pp = lb + t;
+        const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
+        const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v d;
+        d.x = (unsigned)a0 | ((unsigned)a1 << 16);
+        d.y = (unsigned)a2 | ((unsigned)a3 << 16);
+#ifndef F16_ABLATE_POOLST
+        __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff, 0, FB_STORE_AUX);
+#else
+        __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff | OOR, 0, FB_STORE_AUX);
+#endif
+        voff += 16u * plane_bytes;
+        t = (t + 16) & (w2l - 1);
+      }
+    }
+    {  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
+      const int x1 = xbase + (lane & 15), y1 = ybase + (lane >> 4);
+      auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
+        const int h2l = h2 >> lvl, w2l = W2 >> lvl;
+        const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
+        const int x1l = x1 >> lvl, y1l = y1 >> lvl;
+        for (int seg = wave; seg < rows * w2l; seg += 16) {  // (wave-uniform)
+          const int tyl = seg / w2l, dx = seg - tyl * w2l;
+          int dy = (ty0 >> lvl) + tyl - y1l;
+          dy += (dy < 0) ? h2l : 0;
+          const int tx = (x1l + dx) & (w2l - 1);
+          const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
+#ifdef F16_ABLATE_POOLST
+                                                OOR |
+#endif
+                                                (((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + lane)), 0, FB_STORE_AUX);
+        }
+      };
+      store_level(2, P2, 2, W2 / 4);
+      store_level(3, P3, 1, W2 / 8);
+    }
+  };
   for (int strip = s_begin; strip < s_end; strip++) {
     const int p0 = strip * 64;
     _Float16 *Ab = Ab0 + ((strip - s_begin) & 1) * (64 * 128);
     if (strip + 1 < s_end) request_a(strip + 1);   // consumed behind the tile write, BEFORE this strip's stores are issued
     lds_barrier();
+    F16_STAMP(1);
+#ifdef F16_DEFER
+#ifndef F16_DEFER_SPLIT
+#define F16_DEFER_SPLIT 1   // 0: every wave in front of its matrix instructions, 2: every wave behind them (A/B builds)
+#endif
+    const bool stores_first = F16_DEFER_SPLIT == 0 || (F16_DEFER_SPLIT == 1 && ((wave >> 2) & 1) == 0);   // (waves w, w + 4, w + 8, w + 12 share a SIMD)
+    if (strip > s_begin && stores_first) pooled_stores(strip - 1);
+#endif
 
     // ---- products: acc[i] = 32 x 32 tile (targets 32 hf .., sources 32 i ..) of target row ty0 + r -----------------------------
     float16v acc[2];
@@ -743,15 +829,30 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       half8 a[2];
 #pragma unroll
       for (int t = 0; t < 2; t++) {
+#ifndef F16_A_QT
+        const _Float16 *fp = Ab + ((((ks * 2 + t) * 2 + 0) * 2 + (lane >> 5)) * 32 + l31) * 4;
+        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 32 * 4);
+#else
         const _Float16 *fp = Ab + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
         const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
+#endif
 #pragma unroll
         for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
       }
 #pragma unroll
+#ifndef F16_ABLATE_MFMA
       for (int i = 0; i < 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bres[ks], a[i], acc[i], 0, 0, 0);  // targets x sources
+#else
+      acc[0][0] += (float)a[0][0] + (float)a[1][1];
+#endif
     }
+    F16_STAMP(2);
+#ifdef F16_DEFER
+    if (strip > s_begin && !stores_first) pooled_stores(strip - 1);
+    F16_STAMP(8);
+#endif
     lds_barrier();  // every wave is done with the source operand and with the previous strip's tile
+    F16_STAMP(3);
     // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target)
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -771,7 +872,9 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       }
     }
     lds_barrier();
+    F16_STAMP(4);
     if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));
+    F16_STAMP(5);
 
     // ---- the strip's pixels: tile (tyi, txi) of the map; the lane's quad on tile row rr --------------------------------------
     const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
@@ -804,11 +907,16 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
           u2v d;
           d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
           d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
+#ifndef F16_ABLATE_L0
           __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, 0, FB_STORE_AUX);
+#else
+          __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff | OOR, 0, FB_STORE_AUX);
+#endif
           voff += 4u * plane_bytes;
         }
       }
     }
+    F16_STAMP(6);
     // ---- levels 1..3: threads 0..511 pool one 8 x 8 block each (from the ROUNDED level below each time) into the pooled region
     if (tid < 512) {
       const int src = tid >> 3, cb = tid & 7;
@@ -846,54 +954,25 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       }
       P3[src * (W2 / 8) + cb] = q3;
     }
+#ifndef F16_DEFER
     lds_barrier();
-    {  // level 1: wave w takes pooled row w & 3 and the groups of four offsets (w >> 2) + 4 k; a quad's columns (x >> 1) - (x0 >> 1)
-      const int w2l = W2 >> 1, h2l = h2 >> 1;
-      const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
-      const int tyl = wave & 3, grp = wave >> 2;
-      const int tylq = (tyl + (rr >> 1)) & 3, tygq = (ty0 >> 1) + tylq;   // (the quads of tile rows 2, 3 take the next pooled row)
-      const int xh = qx0 >> 1;
-      const int o1 = ((qx0 + 1) >> 1) - xh, o2 = ((qx0 + 2) >> 1) - xh, o3 = ((qx0 + 3) >> 1) - xh;
-      int t = (xh + 4 * grp + g) & (w2l - 1);
-      int dy = tygq - (qy >> 1);
-      dy += (dy < 0) ? h2l : 0;
-      unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
-      const _Float16 *lb = P1 + (q4 * 4 + tylq) * RP1;
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const _Float16 *pp = lb + t;
-        const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
-        const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        u2v d;
-        d.x = (unsigned)a0 | ((unsigned)a1 << 16);
-        d.y = (unsigned)a2 | ((unsigned)a3 << 16);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rl, voff, 0, FB_STORE_AUX);
-        voff += 16u * plane_bytes;
-        t = (t + 16) & (w2l - 1);
-      }
-    }
-    {  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
-      const int x1 = xbase + (lane & 15), y1 = ybase + (lane >> 4);
-      auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
-        const int h2l = h2 >> lvl, w2l = W2 >> lvl;
-        const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
-        const int x1l = x1 >> lvl, y1l = y1 >> lvl;
-        for (int seg = wave; seg < rows * w2l; seg += 16) {  // (wave-uniform)
-          const int tyl = seg / w2l, dx = seg - tyl * w2l;
-          int dy = (ty0 >> lvl) + tyl - y1l;
-          dy += (dy < 0) ? h2l : 0;
-          const int tx = (x1l + dx) & (w2l - 1);
-          const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
-          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
-                                                ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)(p0 + lane), 0, FB_STORE_AUX);
-        }
-      };
-      store_level(2, P2, 2, W2 / 4);
-      store_level(3, P3, 1, W2 / 8);
-    }
+    F16_STAMP(7);
+    pooled_stores(strip);
+#endif
     (void)OOR;
+    F16_STAMP(9);
   }
+#ifdef F16_DEFER
+  lds_barrier();
+  pooled_stores(s_end - 1);
+#endif
+#ifdef F16_PROF
+  if (lane == 0) {
+    unsigned long long *ps = prof + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave) * 12;
+    for (int i = 0; i < 10; i++) ps[i] = f16_acc_[i];
+    ps[10] = (unsigned long long)(s_end - s_begin);
+  }
+#endif
 }
 
 // defined in corr_build.hip
@@ -1006,8 +1085,39 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
       }
       const size_t lds16 = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128 +
                                                (size_t)64 * (4 * (32 + 4) + 2 * 16 + 8));   // tile, two operand buffers, pooled region
+#ifdef F16_PROF
+      static unsigned long long *prof16 = nullptr;
+      const size_t nslots = (size_t)lgrid.x * lgrid.y * lgrid.z * 16;
+      if (!prof16) (void)hipMalloc(&prof16, (size_t)64 << 20);
+      (void)hipMemsetAsync(prof16, 0, nslots * 12 * 8, s);
+#define F16_PROF_ARG , prof16
+#else
+#define F16_PROF_ARG
+#endif
       hipLaunchKernelGGL(corr_build_fused16_kernel, lgrid, dim3(1024), lds16, s, static_cast<const _Float16 *>(fmap1),
-                         static_cast<const _Float16 *>(fmap2), L, h1, w1, h2, HW1p, spw, out_slots);
+                         static_cast<const _Float16 *>(fmap2), L, h1, w1, h2, HW1p, spw, out_slots F16_PROF_ARG);
+#ifdef F16_PROF
+      {
+        (void)hipStreamSynchronize(s);
+        unsigned long long *hp = (unsigned long long *)malloc(nslots * 12 * 8);
+        (void)hipMemcpy(hp, prof16, nslots * 12 * 8, hipMemcpyDeviceToHost);
+        static const char *names[10] = {"prologue (per walk)", "operand wait + barrier 1", "products issued", "barrier 2", "tile write + barrier 3",
+                                        "next operand into LDS", "level-0 loop", "pooling (+ barrier 4)", "pooled stores (not deferred)", "pooled stores behind the products"};
+        for (int grp = 0; grp < 2; grp++) {   // waves 0..7 (they also pool; 0..3 stage the operand) and 8..15
+          double ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, strips = 0, waves = 0;
+          for (size_t i = 0; i < nslots; i++) {
+            if ((int)((i & 15) >> 3) != grp || hp[i * 12 + 10] == 0) continue;
+            for (int k = 0; k < 10; k++) ph[k] += (double)hp[i * 12 + k];
+            strips += (double)hp[i * 12 + 10], waves += 1;
+          }
+          fprintf(stderr, "F16_PROF n=%d spw=%d waves %d..%d | ticks per strip and wave:", n, spw, 8 * grp, 8 * grp + 7);
+          double tot = 0;
+          for (int k = 1; k < 10; k++) fprintf(stderr, " %s %.0f,", names[k], ph[k] / strips), tot += ph[k] / strips;
+          fprintf(stderr, " sum %.0f | %s %.0f per wave\n", tot, names[0], ph[0] / waves);
+        }
+        free(hp);
+      }
+#endif
     } else if (native)
       hipLaunchKernelGGL((corr_build_fused_kernel<2, true, true>), lgrid, dim3(512), lds, s, static_cast<const _Float16 *>(fmap1),
                          static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
