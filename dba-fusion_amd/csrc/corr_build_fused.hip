@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
     if constexpr (NATIVE) {
       if (tid < 256) {
         const int kg = tid >> 3, pg = tid & 7, kbk = kg >> 2, qq = kg & 1, hf = (kg >> 1) & 1, px = 8 * pg;
-        _Float16 *d = dst + (((((kbk * 2 + qq) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4);
+        _Float16 *d = dst + (((((kbk * 2 + (px >> 5)) * 2 + qq) * 2 + hf) * 32 + (px & 31)) * 4);
 #pragma unroll
         for (int j = 0; j < 8; j++) {   // pixel j: its four channels
           half4 o;
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int idx = tid + 512 * u, kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
-      const int fa = ((((kbk * 2 + 0) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4;
+      const int fa = ((((kbk * 2 + (px >> 5)) * 2 + 0) * 2 + hf) * 32 + (px & 31)) * 4;
       half4 lo, hi;
 #pragma unroll
       for (int c = 0; c < 4; c++) lo[c] = apre[u][c], hi[c] = apre[u][4 + c];
       *reinterpret_cast<half4 *>(dst + fa) = lo;
-      *reinterpret_cast<half4 *>(dst + fa + 2 * 2 * 32 * 4) = hi;
+      *reinterpret_cast<half4 *>(dst + fa + 2 * 32 * 4) = hi;
     }
   };
   if constexpr (LOOP) {
@@ -251,15 +251,16 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
     for (int idx = tid; idx < kblocks * 128; idx += 512) {  // 16-byte pieces: [kblock][pixel][half of the 16 channels]
       const int kbk = idx >> 7, r = idx & 127, px = r >> 1, hf = r & 1;
       const half8 v = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(p0 + px, HW1 - 1)) * 16 + hf * 8);
-      // LDS layout [k-step][q][32-pixel block][k-half][pixel][4 halves]: a wave's fragment read is then TWO ds_read_b64 of
+      // LDS layout [k-step][32-pixel block][q][k-half][pixel][4 halves] (q inside the block since round 6: a lane's two halves
+      // pair up into one two-address read whose registers are the fragment): a wave's fragment read is TWO ds_read_b64 of
       // 512 consecutive bytes each (3.4 cycles of the LDS pipe per instruction; the one ds_read_b128 at a 32-byte pitch
       // this replaces takes 32: scratch/lds_rates.hip)
-      const int fa = ((((kbk * 2 + 0) * 2 + (px >> 5)) * 2 + hf) * 32 + (px & 31)) * 4;
+      const int fa = ((((kbk * 2 + (px >> 5)) * 2 + 0) * 2 + hf) * 32 + (px & 31)) * 4;
       half4 lo, hi;
 #pragma unroll
       for (int c = 0; c < 4; c++) lo[c] = v[c], hi[c] = v[4 + c];
       *reinterpret_cast<half4 *>(T + fa) = lo;
-      *reinterpret_cast<half4 *>(T + fa + 2 * 2 * 32 * 4) = hi;
+      *reinterpret_cast<half4 *>(T + fa + 2 * 32 * 4) = hi;
     }
   }
 #endif
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
   auto read_a = [&](int ks, half8 (&a)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      const _Float16 *fp = Ab + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
-      const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
+      const _Float16 *fp = Ab + ((((ks * 2 + t) * 2 + 0) * 2 + (lane >> 5)) * 32 + l31) * 4;
+      const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 32 * 4);
 #pragma unroll
       for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
     }
@@ -701,12 +702,9 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
   auto stage_a = [&](_Float16 *dst) {   // -> LDS, fragment layout [k-step][32-pixel block][q][k-half][pixel][4 halves], scaled
     if (tid < 256) {
       const int kg = tid >> 3, pg = tid & 7, kbk = kg >> 2, qq = kg & 1, hfk = (kg >> 1) & 1, px = 8 * pg;
-#ifndef F16_A_QT   // [k-step][32-pixel block][q][k-half]..: a lane's two halves of a fragment are 512 B apart and pair up into ONE
-      // two-address read whose registers are the fragment (with q outside the block the pairs were (block 0, block 1): six moves per k-step)
+      // [k-step][32-pixel block][q][k-half]..: a lane's two halves of a fragment are 512 B apart and pair up into ONE two-address
+      // read whose registers are the fragment (with q outside the block the pairs were (block 0, block 1): six moves per k-step)
       _Float16 *d = dst + (((((kbk * 2 + (px >> 5)) * 2 + qq) * 2 + hfk) * 32 + (px & 31)) * 4);
-#else
-      _Float16 *d = dst + (((((kbk * 2 + qq) * 2 + (px >> 5)) * 2 + hfk) * 32 + (px & 31)) * 4);
-#endif
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         half4 o;
@@ -829,13 +827,8 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       half8 a[2];
 #pragma unroll
       for (int t = 0; t < 2; t++) {
-#ifndef F16_A_QT
         const _Float16 *fp = Ab + ((((ks * 2 + t) * 2 + 0) * 2 + (lane >> 5)) * 32 + l31) * 4;
         const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 32 * 4);
-#else
-        const _Float16 *fp = Ab + ((((ks * 2 + 0) * 2 + t) * 2 + (lane >> 5)) * 32 + l31) * 4;
-        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 2 * 32 * 4);
-#endif
 #pragma unroll
         for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
       }
