@@ -856,6 +856,7 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
         for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
         *reinterpret_cast<half4 *>(T + (i * 32 + l31) * PITCH + r * RP + 32 * hf + 8 * rq + 4 * (lane >> 5)) = v;
       }
+#ifdef F16_L0_DIAGONAL
     if (hf == 0 && lane < 32) {   // columns 0..3 once more behind column 63: a store lane's diagonal reads never wrap inside a quad
 #pragma unroll
       for (int i = 0; i < 2; i++) {
@@ -864,6 +865,7 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
         for (int k = 0; k < 4; k++) wr[k] = (_Float16)acc[i][k];
       }
     }
+#endif
     lds_barrier();
     F16_STAMP(4);
     if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));
@@ -874,7 +876,47 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
     const int ybase = 4 * tyi, xbase = 16 * txi;
     const int qx0 = xbase + 4 * (q & 3), qy = ybase + rr;
     // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod 64]; the quads of tile row rr take the target
-    // row (r + rr) mod 8 of the tile (whole lines per store instruction, see the kernel above); this wave: dx = 32 hf .. 32 hf + 31
+    // row (r + rr) mod 8 of the tile (whole lines per store instruction, see the kernel above); this wave: dx = 32 hf .. 32 hf + 31.
+    // A lane owns EIGHT consecutive offsets D0 .. D0 + 7 (D0 = 32 hf + 8 g) of its quad's four pixels: pixel u's values for them are
+    // the tile columns base + u + j, base = (x0 + D0) mod 64 a multiple of 4 -- three ALIGNED 8-byte reads per pixel (two for pixel
+    // 0; blocks of four columns never straddle the row's end, so no wrap columns), and store j's quad is picked out of the 22
+    // registers by two byte permutes.  (Until the round's last sessions: sixteen 2-byte reads along the diagonal per four stores --
+    // 32 instead of 11 LDS instructions per lane and strip; the LDS pipe was the busiest unit of this phase.)
+#ifndef F16_L0_DIAGONAL
+    {
+      const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
+      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+      const int D0 = 32 * hf + 8 * g;
+      int dy = tyq - qy;
+      dy += (dy < 0) ? h2 : 0;
+      const unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)D0) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      const int base = (qx0 + D0) & (W2 - 1);
+      const _Float16 *lb = T + q4 * PITCH + wrow * RP;
+      typedef unsigned u2v __attribute__((ext_vector_type(2)));
+      u2v R[4][3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int col = (base + 4 * k) & (W2 - 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (u + 7 >= 4 * k) R[u][k] = *reinterpret_cast<const u2v *>(lb + u * PITCH + col);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        // element e = u + j of pixel u's twelve halves: dword (e >> 1) of its three reads, half e & 1
+        const unsigned hA = (unsigned)(j & 1), hB = (unsigned)((j + 1) & 1);
+        const unsigned sel = (2u * hA) | ((2u * hA + 1u) << 8) | ((4u + 2u * hB) << 16) | ((5u + 2u * hB) << 24);
+        u2v d;
+        d.x = __builtin_amdgcn_perm(R[1][(j + 1) >> 2][((j + 1) >> 1) & 1], R[0][j >> 2][(j >> 1) & 1], sel);
+        d.y = __builtin_amdgcn_perm(R[3][(j + 3) >> 2][((j + 3) >> 1) & 1], R[2][(j + 2) >> 2][((j + 2) >> 1) & 1], sel);
+#ifndef F16_ABLATE_L0
+        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, (unsigned)j * plane_bytes, FB_STORE_AUX);
+#else
+        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff | OOR, (unsigned)j * plane_bytes, FB_STORE_AUX);
+#endif
+      }
+    }
+#else
     {
       const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
       const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
@@ -909,6 +951,7 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
         }
       }
     }
+#endif
     F16_STAMP(6);
     // ---- levels 1..3: threads 0..511 pool one 8 x 8 block each (from the ROUNDED level below each time) into the pooled region
     if (tid < 512) {
