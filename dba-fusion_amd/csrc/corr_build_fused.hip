@@ -714,6 +714,7 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
       }
     }
   };
+  request_a(s_begin);   // (in flight while the target fragments below are fetched and transposed)
   // ---- this wave's target fragments, resident for the whole walk: 32 targets x 128 channels ------------------------------------
   half8 bres[KSL];
   {
@@ -734,7 +735,6 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
 #pragma unroll
     for (int ks = 0; ks < KSL; ks++) asm volatile("" : "+v"(bres[ks]));   // (pinned: not re-read per strip)
   }
-  request_a(s_begin);
   stage_a(Ab0);
   F16_STAMP(0);
 

@@ -34,6 +34,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_IDENTITY_SLOTS = {}
+
+
+def _identity_slots(n, device):
+    """arange(n) as the slot table of a freshly built block, one tensor per (device, n): slot tables are only ever REPLACED
+    (cat / index / compaction make new tensors), never written in place, so blocks can share it -- a launch less per
+    CorrBlock(...), which the motion filter constructs once per frame (motion_filter.py:74-76)"""
+    key = (device.type, device.index, n)
+    t = _IDENTITY_SLOTS.get(key)
+    if t is None:
+        if len(_IDENTITY_SLOTS) > 256:
+            _IDENTITY_SLOTS.clear()
+        t = _IDENTITY_SLOTS[key] = torch.arange(n, dtype=torch.int32, device=device)
+    return t
+
+
 class CorrBlock:
     """layout="sheared" (default when the shapes allow it) keeps every level flow-aligned,
     Vs_l[slot, dy, dx, pixel] with pixel = y1 * w1 + x1 and the pixel axis padded to a multiple of 64
@@ -90,7 +106,7 @@ class CorrBlock:
             self.h1, self.w1 = (int(x) for x in (hw if hw is not None else (self.h2, self.w2)))
         self._capacity_hint, self._pending = 0, None
         self._stores = [v if v.is_contiguous() else v.contiguous() for v in levels]
-        self._slots = torch.arange(self.n, dtype=torch.int32, device=v0.device)
+        self._slots = _identity_slots(self.n, v0.device)
         self._slots_host, self._identity = list(range(self.n)), True
         self.stats = dict(built_edges=0, copied_edges=0, grown=0)
         return self
@@ -116,10 +132,14 @@ class CorrBlock:
         f1, f2 = self._take_pending()
         cap = max(self.n, self._capacity_hint)
         dev = f1.device
-        self._stores = [torch.empty(self._level_shape(l, cap), dtype=torch.float16, device=dev)
-                        for l in range(self.num_levels)]
+        if self.layout == "sheared":
+            hw1p = _lib.load().dba_corr_sheared_plane_elems(self.h1, self.w1)
+            shapes = [(cap, self.h2 >> l, self.w2 >> l, hw1p) for l in range(self.num_levels)]
+        else:
+            shapes = [self._level_shape(l, cap) for l in range(self.num_levels)]
+        self._stores = [torch.empty(sh, dtype=torch.float16, device=dev) for sh in shapes]
         self._slots_host = list(range(self.n))
-        self._slots = torch.arange(self.n, dtype=torch.int32, device=dev)
+        self._slots = _identity_slots(self.n, dev)
         self._identity = (cap == self.n)
         self._build_into(f1, f2, None)
 
@@ -142,8 +162,12 @@ class CorrBlock:
         n = batch * num
         if n == 0:
             return
-        f1 = fmap1.reshape(n, dim, h1, w1).to(torch.float16).contiguous()
-        f2 = fmap2.reshape(n, dim, self.h2, self.w2).to(torch.float16).contiguous()
+        f1 = fmap1.reshape(n, dim, h1, w1)
+        f2 = fmap2.reshape(n, dim, self.h2, self.w2)
+        if f1.dtype != torch.float16 or not f1.is_contiguous():   # (the usual case -- half maps as the encoder left them -- costs no
+            f1 = f1.to(torch.float16).contiguous()                #  torch call beyond the view: this path runs once per frame)
+        if f2.dtype != torch.float16 or not f2.is_contiguous():
+            f2 = f2.to(torch.float16).contiguous()
         sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, self.h2, self.w2)
         scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)
         self.stats["built_edges"] += n
