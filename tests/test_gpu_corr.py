@@ -147,6 +147,50 @@ def test_fused_sheared_build_equals_unfused_pipeline(shape):
         assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (lvl, (a != b).mean())
 
 
+@pytest.mark.parametrize("n,h", [(1, 64), (5, 64), (3, 8), (2, 40), (7, 24), (33, 16), (2, 48)])
+def test_sixteen_wave_build_every_walk_length_and_into_slots(n, h):
+    """the sixteen-wave strip walk (C = 128, 64-wide maps whose planes are tiled: corr_build_fused16_kernel) at the walk lengths its
+    launch heuristic produces -- one edge (two strips per workgroup), walks that end early (the last workgroup of a row tile
+    holds fewer strips), one row tile (h = 8), more edges than one round of workgroups -- bit for bit against the unfused
+    pipeline; then the same edges built INTO THE SLOTS of a standing block (holes in arbitrary order): every slot's planes equal
+    the fresh build's, untouched slots keep their bytes"""
+    from dbaf_amd.corr import CorrBlock
+    C, w = 128, 64
+    rng = np.random.default_rng(100 + n + h)
+    t1 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    t2 = torch.from_numpy(rng.standard_normal((1, n, C, h, w)).astype(np.float16)).cuda()
+    fused = CorrBlock.build_sheared_fused(t1, t2, 4)
+    unfused = CorrBlock.shear_pyramid(CorrBlock.build_pyramid(t1, t2, 4))
+    for lvl in range(4):
+        a = CorrBlock.map_pixels(fused[lvl], h, w).contiguous().view(torch.int16)
+        b = CorrBlock.map_pixels(unfused[lvl], h, w).contiguous().view(torch.int16)
+        assert torch.equal(a, b), lvl
+    # a standing block of n + 3 old edges; drop n of them (every second one first), cat the new ones into the holes
+    m = n + 3
+    o1 = torch.from_numpy(rng.standard_normal((1, m, C, h, w)).astype(np.float16)).cuda()
+    o2 = torch.from_numpy(rng.standard_normal((1, m, C, h, w)).astype(np.float16)).cuda()
+    blk = CorrBlock(o1, o2, capacity=m + 1).build()
+    old = [s.clone() for s in blk._stores]
+    drop = np.zeros(m, bool)
+    drop[rng.permutation(m)[:n]] = True
+    keep = torch.from_numpy(~drop).cuda()
+    blk = blk[keep].cat(CorrBlock(t1, t2))
+    assert blk.stats["copied_edges"] == 0 and blk.stats["grown"] == 0
+    slots = blk._slots.cpu().numpy()
+    assert len(set(slots.tolist())) == 3 + n
+    kept_old = np.flatnonzero(~drop)
+    for lvl in range(4):
+        st = blk._stores[lvl].view(torch.int16)
+        for k in range(3):                                   # the surviving old edges: same slot, same bytes
+            assert slots[k] == kept_old[k]
+            assert torch.equal(st[slots[k]], old[lvl].view(torch.int16)[kept_old[k]])
+        for e in range(n):                                   # the new edges, wherever they landed
+            assert torch.equal(CorrBlock.map_pixels(st[slots[3 + e]][None], h, w), CorrBlock.map_pixels(fused[lvl][e][None].view(torch.int16), h, w)), (lvl, e)
+        free = sorted(set(range(m + 1)) - set(slots.tolist()))
+        assert free == [m]                                    # the spare slot was never written
+        assert torch.equal(st[m], old[lvl].view(torch.int16)[m])
+
+
 def test_sheared_volume_is_a_permutation_of_the_reference_volume():
     from dbaf_amd.corr import CorrBlock
     rng = np.random.default_rng(6)
