@@ -637,9 +637,6 @@ __global__ __launch_bounds__(512, LOOP ? 2 : ((NT <= 2) ? 4 : 2)) void corr_buil
 // order: bit-identical to the eight-wave walk.
 // Restricted to what the headline shapes are: tiled planes (h1 % 4 == 0, w1 % 64 == 0), w2 == 64, h2 % 8 == 0, C == 128, maps whose
 // 16-byte pieces are aligned; everything else keeps the kernel above.
-#ifndef F16_L0_LOW
-#define F16_L0_LOW 2
-#endif
 __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
                                                                   FusedLevels L, int h1, int w1, int h2, int HW1p, int strips_per_wg,
                                                                   const int *__restrict__ oslots
@@ -740,6 +737,56 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
 
   constexpr unsigned OOR = 0x80000000u;
   const int q = lane & 15, g = lane >> 4, q4 = 4 * q, rr = q >> 2;   // the lane's quad of pixels: tile row rr, columns 4 (q & 3) ..
+  // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod 64]; the quads of tile row rr take the target
+  // row (r + rr) mod 8 of the tile (whole lines per store instruction, see the kernel above); this wave: dx = 32 hf .. 32 hf + 31.
+  // A lane owns EIGHT consecutive offsets D0 .. D0 + 7 (D0 = 32 hf + 8 g) of its quad's four pixels: pixel u's values for them are
+  // the tile columns base + u + j, base = (x0 + D0) mod 64 a multiple of 4 -- three ALIGNED 8-byte reads per pixel (two for pixel
+  // 0; blocks of four columns never straddle the row's end, so no wrap columns), and store j's quad is picked out of the 22
+  // registers by two byte permutes.  (Until the round's last sessions: sixteen 2-byte reads along the diagonal per four stores --
+  // 32 instead of 11 LDS instructions per lane and strip; the LDS pipe was the busiest unit of this phase.)
+  // -DF16_L0_SPLIT (measured, slower: 13.8-14.4 against 12.3-13.6 us per edge on one box): the two waves of a target row split the
+  // strip's level-0 stores in TIME as well -- the waves that pool (hf == 0) right behind the tile write, their partners in the NEXT
+  // strip's product phase, in front of their matrix instructions (the tile stays valid until that strip's tile write): the product
+  // phase grows by what the phase behind the tile write loses (profiles/r06_build16.txt, item 5).
+  auto level0_stores = [&](int strip) {
+    const int p0 = strip * 64;
+    const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
+    const int ybase = 4 * tyi, xbase = 16 * txi;
+    const int qx0 = xbase + 4 * (q & 3), qy = ybase + rr;
+    {
+      const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
+      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+      const int D0 = 32 * hf + 8 * g;
+      int dy = tyq - qy;
+      dy += (dy < 0) ? h2 : 0;
+      const unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)D0) * plane_bytes + 2u * (unsigned)(p0 + q4);
+      const int base = (qx0 + D0) & (W2 - 1);
+      const _Float16 *lb = T + q4 * PITCH + wrow * RP;
+      typedef unsigned u2v __attribute__((ext_vector_type(2)));
+      u2v R[4][3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int col = (base + 4 * k) & (W2 - 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (u + 7 >= 4 * k) R[u][k] = *reinterpret_cast<const u2v *>(lb + u * PITCH + col);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        // element e = u + j of pixel u's twelve halves: dword (e >> 1) of its three reads, half e & 1
+        const unsigned hA = (unsigned)(j & 1), hB = (unsigned)((j + 1) & 1);
+        const unsigned sel = (2u * hA) | ((2u * hA + 1u) << 8) | ((4u + 2u * hB) << 16) | ((5u + 2u * hB) << 24);
+        u2v d;
+        d.x = __builtin_amdgcn_perm(R[1][(j + 1) >> 2][((j + 1) >> 1) & 1], R[0][j >> 2][(j >> 1) & 1], sel);
+        d.y = __builtin_amdgcn_perm(R[3][(j + 3) >> 2][((j + 3) >> 1) & 1], R[2][(j + 2) >> 2][((j + 2) >> 1) & 1], sel);
+#ifndef F16_ABLATE_L0
+        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, (unsigned)j * plane_bytes, FB_STORE_AUX);
+#else
+        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff | OOR, (unsigned)j * plane_bytes, FB_STORE_AUX);
+#endif
+      }
+    }
+  };
   // ---- levels 1..3 of a strip from the pooled region, behind the strip's pooling and a barrier.  -DF16_DEFER (measured, not faster:
   // 13.3-13.9 against 13.0-13.4 us per edge at 64x64, profiles/r06_build16.txt) issues the stores of strip s in strip s + 1's product
   // phase instead -- half of the waves in front of their matrix instructions, half behind them -- with the next strip's first
@@ -803,11 +850,13 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
     }
   };
   for (int strip = s_begin; strip < s_end; strip++) {
-    const int p0 = strip * 64;
     _Float16 *Ab = Ab0 + ((strip - s_begin) & 1) * (64 * 128);
     if (strip + 1 < s_end) request_a(strip + 1);   // consumed behind the tile write, BEFORE this strip's stores are issued
     lds_barrier();
     F16_STAMP(1);
+#ifdef F16_L0_SPLIT
+    if (hf == 1 && strip > s_begin) level0_stores(strip - 1);
+#endif
 #ifdef F16_DEFER
 #ifndef F16_DEFER_SPLIT
 #define F16_DEFER_SPLIT 1   // 0: every wave in front of its matrix instructions, 2: every wave behind them (A/B builds)
@@ -856,101 +905,15 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
         for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
         *reinterpret_cast<half4 *>(T + (i * 32 + l31) * PITCH + r * RP + 32 * hf + 8 * rq + 4 * (lane >> 5)) = v;
       }
-#ifdef F16_L0_DIAGONAL
-    if (hf == 0 && lane < 32) {   // columns 0..3 once more behind column 63: a store lane's diagonal reads never wrap inside a quad
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        _Float16 *wr = T + (i * 32 + l31) * PITCH + r * RP + W2;
-#pragma unroll
-        for (int k = 0; k < 4; k++) wr[k] = (_Float16)acc[i][k];
-      }
-    }
-#endif
     lds_barrier();
     F16_STAMP(4);
     if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));
     F16_STAMP(5);
 
-    // ---- the strip's pixels: tile (tyi, txi) of the map; the lane's quad on tile row rr --------------------------------------
-    const int tyi = strip / tiles_x, txi = strip - tyi * tiles_x;
-    const int ybase = 4 * tyi, xbase = 16 * txi;
-    const int qx0 = xbase + 4 * (q & 3), qy = ybase + rr;
-    // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod 64]; the quads of tile row rr take the target
-    // row (r + rr) mod 8 of the tile (whole lines per store instruction, see the kernel above); this wave: dx = 32 hf .. 32 hf + 31.
-    // A lane owns EIGHT consecutive offsets D0 .. D0 + 7 (D0 = 32 hf + 8 g) of its quad's four pixels: pixel u's values for them are
-    // the tile columns base + u + j, base = (x0 + D0) mod 64 a multiple of 4 -- three ALIGNED 8-byte reads per pixel (two for pixel
-    // 0; blocks of four columns never straddle the row's end, so no wrap columns), and store j's quad is picked out of the 22
-    // registers by two byte permutes.  (Until the round's last sessions: sixteen 2-byte reads along the diagonal per four stores --
-    // 32 instead of 11 LDS instructions per lane and strip; the LDS pipe was the busiest unit of this phase.)
-#ifndef F16_L0_DIAGONAL
-    {
-      const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
-      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
-      const int D0 = 32 * hf + 8 * g;
-      int dy = tyq - qy;
-      dy += (dy < 0) ? h2 : 0;
-      const unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)D0) * plane_bytes + 2u * (unsigned)(p0 + q4);
-      const int base = (qx0 + D0) & (W2 - 1);
-      const _Float16 *lb = T + q4 * PITCH + wrow * RP;
-      typedef unsigned u2v __attribute__((ext_vector_type(2)));
-      u2v R[4][3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int col = (base + 4 * k) & (W2 - 1);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (u + 7 >= 4 * k) R[u][k] = *reinterpret_cast<const u2v *>(lb + u * PITCH + col);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        // element e = u + j of pixel u's twelve halves: dword (e >> 1) of its three reads, half e & 1
-        const unsigned hA = (unsigned)(j & 1), hB = (unsigned)((j + 1) & 1);
-        const unsigned sel = (2u * hA) | ((2u * hA + 1u) << 8) | ((4u + 2u * hB) << 16) | ((5u + 2u * hB) << 24);
-        u2v d;
-        d.x = __builtin_amdgcn_perm(R[1][(j + 1) >> 2][((j + 1) >> 1) & 1], R[0][j >> 2][(j >> 1) & 1], sel);
-        d.y = __builtin_amdgcn_perm(R[3][(j + 3) >> 2][((j + 3) >> 1) & 1], R[2][(j + 2) >> 2][((j + 2) >> 1) & 1], sel);
-#ifndef F16_ABLATE_L0
-        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, (unsigned)j * plane_bytes, FB_STORE_AUX);
+#ifndef F16_L0_SPLIT
+    level0_stores(strip);
 #else
-        __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff | OOR, (unsigned)j * plane_bytes, FB_STORE_AUX);
-#endif
-      }
-    }
-#else
-    {
-      const int wrow = (r + rr) & (FT_ROWS - 1), tyq = ty0 + wrow;
-      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
-      // (the waves that also pool -- hf == 0 -- take F16_L0_LOW of the row's four batches of 16 offsets, their partners the rest)
-      const int bt0 = hf ? F16_L0_LOW : 0, bt1 = hf ? 4 : F16_L0_LOW;
-      int t = (qx0 + 16 * bt0 + g) & (W2 - 1);
-      int dy = tyq - qy;
-      dy += (dy < 0) ? h2 : 0;
-      unsigned voff = ((unsigned)dy * (unsigned)W2 + (unsigned)(16 * bt0 + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
-      const _Float16 *lb = T + q4 * PITCH + wrow * RP;
-      for (int bt = bt0; bt < bt1; bt++) {  // four lines per store instruction, four instructions per batch: 16 LDS reads in flight
-        unsigned short a[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const _Float16 *pp = lb + t;
-#pragma unroll
-          for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
-          t = (t + 4) & (W2 - 1);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          typedef unsigned u2v __attribute__((ext_vector_type(2)));
-          u2v d;
-          d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
-          d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
-#ifndef F16_ABLATE_L0
-          __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff, 0, FB_STORE_AUX);
-#else
-          __builtin_amdgcn_raw_buffer_store_b64(d, r0, voff | OOR, 0, FB_STORE_AUX);
-#endif
-          voff += 4u * plane_bytes;
-        }
-      }
-    }
+    if (hf == 0) level0_stores(strip);
 #endif
     F16_STAMP(6);
     // ---- levels 1..3: threads 0..511 pool one 8 x 8 block each (from the ROUNDED level below each time) into the pooled region
@@ -998,6 +961,9 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
     (void)OOR;
     F16_STAMP(9);
   }
+#ifdef F16_L0_SPLIT
+  if (hf == 1) level0_stores(s_end - 1);   // (nothing has touched the last strip's tile)
+#endif
 #ifdef F16_DEFER
   lds_barrier();
   pooled_stores(s_end - 1);

@@ -35,6 +35,19 @@ def _stream():
 
 
 _IDENTITY_SLOTS = {}
+_BUILD_SCRATCH = {}
+
+
+def _build_scratch(nbytes, device):
+    """the volume build's scratch (the k-block-major copies of maps it cannot read as they lie), kept per (device, stream) and
+    only ever grown: builds on one stream are ordered, so they can share it -- an allocation less per build"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _BUILD_SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        if len(_BUILD_SCRATCH) > 64:
+            _BUILD_SCRATCH.clear()
+        t = _BUILD_SCRATCH[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    return t
 
 
 def _identity_slots(n, device):
@@ -169,7 +182,7 @@ class CorrBlock:
         if f2.dtype != torch.float16 or not f2.is_contiguous():
             f2 = f2.to(torch.float16).contiguous()
         sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, h1, w1, self.h2, self.w2)
-        scratch = torch.empty(max(sbytes, 1), dtype=torch.uint8, device=f1.device)
+        scratch = _build_scratch(sbytes, f1.device)
         self.stats["built_edges"] += n
         if self.layout == "sheared" and lib.dba_corr_volume_build_sheared_supported(dim, h1, w1, self.h2, self.w2,
                                                                                     self.num_levels):
