@@ -1064,16 +1064,35 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
 #define FB_PROF_ARG
 #endif
   if (loop_form) {
-    // strips per workgroup: as many as leave ~256 workgroups (ONE round of the 256 CUs: a workgroup's prologue -- its waves' target
-    // fragments, 128 KB -- costs ~11 us against ~7 per strip, so two rounds of short walks pay it twice: a one-edge build, the
-    // motion filter's, was 36 us at 512 workgroups of one strip; round 6), at most 16
+    // strips per workgroup (at most 16).  One workgroup per CU (LDS), so the launch runs in ceil(workgroups / 256) rounds, each as
+    // long as a walk: spw strips + the prologue (the waves' target fragments, 128 KB per workgroup: ~1.5 strips' worth).  Pick the
+    // spw that minimises rounds x (spw + 1.5).  (Until the round's last session: as many as leave ~256 workgroups, capped -- right
+    // for one edge (two strips, one round: 36 -> 28 us against 512 workgroups of one strip) and for 32 edges at 64x64 (4 rounds of
+    // 16), but 32 edges at 48x64 ran 2.25 rounds of 16 strips where 3 rounds of 12 do, and a six-edge build two rounds of 12 where
+    // one round of 16 does.)  DBA_BUILD_WG_TARGET=<n> keeps the old rule with n workgroups as its aim (A/B runs).
     const int nstrips = HW1p / 64;
     const long long rows = (long long)grid.y * n;
-    static const int wg_target = [] { const char *e = getenv("DBA_BUILD_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-    int spw = (int)(((long long)nstrips * rows + wg_target - 1) / wg_target);
+    static const int wg_target = [] { const char *e = getenv("DBA_BUILD_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
     static const int spw_cap = [] { const char *e = getenv("DBA_BUILD_SPW_CAP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
-    spw = spw < 1 ? 1 : (spw > spw_cap ? spw_cap : spw);
+    int spw;
+    if (wg_target > 0) {
+      spw = (int)(((long long)nstrips * rows + wg_target - 1) / wg_target);
+      spw = spw < 1 ? 1 : (spw > spw_cap ? spw_cap : spw);
+    } else {
+      spw = 1;
+      double best = 1e300;
+      for (int c = 1; c <= spw_cap && c <= nstrips; c++) {
+        const long long wgs = (long long)((nstrips + c - 1) / c) * rows;
+        // (a last round that is partly empty is cheaper than a full one -- the walk is half chain, half memory traffic --: the
+        // mean of whole and fractional rounds matches the measured picks, profiles/r06_build16.txt item 7)
+        const double rounds = 0.5 * (double)((wgs + 255) / 256) + 0.5 * ((double)wgs / 256.0 < 1.0 ? 1.0 : (double)wgs / 256.0);
+        const double cost = rounds * ((double)c + 1.5);
+        if (cost <= best) best = cost, spw = c;   // (ties: the longer walk -- fewer prologues in total)
+      }
+    }
     if (force == 2 && spw < 2) spw = 2;
+    static const bool spw_dbg = getenv("DBA_BUILD_DEBUG") != nullptr;
+    if (spw_dbg) fprintf(stderr, "build: n=%d nstrips=%d rows=%lld spw=%d\n", n, nstrips, rows, spw);
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
     // sixteen waves per workgroup on the shapes the headline runs on (DBA_BUILD_WAVES=8 keeps the eight-wave walk: A/B runs)
