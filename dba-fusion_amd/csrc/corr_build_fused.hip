@@ -977,6 +977,346 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
 #endif
 }
 
+// =====================================================================================================================
+// The sixteen-wave strip walk for the maps whose planes keep the LINEAR pixel order (round 6, last session): 32 < w2 <= 64,
+// C = 128, any h2 -- 55 x 55 is what the reference's TUM-VI demo runs on (512 x 512 resized to 440 x 440,
+// demo_vio_tumvi.py:55-60).  Same work split as corr_build_fused16_kernel (a target row shared by two waves, four waves per SIMD,
+// tile + two operand buffers + pooled region in LDS), same arithmetic in the same order as the eight-wave walk
+// (corr_build_fused_kernel<2, true>): bit-identical to it.  What differs from the tiled form: a strip is 64 consecutive pixels of
+// the flattened map and may span a row end (quads that do are stored by the whole wave, sixteen offsets per instruction), the map
+// width is not a power of two (wraps by compare-and-subtract, the tile's wrap columns sit behind column w2 - 1), the last row
+// tile may be partial, and the operands are the k-block-major copies (16-byte pieces of the caller's maps are not aligned at these
+// widths).  The two waves of a row split the offsets dx of the level-0 lines in halves (batches of four lines).
+__global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
+                                                                   FusedLevels L, int h1, int w1, int h2, int w2, int HW1p,
+                                                                   float inv_w1, int strips_per_wg, const int *__restrict__ oslots
+#ifdef F16_PROF
+                                                                   , unsigned long long *prof
+#endif
+                                                                   ) {
+  constexpr int C = 128, W2P = 64, KSL = 8;
+#ifdef F16_PROF   // scratch builds: time per phase of the walk, summed per wave (s_memtime ticks; F16_STAMP: see the kernel above)
+  unsigned long long f16_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, f16_last_ = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int RP = W2P + 4, PITCH = FT_ROWS * RP + 4, RP1 = W2P / 2 + 4;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  _Float16 *T = smem;                          // [64][PITCH]   level 0 of the current strip, rounded
+  _Float16 *Ab0 = smem + 64 * PITCH;           // two source-operand buffers of 16 KB
+  _Float16 *P1 = Ab0 + 2 * 64 * 128;           // [64][4][RP1]  pooled levels of the current strip
+  _Float16 *P2 = P1 + 64 * 4 * RP1;            // [64][2][16]
+  _Float16 *P3 = P2 + 64 * 2 * (W2P / 4);      // [64][8]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = wave & 7, hf = wave >> 3;      // this wave's target row of the tile, its half of the row's targets
+  const int ty0 = blockIdx.y * FT_ROWS, e = blockIdx.z;
+  const int HW1 = h1 * w1, HW2 = h2 * w2;
+  const int l31 = lane & 31, kh = (lane >> 5) * 8;
+  const int nstrips = HW1p >> 6;
+  const int s_begin = blockIdx.x * strips_per_wg, s_end = min(nstrips, s_begin + strips_per_wg);
+  if (s_begin >= s_end) return;   // (workgroup-uniform)
+  const int eo = oslots ? oslots[e] : e;
+  auto level_rsrc = [&](int lvl) {
+    const size_t elems = (size_t)(h2 >> lvl) * (w2 >> lvl) * HW1p;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)eo * elems), 0, (int)(2 * elems), 0x00020000);
+  };
+  const unsigned plane_bytes = 2u * (unsigned)HW1p;
+  constexpr unsigned OOR = 0x80000000u;
+
+  // ---- source operand of a strip: 1024 pieces of 16 bytes ([k-block][pixel][half of the 16 channels]), one per thread ----------
+  half8 apre;
+  const int a_kbk = tid >> 7, a_px = (tid & 127) >> 1, a_hf = tid & 1;
+  auto request_a = [&](int strip) {
+    apre = *reinterpret_cast<const half8 *>(A + (size_t)e * HW1 * C + ((size_t)a_kbk * HW1 + min(strip * 64 + a_px, HW1 - 1)) * 16 + a_hf * 8);
+  };
+  auto stage_a = [&](_Float16 *dst) {   // -> LDS, fragment layout [k-step][32-pixel block][q][k-half][pixel][4 halves]
+    const int fa = ((((a_kbk * 2 + (a_px >> 5)) * 2 + 0) * 2 + a_hf) * 32 + (a_px & 31)) * 4;
+    half4 lo, hi;
+#pragma unroll
+    for (int c = 0; c < 4; c++) lo[c] = apre[c], hi[c] = apre[4 + c];
+    *reinterpret_cast<half4 *>(dst + fa) = lo;
+    *reinterpret_cast<half4 *>(dst + fa + 2 * 32 * 4) = hi;
+  };
+  request_a(s_begin);
+  // ---- this wave's target fragments, resident for the whole walk: 32 targets x 128 channels (rows past the map: a valid row,
+  // never stored; targets past the row's end: the next row's, never stored) ----------------------------------------------------
+  half8 bres[KSL];
+  {
+    const int ty = min(ty0 + r, h2 - 1);
+    const _Float16 *bpt = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + 32 * hf + l31, HW2 - 1) * 16 + kh;
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) bres[ks] = *reinterpret_cast<const half8 *>(bpt + (size_t)ks * 16 * HW2);
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) asm volatile("" : "+v"(bres[ks]));   // (pinned: not re-read per strip)
+  }
+  stage_a(Ab0);
+  F16_STAMP(0);
+
+  const int q4 = (lane & 15) * 4, g = lane >> 4;     // the lane's quad of pixels and its line of a batch of four
+  const int ipx = lane & 3, idx16 = lane >> 2;       // irregular quads: the lane's pixel of the quad, its offset of sixteen
+  const int nb = (w2 + 3) >> 2, nb0 = (nb + 1) >> 1; // batches of four level-0 lines: [0, nb0) to the row's first wave, the rest to its partner
+  const int b_begin = hf ? nb0 : 0, b_end = hf ? nb : nb0;
+  auto pixel_xy = [&](int pix, int &x, int &y) { sh_pixel_yx(min(pix, HW1 - 1), w1, inv_w1, false, y, x); };
+
+  for (int strip = s_begin; strip < s_end; strip++) {
+    const int p0 = strip * 64;
+    _Float16 *Ab = Ab0 + ((strip - s_begin) & 1) * (64 * 128);
+    if (strip + 1 < s_end) request_a(strip + 1);   // consumed behind the tile write, BEFORE this strip's stores are issued
+    lds_barrier();
+    F16_STAMP(1);
+
+    // ---- products: acc[i] = 32 x 32 tile (targets 32 hf .., sources 32 i ..) of target row ty0 + r -----------------------------
+    float16v acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[i][k] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) {
+      half8 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const _Float16 *fp = Ab + ((((ks * 2 + t) * 2 + 0) * 2 + (lane >> 5)) * 32 + l31) * 4;
+        const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 32 * 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bres[ks], a[i], acc[i], 0, 0, 0);  // targets x sources
+    }
+    F16_STAMP(2);
+    lds_barrier();  // every wave is done with the source operand and with the previous strip's tile
+    F16_STAMP(3);
+    // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target).  Columns from
+    // w2 on belong to the wrap copy below (written by the row's OTHER wave): the targets past the row's end are not written.
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        const int tx = 32 * hf + 8 * rq + 4 * (lane >> 5);
+        _Float16 *dst = T + (i * 32 + l31) * PITCH + r * RP + tx;
+        if (tx + 4 <= w2) {
+          half4 v;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
+          *reinterpret_cast<half4 *>(dst) = v;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (tx + k < w2) dst[k] = (_Float16)acc[i][4 * rq + k];
+        }
+      }
+    // columns 0..3 once more behind column w2 - 1: a store lane's four diagonal reads then never wrap inside a quad
+    if (hf == 0 && lane < 32) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        _Float16 *wr = T + (i * 32 + l31) * PITCH + r * RP + w2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wr[k] = (_Float16)acc[i][k];
+      }
+    }
+    lds_barrier();
+    F16_STAMP(4);
+    if (strip + 1 < s_end) stage_a(Ab0 + ((strip + 1 - s_begin) & 1) * (64 * 128));
+    F16_STAMP(5);
+
+    // ---- the lane's quad of pixels (levels 0, 1) and the strip's irregular quads -----------------------------------------------
+    int qx0, qy0, qx3, qy3;
+    pixel_xy(p0 + q4, qx0, qy0);
+    pixel_xy(p0 + q4 + 3, qx3, qy3);
+    const bool quad_regular = (p0 + q4 + 3 < HW1) && (qy0 == qy3);
+    const unsigned long long irregular = __ballot(!quad_regular && g == 0 && (p0 + q4 < HW1));   // bit = quad index (wave-uniform)
+    // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's target row and half of the dx ----
+    {
+      const int ty = ty0 + r;
+      if (ty < h2) {  // (wave-uniform)
+        const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+        if (quad_regular) {
+          int t = qx0 + g + 4 * b_begin;
+          t -= (t >= w2) ? w2 : 0;
+          t -= (t >= w2) ? w2 : 0;
+          int dy = ty - qy0;
+          dy += (dy < 0) ? h2 : 0;
+          unsigned voff = ((unsigned)dy * (unsigned)w2 + (unsigned)(g + 4 * b_begin)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+          const _Float16 *lb = T + q4 * PITCH + r * RP;
+          for (int b0 = b_begin; b0 < b_end; b0 += 4) {  // four batches at a time: their 16 LDS reads are in flight together
+            unsigned short a[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const _Float16 *pp = lb + t;
+#pragma unroll
+              for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
+              t += 4;
+              t -= (t >= w2) ? w2 : 0;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              typedef unsigned u2v __attribute__((ext_vector_type(2)));
+              u2v d;
+              d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
+              d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
+              __builtin_amdgcn_raw_buffer_store_b64(d, r0, (b0 + b < b_end && 4 * (b0 + b) + g < w2) ? voff : OOR, 0, FB_STORE_AUX);
+              voff += 4u * plane_bytes;
+            }
+          }
+        }
+        for (unsigned long long m = irregular; m; m &= m - 1) {
+          const int pl = 4 * (int)__builtin_ctzll(m) + ipx;  // this lane's pixel of the quad, within the strip
+          int xi, yi;
+          pixel_xy(p0 + pl, xi, yi);
+          const bool pok = p0 + pl < HW1;
+          int dy = ty - yi;
+          dy += (dy < 0) ? h2 : 0;
+          const _Float16 *row = T + pl * PITCH + r * RP;
+          const unsigned vbase = (unsigned)dy * (unsigned)w2 * plane_bytes + 2u * (unsigned)(p0 + pl);
+          for (int dx0 = 32 * hf; dx0 < min(w2, 32 * hf + 32); dx0 += 16) {
+            const int dx = dx0 + idx16;
+            int tx = xi + dx;
+            tx -= (tx >= w2) ? w2 : 0;
+            tx = min(tx, w2 - 1);  // (dx beyond the map in the last group: read something valid, store nothing)
+            const _Float16 v = row[tx];
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r0,
+                                                  (pok && dx < w2) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
+          }
+        }
+      }
+    }
+    F16_STAMP(6);
+    // ---- levels 1..3: threads 0..511 pool one 8 x 8 block each (from the ROUNDED level below each time) into the pooled region
+    if (tid < 512) {
+      const int src = tid >> 3, cb = tid & 7;
+      const _Float16 *tb = T + src * PITCH + 8 * cb;
+      _Float16 t8[8][8], q1[4][4], q2[2][2];
+#pragma unroll
+      for (int rw = 0; rw < 8; rw++) {
+        const half4 lo = *reinterpret_cast<const half4 *>(tb + rw * RP), hi = *reinterpret_cast<const half4 *>(tb + rw * RP + 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) t8[rw][c] = lo[c], t8[rw][4 + c] = hi[c];
+      }
+#pragma unroll
+      for (int rw = 0; rw < 4; rw++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) q1[rw][c] = pool4(t8[2 * rw][2 * c], t8[2 * rw][2 * c + 1], t8[2 * rw + 1][2 * c], t8[2 * rw + 1][2 * c + 1]);
+#pragma unroll
+      for (int rw = 0; rw < 2; rw++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) q2[rw][c] = pool4(q1[2 * rw][2 * c], q1[2 * rw][2 * c + 1], q1[2 * rw + 1][2 * c], q1[2 * rw + 1][2 * c + 1]);
+      const _Float16 q3 = pool4(q2[0][0], q2[0][1], q2[1][0], q2[1][1]);
+      const int w2l = w2 >> 1;
+#pragma unroll
+      for (int rw = 0; rw < 4; rw++) {
+        _Float16 *row1 = P1 + (src * 4 + rw) * RP1;
+        if (4 * cb + 4 <= w2l) {
+          half4 v;
+#pragma unroll
+          for (int c = 0; c < 4; c++) v[c] = q1[rw][c];
+          *reinterpret_cast<half4 *>(row1 + 4 * cb) = v;
+        } else {  // the block that holds column w2l - 1: the columns behind it belong to the copy of block 0
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (4 * cb + c < w2l) row1[4 * cb + c] = q1[rw][c];
+        }
+        if (cb == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) row1[w2l + c] = q1[rw][c];
+        }
+      }
+#pragma unroll
+      for (int rw = 0; rw < 2; rw++) {
+        half2v v;
+        v.x = q2[rw][0], v.y = q2[rw][1];
+        *reinterpret_cast<half2v *>(P2 + (src * 2 + rw) * (W2P / 4) + 2 * cb) = v;
+      }
+      P3[src * (W2P / 8) + cb] = q3;
+    }
+    lds_barrier();
+    F16_STAMP(7);
+    {  // level 1: 4 rows x w2l offsets, four lines per store instruction; wave w takes pooled row w & 3 and the groups of four
+       // offsets (w >> 2) + 4 k.  The quad's columns (x >> 1) - (x0 >> 1) are 0, 0|1, 1, 1|2
+      const int w2l = w2 >> 1, h2l = h2 >> 1;
+      const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
+      const int tyl = wave & 3, grp = wave >> 2, tyg = (ty0 >> 1) + tyl;
+      if (tyg < h2l) {  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
+        if (quad_regular) {
+          const int xh = qx0 >> 1;
+          const int o1 = ((qx0 + 1) >> 1) - xh, o2 = ((qx0 + 2) >> 1) - xh, o3 = ((qx0 + 3) >> 1) - xh;
+          int t = xh + 4 * grp + g;
+          t -= (t >= w2l) ? w2l : 0;
+          t -= (t >= w2l) ? w2l : 0;
+          int dy = tyg - (qy0 >> 1);
+          dy += (dy < 0) ? h2l : 0;
+          unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+          const _Float16 *lb = P1 + (q4 * 4 + tyl) * RP1;
+          for (int dx0 = 4 * grp; dx0 < w2l; dx0 += 16) {
+            const _Float16 *pp = lb + t;
+            const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
+            const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            u2v d;
+            d.x = (unsigned)a0 | ((unsigned)a1 << 16);
+            d.y = (unsigned)a2 | ((unsigned)a3 << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(d, rl, (dx0 + g < w2l) ? voff : OOR, 0, FB_STORE_AUX);
+            voff += 16u * plane_bytes;
+            t += 16;
+            t -= (t >= w2l) ? w2l : 0;
+            t -= (t >= w2l) ? w2l : 0;
+          }
+        }
+        for (unsigned long long m = irregular; m; m &= m - 1) {  // (the four waves of a pooled row take every fourth group of 16 offsets)
+          const int pl = 4 * (int)__builtin_ctzll(m) + ipx;
+          int xi, yi;
+          pixel_xy(p0 + pl, xi, yi);
+          const bool pok = p0 + pl < HW1;
+          int dy = tyg - (yi >> 1);
+          dy += (dy < 0) ? h2l : 0;
+          const _Float16 *row = P1 + (pl * 4 + tyl) * RP1;
+          const unsigned vbase = (unsigned)dy * (unsigned)w2l * plane_bytes + 2u * (unsigned)(p0 + pl);
+          for (int dx0 = 16 * grp; dx0 < w2l; dx0 += 64) {
+            const int dx = dx0 + idx16;
+            int tx = (xi >> 1) + dx;
+            tx -= (tx >= w2l) ? w2l : 0;
+            tx = min(tx, w2l - 1);
+            const _Float16 v = row[tx];
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
+                                                  (pok && dx < w2l) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
+          }
+        }
+      }
+    }
+    {  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
+      const int p = p0 + lane;
+      const bool active = p < HW1;
+      int x1, y1;
+      pixel_xy(p, x1, y1);
+      auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
+        const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+        const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
+        const int x1l = x1 >> lvl, y1l = y1 >> lvl;
+        for (int seg = wave; seg < rows * w2l; seg += 16) {  // (wave-uniform)
+          const int tyl = seg / w2l, dx = seg - tyl * w2l;
+          const int tyg = (ty0 >> lvl) + tyl;
+          if (tyg >= h2l) continue;
+          int dy = tyg - y1l;
+          dy += (dy < 0) ? h2l : 0;
+          int tx = x1l + dx;
+          tx -= (tx >= w2l) ? w2l : 0;
+          const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
+          const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, FB_STORE_AUX);
+        }
+      };
+      store_level(2, P2, 2, W2P / 4);
+      store_level(3, P3, 1, W2P / 8);
+    }
+    F16_STAMP(9);
+  }
+#ifdef F16_PROF
+  if (lane == 0) {
+    unsigned long long *ps = prof + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave) * 12;
+    for (int i = 0; i < 10; i++) ps[i] = f16_acc_[i];
+    ps[10] = (unsigned long long)(s_end - s_begin);
+  }
+#endif
+}
+
 // defined in corr_build.hip
 __global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
 
@@ -1029,7 +1369,13 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     const char *e = getenv("DBA_BUILD_OPERANDS");
     return !e ? 1 : (e[0] == 'c' ? 0 : (e[0] == 'b' ? 2 : 1));
   }();
-  const bool native_b = loop_form && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
+  // sixteen waves per workgroup (DBA_BUILD_WAVES=8 keeps the eight-wave walks: A/B runs); on planes in the linear pixel order: the
+  // general form, on the k-block-major copies
+  static const bool waves16 = [] { const char *e = getenv("DBA_BUILD_WAVES"); return !(e && atoi(e) == 8); }();
+  // (where 16-byte pieces of the maps are aligned -- widths that are multiples of 8 -- the eight-wave walk on the caller's own maps
+  // is as fast or faster: 40 x 56 6.1 against 6.2 us per edge, 30 x 40 2.6 against 2.8; profiles/r06_build_g16.txt)
+  const bool general16 = loop_form && waves16 && !tiled && w2 > 32 && h1 == h2 && w1 == w2 && ((w2 % 8) != 0 || (HW2 % 8) != 0);
+  const bool native_b = loop_form && !general16 && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
   const bool native = native_b && native_mode == 1 && (HW1 % 8 == 0) && (w1 % 8 == 0);
   if (!native)
     hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
@@ -1095,50 +1441,58 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     if (spw_dbg) fprintf(stderr, "build: n=%d nstrips=%d rows=%lld spw=%d\n", n, nstrips, rows, spw);
     const size_t lds = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128);
     const dim3 lgrid((nstrips + spw - 1) / spw, grid.y, n);
-    // sixteen waves per workgroup on the shapes the headline runs on (DBA_BUILD_WAVES=8 keeps the eight-wave walk: A/B runs)
-    static const bool waves16 = [] { const char *e = getenv("DBA_BUILD_WAVES"); return !(e && atoi(e) == 8); }();
-    if (native && tiled && w2 == 64 && (h2 % 8) == 0 && waves16) {
+    const size_t lds16 = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128 +
+                                             (size_t)64 * (4 * (32 + 4) + 2 * 16 + 8));   // tile, two operand buffers, pooled region
+#ifdef F16_PROF
+    static unsigned long long *prof16 = nullptr;
+    const size_t nslots = (size_t)lgrid.x * lgrid.y * lgrid.z * 16;
+    if (!prof16) (void)hipMalloc(&prof16, (size_t)64 << 20);
+    (void)hipMemsetAsync(prof16, 0, nslots * 12 * 8, s);
+#define F16_PROF_ARG , prof16
+    auto f16_prof_dump = [&]() {
+      (void)hipStreamSynchronize(s);
+      unsigned long long *hp = (unsigned long long *)malloc(nslots * 12 * 8);
+      (void)hipMemcpy(hp, prof16, nslots * 12 * 8, hipMemcpyDeviceToHost);
+      static const char *names[10] = {"prologue (per walk)", "operand wait + barrier 1", "products issued", "barrier 2", "tile write + barrier 3",
+                                      "next operand into LDS", "level-0 loop", "pooling (+ barrier 4)", "pooled stores (not deferred)", "pooled stores behind the products"};
+      for (int grp = 0; grp < 2; grp++) {   // waves 0..7 (they also pool; 0..3 stage the operand) and 8..15
+        double ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, strips = 0, waves = 0;
+        for (size_t i = 0; i < nslots; i++) {
+          if ((int)((i & 15) >> 3) != grp || hp[i * 12 + 10] == 0) continue;
+          for (int k = 0; k < 10; k++) ph[k] += (double)hp[i * 12 + k];
+          strips += (double)hp[i * 12 + 10], waves += 1;
+        }
+        fprintf(stderr, "F16_PROF n=%d spw=%d waves %d..%d | ticks per strip and wave:", n, spw, 8 * grp, 8 * grp + 7);
+        double tot = 0;
+        for (int k = 1; k < 10; k++) fprintf(stderr, " %s %.0f,", names[k], ph[k] / strips), tot += ph[k] / strips;
+        fprintf(stderr, " sum %.0f | %s %.0f per wave\n", tot, names[0], ph[0] / waves);
+      }
+      free(hp);
+    };
+#define F16_PROF_DUMP() f16_prof_dump()
+#else
+#define F16_PROF_ARG
+#define F16_PROF_DUMP() (void)0
+#endif
+    if (general16) {
+      static DeviceOnce attr16g_once;
+      if (attr16g_once.needed()) {
+        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16g_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr16g_once.done();
+      }
+      hipLaunchKernelGGL(corr_build_fused16g_kernel, lgrid, dim3(1024), lds16, s, A, Bm, L, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots F16_PROF_ARG);
+      F16_PROF_DUMP();
+    } else if (native && tiled && w2 == 64 && (h2 % 8) == 0 && waves16) {   // the shapes the headline runs on
       static DeviceOnce attr16_once;
       if (attr16_once.needed()) {
         DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr16_once.done();
       }
-      const size_t lds16 = sizeof(_Float16) * ((size_t)64 * (FT_ROWS * (64 + 4) + 4) + (size_t)2 * 64 * 128 +
-                                               (size_t)64 * (4 * (32 + 4) + 2 * 16 + 8));   // tile, two operand buffers, pooled region
-#ifdef F16_PROF
-      static unsigned long long *prof16 = nullptr;
-      const size_t nslots = (size_t)lgrid.x * lgrid.y * lgrid.z * 16;
-      if (!prof16) (void)hipMalloc(&prof16, (size_t)64 << 20);
-      (void)hipMemsetAsync(prof16, 0, nslots * 12 * 8, s);
-#define F16_PROF_ARG , prof16
-#else
-#define F16_PROF_ARG
-#endif
       hipLaunchKernelGGL(corr_build_fused16_kernel, lgrid, dim3(1024), lds16, s, static_cast<const _Float16 *>(fmap1),
                          static_cast<const _Float16 *>(fmap2), L, h1, w1, h2, HW1p, spw, out_slots F16_PROF_ARG);
-#ifdef F16_PROF
-      {
-        (void)hipStreamSynchronize(s);
-        unsigned long long *hp = (unsigned long long *)malloc(nslots * 12 * 8);
-        (void)hipMemcpy(hp, prof16, nslots * 12 * 8, hipMemcpyDeviceToHost);
-        static const char *names[10] = {"prologue (per walk)", "operand wait + barrier 1", "products issued", "barrier 2", "tile write + barrier 3",
-                                        "next operand into LDS", "level-0 loop", "pooling (+ barrier 4)", "pooled stores (not deferred)", "pooled stores behind the products"};
-        for (int grp = 0; grp < 2; grp++) {   // waves 0..7 (they also pool; 0..3 stage the operand) and 8..15
-          double ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, strips = 0, waves = 0;
-          for (size_t i = 0; i < nslots; i++) {
-            if ((int)((i & 15) >> 3) != grp || hp[i * 12 + 10] == 0) continue;
-            for (int k = 0; k < 10; k++) ph[k] += (double)hp[i * 12 + k];
-            strips += (double)hp[i * 12 + 10], waves += 1;
-          }
-          fprintf(stderr, "F16_PROF n=%d spw=%d waves %d..%d | ticks per strip and wave:", n, spw, 8 * grp, 8 * grp + 7);
-          double tot = 0;
-          for (int k = 1; k < 10; k++) fprintf(stderr, " %s %.0f,", names[k], ph[k] / strips), tot += ph[k] / strips;
-          fprintf(stderr, " sum %.0f | %s %.0f per wave\n", tot, names[0], ph[0] / waves);
-        }
-        free(hp);
-      }
-#endif
+      F16_PROF_DUMP();
     } else if (native)
       hipLaunchKernelGGL((corr_build_fused_kernel<2, true, true>), lgrid, dim3(512), lds, s, static_cast<const _Float16 *>(fmap1),
                          static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
