@@ -987,14 +987,19 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
 // width is not a power of two (wraps by compare-and-subtract, the tile's wrap columns sit behind column w2 - 1), the last row
 // tile may be partial, and the operands are the k-block-major copies (16-byte pieces of the caller's maps are not aligned at these
 // widths).  The two waves of a row split the offsets dx of the level-0 lines in halves (batches of four lines).
+// W2C > 0: the map width as a compile-time constant (w1 == w2 == W2C: the wraps, the splits of the lines between the waves and the
+// divisions by the width fold into constants and the store loops unroll); 0: any width at run time.
+template <int W2C>
 __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
-                                                                   FusedLevels L, int h1, int w1, int h2, int w2, int HW1p,
-                                                                   float inv_w1, int strips_per_wg, const int *__restrict__ oslots
+                                                                   FusedLevels L, int h1, int w1_, int h2, int w2_, int HW1p,
+                                                                   float inv_w1_, int strips_per_wg, const int *__restrict__ oslots
 #ifdef F16_PROF
                                                                    , unsigned long long *prof
 #endif
                                                                    ) {
   constexpr int C = 128, W2P = 64, KSL = 8;
+  const int w2 = W2C > 0 ? W2C : w2_, w1 = W2C > 0 ? W2C : w1_;
+  const float inv_w1 = W2C > 0 ? 1.0f / (float)W2C : inv_w1_;
 #ifdef F16_PROF   // scratch builds: time per phase of the walk, summed per wave (s_memtime ticks; F16_STAMP: see the kernel above)
   unsigned long long f16_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, f16_last_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1477,11 +1482,18 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     if (general16) {
       static DeviceOnce attr16g_once;
       if (attr16g_once.needed()) {
-        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16g_kernel),
+        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16g_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16g_kernel<55>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr16g_once.done();
       }
-      hipLaunchKernelGGL(corr_build_fused16g_kernel, lgrid, dim3(1024), lds16, s, A, Bm, L, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots F16_PROF_ARG);
+      // 55 x 55 (the reference's TUM-VI demo, demo_vio_tumvi.py:55-60) has its own instantiation (DBA_BUILD_G16_GENERIC=1: A/B runs)
+      static const bool g16_generic = getenv("DBA_BUILD_G16_GENERIC") != nullptr;
+      if (w2 == 55 && !g16_generic)
+        hipLaunchKernelGGL(corr_build_fused16g_kernel<55>, lgrid, dim3(1024), lds16, s, A, Bm, L, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots F16_PROF_ARG);
+      else
+        hipLaunchKernelGGL(corr_build_fused16g_kernel<0>, lgrid, dim3(1024), lds16, s, A, Bm, L, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots F16_PROF_ARG);
       F16_PROF_DUMP();
     } else if (native && tiled && w2 == 64 && (h2 % 8) == 0 && waves16) {   // the shapes the headline runs on
       static DeviceOnce attr16_once;
