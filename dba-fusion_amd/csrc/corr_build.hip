@@ -32,11 +32,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // channels (round 3; 2-byte accesses before: 23.4 us per 32-edge map, two launches).
 // w_tiled > 0: the output pixel axis is in the 4 x 16 tile order of common.h (the source operand of the flow-aligned build,
 // whose 64-pixel strips are then tiles of the map); 0: linear.
-__global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
-                                                               _Float16 *__restrict__ out, int C, int HW, int kb,
-                                                               int w_tiled) {
+__device__ __forceinline__ void fmap_pixel_major_body(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int C, int HW,
+                                                      int kb, int w_tiled, int e) {
   __shared__ _Float16 tile[64][72];   // [channel][pixel]; pitch 144 B: the 8 lanes of a channel row write 16 B each
-  const int e = blockIdx.z;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const _Float16 *src = in + (size_t)e * C * HW;
   _Float16 *dst = out + (size_t)e * HW * C;
@@ -77,6 +75,23 @@ __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *_
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
+                                                               _Float16 *__restrict__ out, int C, int HW, int kb,
+                                                               int w_tiled) {
+  fmap_pixel_major_body(in, out, C, HW, kb, w_tiled, (int)blockIdx.z);
+}
+
+// both maps of a build in ONE launch (maps of the same size: grid.z = 2 n; the first n slices are map 1 in the pixel order
+// w_tiled1 asks for, the others map 2, linear): a launch and its gap less in front of the small builds (one edge of the motion
+// filter, the six of a new keyframe)
+__global__ __launch_bounds__(256) void fmap_pixel_major_pair_kernel(const _Float16 *__restrict__ in1, _Float16 *__restrict__ out1,
+                                                                    int w_tiled1, const _Float16 *__restrict__ in2,
+                                                                    _Float16 *__restrict__ out2, int C, int HW, int kb, int n) {
+  const int z = (int)blockIdx.z;
+  if (z < n) fmap_pixel_major_body(in1, out1, C, HW, kb, w_tiled1, z);
+  else fmap_pixel_major_body(in2, out2, C, HW, kb, 0, z - n);
 }
 
 // C must be a multiple of 16.  A = fmap1 pixel-major [HW1][C], B = fmap2 pixel-major [HW2][C].

@@ -1324,6 +1324,8 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
 
 // defined in corr_build.hip
 __global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
+__global__ void fmap_pixel_major_pair_kernel(const _Float16 *in1, _Float16 *out1, int w_tiled1, const _Float16 *in2, _Float16 *out2,
+                                             int C, int HW, int kb, int n);
 
 }  // namespace dba
 
@@ -1382,12 +1384,17 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
   const bool general16 = loop_form && waves16 && !tiled && w2 > 32 && h1 == h2 && w1 == w2 && ((w2 % 8) != 0 || (HW2 % 8) != 0);
   const bool native_b = loop_form && !general16 && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
   const bool native = native_b && native_mode == 1 && (HW1 % 8 == 0) && (w1 % 8 == 0);
-  if (!native)
-    hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                       static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
-  if (!native_b)
-    hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                       static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
+  if (!native && !native_b && HW1 == HW2 && 2 * (long long)n <= 65535)   // both copies in one launch
+    hipLaunchKernelGGL(fmap_pixel_major_pair_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, 2 * n), dim3(256), 0, s,
+                       static_cast<const _Float16 *>(fmap1), A, tiled ? w1 : 0, static_cast<const _Float16 *>(fmap2), Bm, C, HW1, 16, n);
+  else {
+    if (!native)
+      hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                         static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
+    if (!native_b)
+      hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
+                         static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
+  }
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
   const dim3 grid(HW1p / 64, (h2 + FT_ROWS - 1) / FT_ROWS, n);
