@@ -443,6 +443,36 @@ def main():
         reps = max(10, args.steps // 2)
         t_plain = loop(plain, reps)
         extras["sharded_x1_overhead_us"] = round(loop(sharded1, reps) - t_plain, 1)
+
+        # the whole headline step as a hipGraph (dbaf_amd.graphed): every call of the path only enqueues, so one update -- state
+        # reset, [reprojection + lookup], the caller's ten statements, ba(itrs=2) with the clamp -- is recorded once per factor-graph
+        # shape and replayed with ONE launch: what is left of the step when the host's share (Python, ~15 launch latencies) is
+        # gone.  One recording holds an update per pyramid copy (the lookups stay MALL-cold like the headline's).
+        if n_loc > 0 and fused and fused_clamp:
+            from dbaf_amd.graphed import GraphedUpdate
+
+            def updates_over_the_copies():
+                for cb_ in corrs:
+                    reset_state()
+                    keep[0] = cb_.lookup_reprojected(poses, disps, K_b4, ii, jj)[0]
+                    ii_g, jj_g, tg_g, wt_g = caller_graph()
+                    droid_backends.ba_clamped(poses, disps, intr, dsens, tg_g, wt_g, eta, ii_g, jj_g, W.t0, W.t1, 2, W.lm,
+                                              W.ep, False, 0.001)
+            try:
+                step(0)
+                torch.cuda.synchronize()
+                eager_state = state.clone()
+                gu = GraphedUpdate(updates_over_the_copies)
+                extras["step_graph_replay_us"] = round(loop(gu.replay, max(4, reps // ncopies)) / ncopies, 1)
+                torch.cuda.synchronize()
+                extras["step_graph_replay_vs_eager_max_abs"] = float((state - eager_state).abs().max().item())
+                extras["step_graph_replay_note"] = ("one hipGraph launch per %d updates (one per pyramid copy); same kernels and "
+                                                    "tensor statements as the headline step, recorded once per factor-graph shape"
+                                                    % ncopies)
+                del gu
+            except Exception as ex:   # (an extra: never the reason a bench line is missing)
+                extras["step_graph_replay_us"] = None
+                extras["step_graph_replay_note"] = "capture failed: %s" % str(ex)[:200]
         # ba(itrs=2) wall clock per call: the same tensor objects (stage 0 not launched), new objects holding the same edges
         # (stage 0 launched, leaves at its key comparison), another edge list of the same shape (stage 0 rebuilds)
         extras["ba_itrs2_cached_graph_wall_us"] = round(t_plain, 1)
