@@ -622,6 +622,9 @@ def main():
         coords0 = pops.coords_grid(h, w, device=dev)[None, None]
         fm_kf, fm_new = fmaps[0][None, None], fmaps[1][None, None]
         extras["motion_filter_us"] = round(timed(lambda: CorrBlock(fm_kf, fm_new)(coords0), 20), 1)
+        # (the unit is `CorrBlock(...)(coords0)` as the reference writes it: since the round's last session one library call --
+        # dba_corr_build_lookup_once_sheared -- and about the device time of its two kernels.  Recorded into a hipGraph and replayed it
+        # is SLOWER, 38-40 us: a graph launch costs the host more than the one call, profiles/r06_build_g16.txt)
         # volume build (per add_factors batch of 32 edges): CorrBlock(fmap1, fmap2), MFMA + pooling + flow-aligned store
         nb = min(32, n_loc)
         f1, f2 = fmaps[ii[:nb]][None], fmaps[jj[:nb]][None]

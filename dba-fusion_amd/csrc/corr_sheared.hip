@@ -977,6 +977,35 @@ int dba_corr_lookup_pyramid_sheared_slots(const void *const *volumes, const int 
   return lookup_sheared_launch(L, coords_nhw2, corr, n, h1, w1, h2, w2, 0, num_levels, 0, stream, slots);
 }
 
+// The motion filter's unit (dbaf/motion_filter.py:74-76): a pyramid built, looked up once and dropped, as one call
+size_t dba_corr_once_pyramid_bytes(int n, int h1, int w1, int h2, int w2, int num_levels) {
+  if (n <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS) return 0;
+  const size_t hw1p = (size_t)dba_corr_sheared_plane_elems(h1, w1);
+  size_t total = 0;
+  for (int l = 0; l < num_levels; l++) total += align_up((size_t)n * (h2 >> l) * (w2 >> l) * hw1p * sizeof(_Float16), 256);
+  return total;
+}
+
+int dba_corr_build_lookup_once_sheared(const void *fmap1, const void *fmap2, const float *coords_nhw2, void *corr, void *pyramid,
+                                       size_t pyramid_bytes, void *scratch, size_t scratch_bytes, int n, int C, int h1, int w1,
+                                       int h2, int w2, int num_levels, int radius, dba_stream_t stream) {
+  if (n < 0 || num_levels < 1 || num_levels > SH_MAX_LEVELS) return DBA_ERR_ARG;
+  if (radius != 3) return DBA_ERR_UNSUPPORTED;
+  if (n == 0) return DBA_OK;
+  if (!pyramid || pyramid_bytes < dba_corr_once_pyramid_bytes(n, h1, w1, h2, w2, num_levels)) return DBA_ERR_WORKSPACE;
+  void *levels[SH_MAX_LEVELS];
+  const size_t hw1p = (size_t)dba_corr_sheared_plane_elems(h1, w1);
+  char *p = static_cast<char *>(pyramid);
+  for (int l = 0; l < num_levels; l++) {
+    levels[l] = p;
+    p += align_up((size_t)n * (h2 >> l) * (w2 >> l) * hw1p * sizeof(_Float16), 256);
+  }
+  const int rc = dba_corr_volume_build_sheared_slots(fmap1, fmap2, levels, nullptr, n, C, h1, w1, h2, w2, num_levels, scratch,
+                                                     scratch_bytes, stream);
+  if (rc != DBA_OK) return rc;
+  return dba_corr_lookup_pyramid_sheared_slots(levels, nullptr, coords_nhw2, corr, n, h1, w1, h2, w2, num_levels, radius, stream);
+}
+
 int dba_corr_lookup_reproject_sheared(const void *const *volumes, const int *slots, const float *poses, const float *disps,
                                       const float *intrinsics_b4, const int64_t *ii, const int64_t *jj, float *coords_out,
                                       float *valid_out, void *corr, int n, int h1, int w1, int h2, int w2, int num_levels,

@@ -100,6 +100,8 @@ SYMBOLS = {
     "dba_corr_lookup_reproject_sheared": (c_int, [_P] * 10 + [c_int] * 7 + [_P]),
     "dba_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "dba_corr_volume_scratch_bytes": (c_size_t, [c_int] * 6),
+    "dba_corr_once_pyramid_bytes": (c_size_t, [c_int] * 6),
+    "dba_corr_build_lookup_once_sheared": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P, c_size_t] + [c_int] * 8 + [_P]),
     "dba_corr_volume_build": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P]),
     "dba_altcorr_forward_t": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),

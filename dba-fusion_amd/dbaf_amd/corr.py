@@ -36,6 +36,11 @@ def _stream():
 
 _IDENTITY_SLOTS = {}
 _BUILD_SCRATCH = {}
+_ONCE_PYRAMID = {}
+# CorrBlock(f1, f2)(coords) on a block of at most this many edges that was never built, cat'ed or indexed: the pyramid is built
+# into a standing per-stream buffer and looked up in ONE library call, the block itself stays unbuilt (MotionFilter.track builds
+# a one-edge block per incoming frame, looks it up once and drops it: motion_filter.py:74-76).  0 switches the path off.
+ONCE_MAX_EDGES = int(os.environ.get("DBA_CORR_ONCE_MAX_EDGES", "2"))
 
 
 def _build_scratch(nbytes, device):
@@ -103,6 +108,7 @@ class CorrBlock:
         self._slots_host = None    # list mirror of _slots, or None when stale (after a device-side index)
         self._identity = True      # slots == arange(n) and capacity == n: the stores ARE the pyramid
         self.stats = dict(built_edges=0, copied_edges=0, grown=0)
+        self._once_used = False    # the one-call build + lookup has served this (still unbuilt) block
 
     # ---- construction ------------------------------------------------------------------------------------------------
     @classmethod
@@ -306,10 +312,54 @@ class CorrBlock:
     def _store_ptrs(self):
         return (ctypes.c_void_p * self.num_levels)(*[s.data_ptr() for s in self._stores])
 
+    def _lookup_once(self, coords):
+        """the first lookup of a small block that has not been built: build into the stream's standing pyramid buffer + lookup, one
+        library call; the block stays unbuilt (a second lookup, a cat or an index builds it the regular way).  None: not this case"""
+        f1, f2, v1, v2 = self._pending
+        if f1._version != v1 or f2._version != v2:
+            return None   # (the regular path raises)
+        if f1.dtype != torch.float16 or f2.dtype != torch.float16 or not f1.is_contiguous() or not f2.is_contiguous():
+            return None
+        batch, num, ht, wd, _ = coords.shape
+        n, dim = self.n, int(f1.shape[2])
+        if batch * num != n or (ht, wd) != (self.h1, self.w1) or self.radius != 3:
+            return None
+        lib = _lib.load()
+        if not lib.dba_corr_volume_build_sheared_supported(dim, self.h1, self.w1, self.h2, self.w2, self.num_levels):
+            return None
+        dev = f1.device
+        stream = _stream()
+        key = (dev.index, stream.value, n, dim, self.h1, self.w1, self.h2, self.w2, self.num_levels)
+        ent = _ONCE_PYRAMID.get(key)
+        if ent is None:
+            if len(_ONCE_PYRAMID) > 8:
+                _ONCE_PYRAMID.clear()
+            pbytes = lib.dba_corr_once_pyramid_bytes(n, self.h1, self.w1, self.h2, self.w2, self.num_levels)
+            sbytes = lib.dba_corr_volume_scratch_bytes(n, dim, self.h1, self.w1, self.h2, self.w2)
+            ent = _ONCE_PYRAMID[key] = (torch.empty(pbytes, dtype=torch.uint8, device=dev), pbytes,
+                                        torch.empty(max(sbytes, 1), dtype=torch.uint8, device=dev), sbytes)
+        c = coords.reshape(n, ht, wd, 2)
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        rd = 2 * self.radius + 1
+        out = torch.empty(batch, num, self.num_levels * rd * rd, ht, wd, dtype=torch.float16, device=dev)
+        _lib.check(lib.dba_corr_build_lookup_once_sheared(f1.data_ptr(), f2.data_ptr(), c.data_ptr(), out.data_ptr(),
+                                                          ent[0].data_ptr(), ent[1], ent[2].data_ptr(), ent[3], n, dim, self.h1,
+                                                          self.w1, self.h2, self.w2, self.num_levels, self.radius, stream),
+                   "dba_corr_build_lookup_once_sheared")
+        self._once_used = True
+        self.stats["built_edges"] += n
+        return out
+
     def __call__(self, coords, timing=None):
         """timing = (start, stop): two torch.cuda.Event(enable_timing=True) that have been recorded once (so that they
         exist); they are attached to the lookup kernel's dispatch (sheared layout only), start.elapsed_time(stop) is
         then the kernel's duration -- a measurement hook for bench.py, without marker packets in the stream"""
+        if self._pending is not None and self.n <= ONCE_MAX_EDGES and not self._once_used and timing is None \
+                and self.layout == "sheared":
+            out = self._lookup_once(coords)
+            if out is not None:
+                return out
         self._materialise()
         batch, num, ht, wd, _ = coords.shape
         n = batch * num

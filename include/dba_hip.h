@@ -442,6 +442,17 @@ int dba_corr_lookup_reproject_sheared(const void *const *level_stores, const int
                                       float *coords_out, float *valid_out, void *corr, int n, int h1, int w1, int h2, int w2,
                                       int num_levels, int radius, dba_stream_t stream);
 
+/* A pyramid that is built, looked up ONCE and dropped -- MotionFilter.track, dbaf/motion_filter.py:74-76:
+ * `corr = CorrBlock(self.fmap[None,[0]], gmap[None,[0]])(coords0)`, once per incoming frame -- as one call: the levels go into
+ * `pyramid` (device scratch of dba_corr_once_pyramid_bytes bytes that the caller keeps per stream and reuses from frame to frame:
+ * calls on one stream are ordered), then the fused lookup reads them.  = dba_corr_volume_build_sheared_slots followed by
+ * dba_corr_lookup_pyramid_sheared_slots with identity slots, bit for bit; what it saves is the host's share (four level
+ * allocations and one library call per frame).  DBA_ERR_UNSUPPORTED where dba_corr_volume_build_sheared_supported says no. */
+size_t dba_corr_once_pyramid_bytes(int n, int h1, int w1, int h2, int w2, int num_levels);
+int dba_corr_build_lookup_once_sheared(const void *fmap1, const void *fmap2, const float *coords_nhw2, void *corr, void *pyramid,
+                                       size_t pyramid_bytes, void *scratch, size_t scratch_bytes, int n, int C, int h1, int w1,
+                                       int h2, int w2, int num_levels, int radius, dba_stream_t stream);
+
 /* ONE level of the flow-aligned pyramid looked up with the arguments droid_backends.corr_index_forward receives from the
  * reference's unmodified CorrBlock.__call__ (dbaf/modules/corr.py:40-50): coords [n, 2, h1, w1] ALREADY divided by 2^lvl,
  * corr [n, 7, 7, h1, w1].  h2, w2 are the LEVEL-0 target map sizes (the level's planes are (h2 >> lvl) x (w2 >> lvl)).

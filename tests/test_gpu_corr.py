@@ -484,3 +484,45 @@ def test_strip_walking_build_on_a_48x64_map_with_few_edges():
         for lvl in range(4):
             assert torch.equal(CorrBlock.map_pixels(fused[lvl], h, w).contiguous().view(torch.int16),
                                CorrBlock.map_pixels(unfused[lvl], h, w).contiguous().view(torch.int16)), (n, lvl)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 64, 64), (1, 55, 55), (1, 28, 107), (2, 24, 40)])
+def test_block_built_looked_up_once_and_dropped_takes_one_library_call(shape):
+    """MotionFilter.track's pattern (dbaf/motion_filter.py:74-76: `CorrBlock(fmap_kf, fmap_new)(coords0)`, one block per incoming
+    frame): the first lookup of a small block that was never built goes through dba_corr_build_lookup_once_sheared (pyramid into
+    the stream's standing buffer + lookup, one call; the block stays unbuilt) -- bit-identical to the built block's lookup, frame
+    after frame through the same buffer; a second lookup, a `cat` or an index of the same block build it the regular way"""
+    from dbaf_amd import corr as corr_mod
+    from dbaf_amd.corr import CorrBlock
+    n, h, w = shape
+    rng = np.random.default_rng(31 + n + h)
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    grid = np.stack([xs, ys], -1)[None, None]
+    for frame in range(3):
+        f1 = torch.from_numpy(rng.standard_normal((1, n, 128, h, w)).astype(np.float16)).cuda()
+        f2 = torch.from_numpy(rng.standard_normal((1, n, 128, h, w)).astype(np.float16)).cuda()
+        coords = torch.from_numpy((grid + rng.uniform(-2.5, 2.5, (1, n, h, w, 2))).astype(np.float32)).cuda()
+        blk = CorrBlock(f1, f2)
+        once = blk(coords)
+        assert blk._pending is not None and blk._once_used and blk._stores is None          # still unbuilt
+        ref = CorrBlock(f1, f2).build()(coords)
+        assert torch.equal(once.view(torch.int16), ref.view(torch.int16)), frame
+        again = blk(coords)                                                                   # the regular path now
+        assert blk._pending is None and blk._stores is not None
+        assert torch.equal(again.view(torch.int16), ref.view(torch.int16))
+    # a block that served one lookup can still be absorbed by a cat / indexed
+    blk = CorrBlock(f1, f2)
+    once = blk(coords)
+    both = CorrBlock(f1, f2).cat(blk)
+    out2 = both(torch.cat([coords, coords], 1))
+    assert torch.equal(out2[:, n:].view(torch.int16), once.view(torch.int16))
+    # switched off: the regular path from the first lookup on
+    old = corr_mod.ONCE_MAX_EDGES
+    corr_mod.ONCE_MAX_EDGES = 0
+    try:
+        blk = CorrBlock(f1, f2)
+        out3 = blk(coords)
+        assert blk._pending is None and not blk._once_used
+        assert torch.equal(out3.view(torch.int16), once.view(torch.int16))
+    finally:
+        corr_mod.ONCE_MAX_EDGES = old

@@ -80,9 +80,12 @@ def test_cat_and_index_edit_the_slot_table_and_lookups_stay_bit_identical(layout
     c13 = _coords(13, h, w, 6)
     assert torch.equal(a(c13), fresh(sel)(c13))
 
-    # a block that was already used is copied in (its edges' bytes only)
+    # a block that was already BUILT is copied in (its edges' bytes only).  (One lookup of a fresh small block does not build it --
+    # dba_corr_build_lookup_once_sheared, test_gpu_corr.py -- the second one does.)
     used = CorrBlock(fm[ii[:2]][None], fm[jj[:2]][None], layout=layout)
     used(_coords(2, h, w, 7))
+    used(_coords(2, h, w, 7))
+    assert used._pending is None
     cap = a.capacity
     a = a[torch.arange(10, device="cuda")].cat(used)
     sel = torch.cat([sel[:10], torch.arange(2, device="cuda")])
