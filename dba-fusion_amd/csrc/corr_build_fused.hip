@@ -984,9 +984,11 @@ __global__ __launch_bounds__(1024) void corr_build_fused16_kernel(const _Float16
 // tile + two operand buffers + pooled region in LDS), same arithmetic in the same order as the eight-wave walk
 // (corr_build_fused_kernel<2, true>): bit-identical to it.  What differs from the tiled form: a strip is 64 consecutive pixels of
 // the flattened map and may span a row end (quads that do are stored by the whole wave, sixteen offsets per instruction), the map
-// width is not a power of two (wraps by compare-and-subtract, the tile's wrap columns sit behind column w2 - 1), the last row
-// tile may be partial, and the operands are the k-block-major copies (16-byte pieces of the caller's maps are not aligned at these
-// widths).  The two waves of a row split the offsets dx of the level-0 lines in halves (batches of four lines).
+// width is not a power of two (wraps by compare-and-subtract; the tile's wrap columns sit behind column w2 - 1 and are the second
+// wave's own products: its fragments for those columns are targets 0..3 of the row, so no write of the tile is masked; the pooled
+// region has no wrap columns, the level-1 loop wraps its offsets itself), the last row tile may be partial, and the operands are
+// the k-block-major copies (16-byte pieces of the caller's maps are not aligned at these widths).  The two waves of a row split the
+// offsets dx of the level-0 lines (batches of four lines; the wave that also pools takes one batch less).
 // W2C > 0: the map width as a compile-time constant (w1 == w2 == W2C: the wraps, the splits of the lines between the waves and the
 // divisions by the width fold into constants and the store loops unroll); 0: any width at run time.
 template <int W2C>
@@ -1046,7 +1048,12 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
   half8 bres[KSL];
   {
     const int ty = min(ty0 + r, h2 - 1);
-    const _Float16 *bpt = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + 32 * hf + l31, HW2 - 1) * 16 + kh;
+    // The tile wants columns 0..3 of a row once more behind column w2 - 1 (the level-0 loop's diagonal reads).  Those columns lie
+    // in the second wave's half (w2 > 32): its fragments for them are targets 0..3 of the row, so the products land there by
+    // themselves -- same operands, same order of accumulation, the same bits as in columns 0..3 -- and the tile write needs no mask
+    int txl = 32 * hf + l31;
+    txl -= (txl >= w2 && txl < w2 + 4) ? w2 : 0;
+    const _Float16 *bpt = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + txl, HW2 - 1) * 16 + kh;
 #pragma unroll
     for (int ks = 0; ks < KSL; ks++) bres[ks] = *reinterpret_cast<const half8 *>(bpt + (size_t)ks * 16 * HW2);
 #pragma unroll
@@ -1057,7 +1064,11 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
 
   const int q4 = (lane & 15) * 4, g = lane >> 4;     // the lane's quad of pixels and its line of a batch of four
   const int ipx = lane & 3, idx16 = lane >> 2;       // irregular quads: the lane's pixel of the quad, its offset of sixteen
-  const int nb = (w2 + 3) >> 2, nb0 = (nb + 1) >> 1; // batches of four level-0 lines: [0, nb0) to the row's first wave, the rest to its partner
+#ifndef G16_L0_SHIFT
+#define G16_L0_SHIFT 1   // batches of level-0 lines moved from the row's first wave, which also pools, to its partner (0 / 1 / 2 measured:
+                         // 55x55 11.56 / 11.52 / 11.90, 44x60 8.07 / 7.73 / 8.30 us per edge, profiles/r06_build_g16.txt)
+#endif
+  const int nb = (w2 + 3) >> 2, nb0 = ((nb + 1) >> 1) - G16_L0_SHIFT; // batches of four level-0 lines: [0, nb0) to the row's first wave, the rest to its partner
   const int b_begin = hf ? nb0 : 0, b_end = hf ? nb : nb0;
   auto pixel_xy = [&](int pix, int &x, int &y) { sh_pixel_yx(min(pix, HW1 - 1), w1, inv_w1, false, y, x); };
 
@@ -1090,32 +1101,25 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
     F16_STAMP(2);
     lds_barrier();  // every wave is done with the source operand and with the previous strip's tile
     F16_STAMP(3);
-    // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target).  Columns from
-    // w2 on belong to the wrap copy below (written by the row's OTHER wave): the targets past the row's end are not written.
+    // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target).  Columns
+    // w2 .. w2 + 3 hold columns 0..3 once more (the second wave's products, see its fragments); the ones behind them are never read.
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) {
-        const int tx = 32 * hf + 8 * rq + 4 * (lane >> 5);
-        _Float16 *dst = T + (i * 32 + l31) * PITCH + r * RP + tx;
-        if (tx + 4 <= w2) {
-          half4 v;
+        half4 v;
 #pragma unroll
-          for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
-          *reinterpret_cast<half4 *>(dst) = v;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (tx + k < w2) dst[k] = (_Float16)acc[i][4 * rq + k];
-        }
+        for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][4 * rq + k];
+        *reinterpret_cast<half4 *>(T + (i * 32 + l31) * PITCH + r * RP + 32 * hf + 8 * rq + 4 * (lane >> 5)) = v;
       }
-    // columns 0..3 once more behind column w2 - 1: a store lane's four diagonal reads then never wrap inside a quad
-    if (hf == 0 && lane < 32) {
+    // (maps 61..63 wide: the wrap columns from 64 on are outside the second wave's half -- the first wave's own values go there)
+    if (w2 + 3 >= W2P && hf == 0 && lane < 32) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         _Float16 *wr = T + (i * 32 + l31) * PITCH + r * RP + w2;
 #pragma unroll
-        for (int k = 0; k < 4; k++) wr[k] = (_Float16)acc[i][k];
+        for (int k = 0; k < 4; k++)
+          if (w2 + k >= W2P) wr[k] = (_Float16)acc[i][k];
       }
     }
     lds_barrier();
@@ -1205,24 +1209,14 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
 #pragma unroll
         for (int c = 0; c < 2; c++) q2[rw][c] = pool4(q1[2 * rw][2 * c], q1[2 * rw][2 * c + 1], q1[2 * rw + 1][2 * c], q1[2 * rw + 1][2 * c + 1]);
       const _Float16 q3 = pool4(q2[0][0], q2[0][1], q2[1][0], q2[1][1]);
-      const int w2l = w2 >> 1;
+      // (no wrap columns in the pooled region here, unlike the eight-wave walk: with a run-time width they would be 2-byte writes
+      // at an odd offset and the row's last block a masked write -- the level-1 loop wraps its three offset columns itself)
 #pragma unroll
       for (int rw = 0; rw < 4; rw++) {
-        _Float16 *row1 = P1 + (src * 4 + rw) * RP1;
-        if (4 * cb + 4 <= w2l) {
-          half4 v;
+        half4 v;
 #pragma unroll
-          for (int c = 0; c < 4; c++) v[c] = q1[rw][c];
-          *reinterpret_cast<half4 *>(row1 + 4 * cb) = v;
-        } else {  // the block that holds column w2l - 1: the columns behind it belong to the copy of block 0
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-            if (4 * cb + c < w2l) row1[4 * cb + c] = q1[rw][c];
-        }
-        if (cb == 0) {
-#pragma unroll
-          for (int c = 0; c < 4; c++) row1[w2l + c] = q1[rw][c];
-        }
+        for (int c = 0; c < 4; c++) v[c] = q1[rw][c];
+        *reinterpret_cast<half4 *>(P1 + (src * 4 + rw) * RP1 + 4 * cb) = v;
       }
 #pragma unroll
       for (int rw = 0; rw < 2; rw++) {
@@ -1251,9 +1245,12 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
           unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
           const _Float16 *lb = P1 + (q4 * 4 + tyl) * RP1;
           for (int dx0 = 4 * grp; dx0 < w2l; dx0 += 16) {
-            const _Float16 *pp = lb + t;
-            const unsigned short a0 = __builtin_bit_cast(unsigned short, pp[0]), a1 = __builtin_bit_cast(unsigned short, pp[4 * RP1 + o1]);
-            const unsigned short a2 = __builtin_bit_cast(unsigned short, pp[8 * RP1 + o2]), a3 = __builtin_bit_cast(unsigned short, pp[12 * RP1 + o3]);
+            int c1 = t + o1, c2 = t + o2, c3 = t + o3;   // (t < w2l; the offsets are 0..2)
+            c1 -= (c1 >= w2l) ? w2l : 0;
+            c2 -= (c2 >= w2l) ? w2l : 0;
+            c3 -= (c3 >= w2l) ? w2l : 0;
+            const unsigned short a0 = __builtin_bit_cast(unsigned short, lb[t]), a1 = __builtin_bit_cast(unsigned short, lb[4 * RP1 + c1]);
+            const unsigned short a2 = __builtin_bit_cast(unsigned short, lb[8 * RP1 + c2]), a3 = __builtin_bit_cast(unsigned short, lb[12 * RP1 + c3]);
             typedef unsigned u2v __attribute__((ext_vector_type(2)));
             u2v d;
             d.x = (unsigned)a0 | ((unsigned)a1 << 16);
