@@ -1436,7 +1436,11 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
     } else {
       spw = 1;
       double best = 1e300;
-      for (int c = 1; c <= spw_cap && c <= nstrips; c++) {
+      // (the general sixteen-wave walk may take a whole row of strips: 36 edges at 55 x 55 -- the TUM-VI window -- are 252 rows, one
+      // round of one walk each: 10.5 against 10.8 us per edge with the cap of 16; the other forms were measured with the cap)
+      static const bool cap_given = getenv("DBA_BUILD_SPW_CAP") != nullptr;
+      const int cap = (general16 && !cap_given) ? nstrips : spw_cap;
+      for (int c = 1; c <= cap && c <= nstrips; c++) {
         const long long wgs = (long long)((nstrips + c - 1) / c) * rows;
         // (a last round that is partly empty is cheaper than a full one -- the walk is half chain, half memory traffic --: the
         // mean of whole and fractional rounds matches the measured picks, profiles/r06_build16.txt item 7)
