@@ -1319,6 +1319,315 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
 #endif
 }
 
+// =====================================================================================================================
+// Maps 65..128 wide in the linear pixel order on SIXTEEN waves (round 6, last session): 28 x 107 is the KITTI-360 shape of
+// BASELINE's configs.  One strip per workgroup like corr_build_fused_kernel<4, false> -- a 128-column tile (136 KB) leaves no LDS for
+// a walk's second operand buffer and no registers for resident target fragments -- but a target row is shared by two waves: wave
+// (r, hf) owns the columns 64 hf .. 64 hf + 63 of row ty0 + r (2 x 2 accumulator tiles, 64 registers, instead of 2 x 4), so four
+// waves per SIMD instead of two wait for the row's target fragments, which come out of L2 in every strip (32 KB per row: the
+// matrix phase of the eight-wave form is mostly that wait).  Same arithmetic in the same order: bit-identical.  The conventions of
+// corr_build_fused16g_kernel: the tile's wrap columns are the second wave's own products, no masked tile writes, no wrap columns
+// in the pooled region (which takes the dead tile's place, as in the eight-wave form), level-0 lines split between a row's waves.
+__global__ __launch_bounds__(1024) void corr_build_fused16w_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ Bm,
+                                                                   FusedLevels L, int C, int h1, int w1, int h2, int w2, int HW1p,
+                                                                   float inv_w1, const int *__restrict__ oslots) {
+  constexpr int W2P = 128;
+  constexpr int RP = W2P + 4, PITCH = FT_ROWS * RP + 4, RP1 = W2P / 2 + 4;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  _Float16 *T = smem;                          // [64][PITCH]   level 0 of the strip, rounded; before that: the strip's source operand
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = wave & 7, hf = wave >> 3;      // this wave's target row of the tile, its half of the row's columns
+  const int strip = blockIdx.x, ty0 = blockIdx.y * FT_ROWS, e = blockIdx.z;
+  const int HW1 = h1 * w1, HW2 = h2 * w2;
+  const int l31 = lane & 31, kh = (lane >> 5) * 8;
+  const int p0 = strip * 64;
+  const int eo = oslots ? oslots[e] : e;
+  auto level_rsrc = [&](int lvl) {
+    const size_t elems = (size_t)(h2 >> lvl) * (w2 >> lvl) * HW1p;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(L.vs[lvl] + (size_t)eo * elems), 0, (int)(2 * elems), 0x00020000);
+  };
+  const unsigned plane_bytes = 2u * (unsigned)HW1p;
+  constexpr unsigned OOR = 0x80000000u;
+  const int ksteps = C >> 4;
+
+  // ---- the strip's source operand into the (still unused) tile: [k-step][32-pixel block][q][k-half][pixel][4 halves] ----------
+  {
+    const _Float16 *Ae = A + (size_t)e * HW1 * C;
+    for (int idx = tid; idx < ksteps * 128; idx += 1024) {  // 16-byte pieces: [k-block][pixel][half of the 16 channels]
+      const int kbk = idx >> 7, rem = idx & 127, px = rem >> 1, hk = rem & 1;
+      const half8 v = *reinterpret_cast<const half8 *>(Ae + ((size_t)kbk * HW1 + min(p0 + px, HW1 - 1)) * 16 + hk * 8);
+      const int fa = ((((kbk * 2 + (px >> 5)) * 2 + 0) * 2 + hk) * 32 + (px & 31)) * 4;
+      half4 lo, hi;
+#pragma unroll
+      for (int c = 0; c < 4; c++) lo[c] = v[c], hi[c] = v[4 + c];
+      *reinterpret_cast<half4 *>(T + fa) = lo;
+      *reinterpret_cast<half4 *>(T + fa + 2 * 32 * 4) = hi;
+    }
+  }
+  // ---- this wave's target fragments: streamed per k-step, two steps ahead (rows past the map: a valid row, never stored; the
+  // columns w2 .. w2 + 3: targets 0..3 of the row -- the tile's wrap columns; columns behind them: never read) -------------------
+  const _Float16 *bp[2];
+  {
+    const int ty = min(ty0 + r, h2 - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int txl = 64 * hf + 32 * j + l31;
+      txl -= (txl >= w2 && txl < w2 + 4) ? w2 : 0;
+      bp[j] = Bm + (size_t)e * HW2 * C + (size_t)min(ty * w2 + txl, HW2 - 1) * 16 + kh;
+    }
+  }
+  const size_t kb = (size_t)HW2;
+  half8 b0[2], b1[2], b2[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    b0[j] = *reinterpret_cast<const half8 *>(bp[j]);
+    b1[j] = *reinterpret_cast<const half8 *>(bp[j] + (size_t)min(1, ksteps - 1) * 16 * kb);
+  }
+  __syncthreads();
+
+  // ---- products: acc[i][j] = 32 x 32 tile (sources 32 i .., targets 64 hf + 32 j ..) of target row ty0 + r ------------------------
+  float16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[i][j][k] = 0.f;
+  for (int ks = 0; ks < ksteps; ks++) {
+    const int kn = min(ks + 2, ksteps - 1);  // (the last steps re-request a fragment: no branch in the loop)
+#pragma unroll
+    for (int j = 0; j < 2; j++) b2[j] = *reinterpret_cast<const half8 *>(bp[j] + (size_t)kn * 16 * kb);
+    half8 a[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const _Float16 *fp = T + ((((ks * 2 + t) * 2 + 0) * 2 + (lane >> 5)) * 32 + l31) * 4;
+      const half4 lo = *reinterpret_cast<const half4 *>(fp), hi = *reinterpret_cast<const half4 *>(fp + 2 * 32 * 4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) a[t][c] = lo[c], a[t][4 + c] = hi[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0[j], a[i], acc[i][j], 0, 0, 0);  // targets x sources
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      b0[j] = b1[j];
+      b1[j] = b2[j];
+    }
+  }
+  lds_barrier();  // every wave is done with the source operand: the tile takes its place
+  // D layout: col = lane & 31 (source within the 32-block), row = (k & 3) + 8 (k >> 2) + 4 (lane >> 5) (target)
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        half4 v;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (_Float16)acc[i][j][4 * rq + k];
+        *reinterpret_cast<half4 *>(T + (i * 32 + l31) * PITCH + r * RP + 64 * hf + 32 * j + 8 * rq + 4 * (lane >> 5)) = v;
+      }
+  // (maps 125..128 wide: the wrap columns from 128 on are outside the second wave's half -- the first wave's own values go there)
+  if (w2 + 3 >= W2P && hf == 0 && lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      _Float16 *wr = T + (i * 32 + l31) * PITCH + r * RP + w2;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (w2 + k >= W2P) wr[k] = (_Float16)acc[i][0][k];
+    }
+  }
+  lds_barrier();
+
+  const int q4 = (lane & 15) * 4, g = lane >> 4;     // the lane's quad of pixels and its line of a batch of four
+  const int ipx = lane & 3, idx16 = lane >> 2;       // irregular quads: the lane's pixel of the quad, its offset of sixteen
+  const int nb = (w2 + 3) >> 2, nb0 = ((nb + 1) >> 1) - 1;   // batches of four level-0 lines: [0, nb0) to the row's first wave (it has the
+  const int b_begin = hf ? nb0 : 0, b_end = hf ? nb : nb0;   // larger share of the pooling's reads in front of it), the rest to its partner
+  auto pixel_xy = [&](int pix, int &x, int &y) { sh_pixel_yx(min(pix, HW1 - 1), w1, inv_w1, false, y, x); };
+  int qx0, qy0, qx3, qy3;
+  pixel_xy(p0 + q4, qx0, qy0);
+  pixel_xy(p0 + q4 + 3, qx3, qy3);
+  const bool quad_regular = (p0 + q4 + 3 < HW1) && (qy0 == qy3);
+  const unsigned long long irregular = __ballot(!quad_regular && g == 0 && (p0 + q4 < HW1));   // bit = quad index (wave-uniform)
+  // ---- level 0: Vs0[(ty - y1) mod h2][dx][pixel] = T[pixel][ty][(x1 + dx) mod w2], this wave's target row and share of the dx ----
+  {
+    const int ty = ty0 + r;
+    if (ty < h2) {  // (wave-uniform)
+      const __amdgpu_buffer_rsrc_t r0 = level_rsrc(0);
+      if (quad_regular) {
+        int t = qx0 + g + 4 * b_begin;
+        t -= (t >= w2) ? w2 : 0;
+        t -= (t >= w2) ? w2 : 0;
+        int dy = ty - qy0;
+        dy += (dy < 0) ? h2 : 0;
+        unsigned voff = ((unsigned)dy * (unsigned)w2 + (unsigned)(g + 4 * b_begin)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+        const _Float16 *lb = T + q4 * PITCH + r * RP;
+        for (int b0_ = b_begin; b0_ < b_end; b0_ += 4) {  // four batches at a time: their 16 LDS reads are in flight together
+          unsigned short a[4][4];
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const _Float16 *pp = lb + t;
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
+            t += 4;
+            t -= (t >= w2) ? w2 : 0;
+          }
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            u2v d;
+            d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
+            d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r0, (b0_ + b < b_end && 4 * (b0_ + b) + g < w2) ? voff : OOR, 0, FB_STORE_AUX);
+            voff += 4u * plane_bytes;
+          }
+        }
+      }
+      for (unsigned long long m = irregular; m; m &= m - 1) {
+        const int pl = 4 * (int)__builtin_ctzll(m) + ipx;  // this lane's pixel of the quad, within the strip
+        int xi, yi;
+        pixel_xy(p0 + pl, xi, yi);
+        const bool pok = p0 + pl < HW1;
+        int dy = ty - yi;
+        dy += (dy < 0) ? h2 : 0;
+        const _Float16 *row = T + pl * PITCH + r * RP;
+        const unsigned vbase = (unsigned)dy * (unsigned)w2 * plane_bytes + 2u * (unsigned)(p0 + pl);
+        for (int dx0 = 64 * hf; dx0 < min(w2, 64 * hf + 64); dx0 += 16) {
+          const int dx = dx0 + idx16;
+          int tx = xi + dx;
+          tx -= (tx >= w2) ? w2 : 0;
+          tx = min(tx, w2 - 1);  // (dx beyond the map in the last group: read something valid, store nothing)
+          const _Float16 v = row[tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r0,
+                                                (pok && dx < w2) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
+        }
+      }
+    }
+  }
+  // ---- levels 1..3: every thread pools one 8 x 8 block (from the ROUNDED level below each time) in registers; behind a barrier (the
+  // tile is dead: its level-0 stores have read it) the values take its place, behind a second one the sheared store loops read them
+  _Float16 *P1 = T;                                // [64][4][RP1]
+  _Float16 *P2 = P1 + 64 * 4 * RP1;                // [64][2][W2P / 4]
+  _Float16 *P3 = P2 + 64 * 2 * (W2P / 4);          // [64][W2P / 8]
+  {
+    const int src = tid >> 4, cb = tid & 15;
+    const _Float16 *tb = T + src * PITCH + 8 * cb;
+    _Float16 t8[8][8], q1[4][4], q2[2][2];
+#pragma unroll
+    for (int rw = 0; rw < 8; rw++) {
+      const half4 lo = *reinterpret_cast<const half4 *>(tb + rw * RP), hi = *reinterpret_cast<const half4 *>(tb + rw * RP + 4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) t8[rw][c] = lo[c], t8[rw][4 + c] = hi[c];
+    }
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) q1[rw][c] = pool4(t8[2 * rw][2 * c], t8[2 * rw][2 * c + 1], t8[2 * rw + 1][2 * c], t8[2 * rw + 1][2 * c + 1]);
+#pragma unroll
+    for (int rw = 0; rw < 2; rw++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) q2[rw][c] = pool4(q1[2 * rw][2 * c], q1[2 * rw][2 * c + 1], q1[2 * rw + 1][2 * c], q1[2 * rw + 1][2 * c + 1]);
+    const _Float16 q3 = pool4(q2[0][0], q2[0][1], q2[1][0], q2[1][1]);
+    lds_barrier();  // every read of the level-0 tile is done (its sheared store above included)
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+      half4 v;
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = q1[rw][c];
+      *reinterpret_cast<half4 *>(P1 + (src * 4 + rw) * RP1 + 4 * cb) = v;
+    }
+#pragma unroll
+    for (int rw = 0; rw < 2; rw++) {
+      half2v v;
+      v.x = q2[rw][0], v.y = q2[rw][1];
+      *reinterpret_cast<half2v *>(P2 + (src * 2 + rw) * (W2P / 4) + 2 * cb) = v;
+    }
+    P3[src * (W2P / 8) + cb] = q3;
+  }
+  lds_barrier();
+  {  // level 1: 4 rows x w2l offsets, four lines per store instruction; wave w takes pooled row w & 3 and the groups of four
+     // offsets (w >> 2) + 4 k.  The quad's columns (x >> 1) - (x0 >> 1) are 0, 0|1, 1, 1|2
+    const int w2l = w2 >> 1, h2l = h2 >> 1;
+    const __amdgpu_buffer_rsrc_t rl = level_rsrc(1);
+    const int tyl = wave & 3, grp = wave >> 2, tyg = (ty0 >> 1) + tyl;
+    if (tyg < h2l) {  // floor sizes of avg_pool2d: the last partial row of the level below is dropped
+      if (quad_regular) {
+        const int xh = qx0 >> 1;
+        const int o1 = ((qx0 + 1) >> 1) - xh, o2 = ((qx0 + 2) >> 1) - xh, o3 = ((qx0 + 3) >> 1) - xh;
+        int t = xh + 4 * grp + g;
+        t -= (t >= w2l) ? w2l : 0;
+        t -= (t >= w2l) ? w2l : 0;
+        int dy = tyg - (qy0 >> 1);
+        dy += (dy < 0) ? h2l : 0;
+        unsigned voff = ((unsigned)dy * (unsigned)w2l + (unsigned)(4 * grp + g)) * plane_bytes + 2u * (unsigned)(p0 + q4);
+        const _Float16 *lb = P1 + (q4 * 4 + tyl) * RP1;
+        for (int dx0 = 4 * grp; dx0 < w2l; dx0 += 16) {
+          int c1 = t + o1, c2 = t + o2, c3 = t + o3;   // (t < w2l; the offsets are 0..2)
+          c1 -= (c1 >= w2l) ? w2l : 0;
+          c2 -= (c2 >= w2l) ? w2l : 0;
+          c3 -= (c3 >= w2l) ? w2l : 0;
+          const unsigned short a0 = __builtin_bit_cast(unsigned short, lb[t]), a1 = __builtin_bit_cast(unsigned short, lb[4 * RP1 + c1]);
+          const unsigned short a2 = __builtin_bit_cast(unsigned short, lb[8 * RP1 + c2]), a3 = __builtin_bit_cast(unsigned short, lb[12 * RP1 + c3]);
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          u2v d;
+          d.x = (unsigned)a0 | ((unsigned)a1 << 16);
+          d.y = (unsigned)a2 | ((unsigned)a3 << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(d, rl, (dx0 + g < w2l) ? voff : OOR, 0, FB_STORE_AUX);
+          voff += 16u * plane_bytes;
+          t += 16;
+          t -= (t >= w2l) ? w2l : 0;
+          t -= (t >= w2l) ? w2l : 0;
+        }
+      }
+      for (unsigned long long m = irregular; m; m &= m - 1) {  // (the four waves of a pooled row take every fourth group of 16 offsets)
+        const int pl = 4 * (int)__builtin_ctzll(m) + ipx;
+        int xi, yi;
+        pixel_xy(p0 + pl, xi, yi);
+        const bool pok = p0 + pl < HW1;
+        int dy = tyg - (yi >> 1);
+        dy += (dy < 0) ? h2l : 0;
+        const _Float16 *row = P1 + (pl * 4 + tyl) * RP1;
+        const unsigned vbase = (unsigned)dy * (unsigned)w2l * plane_bytes + 2u * (unsigned)(p0 + pl);
+        for (int dx0 = 16 * grp; dx0 < w2l; dx0 += 64) {
+          const int dx = dx0 + idx16;
+          int tx = (xi >> 1) + dx;
+          tx -= (tx >= w2l) ? w2l : 0;
+          tx = min(tx, w2l - 1);
+          const _Float16 v = row[tx];
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl,
+                                                (pok && dx < w2l) ? vbase + (unsigned)dx * plane_bytes : OOR, 0, FB_STORE_AUX);
+        }
+      }
+    }
+  }
+  {  // levels 2 and 3: a lane is one source pixel, (ty_l, dx) segments are dealt to the waves
+    const int p = p0 + lane;
+    const bool active = p < HW1;
+    int x1, y1;
+    pixel_xy(p, x1, y1);
+    auto store_level = [&](int lvl, const _Float16 *Pl, int rows, int pitch_cols) {
+      const int h2l = h2 >> lvl, w2l = w2 >> lvl;
+      const __amdgpu_buffer_rsrc_t rl = level_rsrc(lvl);
+      const int x1l = x1 >> lvl, y1l = y1 >> lvl;
+      for (int seg = wave; seg < rows * w2l; seg += 16) {  // (wave-uniform)
+        const int tyl = seg / w2l, dx = seg - tyl * w2l;
+        const int tyg = (ty0 >> lvl) + tyl;
+        if (tyg >= h2l) continue;
+        int dy = tyg - y1l;
+        dy += (dy < 0) ? h2l : 0;
+        int tx = x1l + dx;
+        tx -= (tx >= w2l) ? w2l : 0;
+        const _Float16 v = Pl[(lane * rows + tyl) * pitch_cols + tx];
+        const unsigned voff = active ? ((unsigned)dy * (unsigned)w2l + (unsigned)dx) * plane_bytes + 2u * (unsigned)p : OOR;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rl, voff, 0, FB_STORE_AUX);
+      }
+    };
+    store_level(2, P2, 2, W2P / 4);
+    store_level(3, P3, 1, W2P / 8);
+  }
+}
+
 // defined in corr_build.hip
 __global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
 __global__ void fmap_pixel_major_pair_kernel(const _Float16 *in1, _Float16 *out1, int w_tiled1, const _Float16 *in2, _Float16 *out2,
@@ -1530,8 +1839,18 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
                        1, out_slots, tiled FB_PROF_ARG);
   } else {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
-    hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
-                       1, out_slots, tiled FB_PROF_ARG);
+    // sixteen waves per workgroup where the planes keep the linear pixel order (DBA_BUILD_WAVES=8: the eight-wave form; A/B runs)
+    if (waves16 && !tiled && h1 == h2 && w1 == w2 && (C % 16) == 0 && C <= 512) {
+      static DeviceOnce attr16w_once;
+      if (attr16w_once.needed()) {
+        DBA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&corr_build_fused16w_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr16w_once.done();
+      }
+      hipLaunchKernelGGL(corr_build_fused16w_kernel, grid, dim3(1024), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1, out_slots);
+    } else
+      hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
+                         1, out_slots, tiled FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();
 #ifdef FB_PROF

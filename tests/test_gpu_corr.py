@@ -148,11 +148,14 @@ def test_fused_sheared_build_equals_unfused_pipeline(shape):
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 64, 64), (5, 64, 64), (3, 8, 64), (2, 40, 64), (7, 24, 64), (33, 16, 64), (2, 48, 64),
-                                   (1, 55, 55), (5, 55, 55), (3, 9, 33), (2, 44, 60), (33, 17, 37), (7, 8, 63), (2, 61, 61)])
+                                   (1, 55, 55), (5, 55, 55), (3, 9, 33), (2, 44, 60), (33, 17, 37), (7, 8, 63), (2, 61, 61),
+                                   (5, 28, 107), (1, 28, 107), (2, 9, 126), (3, 17, 125), (1, 12, 127), (2, 20, 65)])
 def test_sixteen_wave_build_every_walk_length_and_into_slots(n, h, w):
     """the sixteen-wave strip walks (C = 128; 64-wide maps whose planes are tiled: corr_build_fused16_kernel; maps 33..63 wide whose
     planes keep the linear pixel order and whose 16-byte pieces are not aligned, 55 x 55 of the reference's TUM-VI demo among them:
-    corr_build_fused16g_kernel) at the walk lengths the launch heuristic produces -- one edge (two strips per workgroup), walks that
+    corr_build_fused16g_kernel; maps 65..128 wide in the linear order, 28 x 107 of the KITTI config among them: corr_build_fused16w_kernel,
+    one strip per workgroup, incl. the widths from 125 on whose wrap columns lie outside the second wave's half) at the walk lengths
+    the launch heuristic produces -- one edge (two strips per workgroup), walks that
     end early (the last workgroup of a row tile holds fewer strips), one row tile (h = 8), a last row tile with one valid row
     (h = 9, 17), widths just past 32 and just below 64 (the split of the level-0 lines between a row's two waves), more edges than
     one round of workgroups -- bit for bit against the unfused pipeline; then the same edges built INTO THE SLOTS of a standing
