@@ -1146,15 +1146,18 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
           dy += (dy < 0) ? h2 : 0;
           unsigned voff = ((unsigned)dy * (unsigned)w2 + (unsigned)(g + 4 * b_begin)) * plane_bytes + 2u * (unsigned)(p0 + q4);
           const _Float16 *lb = T + q4 * PITCH + r * RP;
+          // (a line dx = 4 b + g is this lane's to store iff b < b_end and dx < w2: ONE compare against the lane's limit; the column
+          // counter wraps as an unsigned minimum: t + 4 - w2 is huge while t + 4 < w2)
+          const unsigned dx_lim = (unsigned)min(w2, 4 * b_end + g);
+          unsigned dxu = (unsigned)(4 * b_begin + g), tu = (unsigned)t;
           for (int b0 = b_begin; b0 < b_end; b0 += 4) {  // four batches at a time: their 16 LDS reads are in flight together
             unsigned short a[4][4];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-              const _Float16 *pp = lb + t;
+              const _Float16 *pp = lb + tu;
 #pragma unroll
               for (int u = 0; u < 4; u++) a[b][u] = __builtin_bit_cast(unsigned short, pp[u * (PITCH + 1)]);
-              t += 4;
-              t -= (t >= w2) ? w2 : 0;
+              tu = min(tu + 4u, tu + 4u - (unsigned)w2);
             }
 #pragma unroll
             for (int b = 0; b < 4; b++) {
@@ -1162,8 +1165,9 @@ __global__ __launch_bounds__(1024) void corr_build_fused16g_kernel(const _Float1
               u2v d;
               d.x = (unsigned)a[b][0] | ((unsigned)a[b][1] << 16);
               d.y = (unsigned)a[b][2] | ((unsigned)a[b][3] << 16);
-              __builtin_amdgcn_raw_buffer_store_b64(d, r0, (b0 + b < b_end && 4 * (b0 + b) + g < w2) ? voff : OOR, 0, FB_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(d, r0, (dxu < dx_lim) ? voff : OOR, 0, FB_STORE_AUX);
               voff += 4u * plane_bytes;
+              dxu += 4u;
             }
           }
         }
