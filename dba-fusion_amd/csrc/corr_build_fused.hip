@@ -47,6 +47,12 @@
 // channel slice consists of (16.9 against 17.6 us per edge end to end; DBA_BUILD_OPERANDS=copy|bnative for the A/B run).
 // Shapes: w2 <= 128, C % 16 == 0, 4 levels, h2 >> 3 >= 1, w2 >> 3 >= 1; anything else takes the unfused path of
 // corr_build.hip + corr_shear_kernel.
+// Kernels in this file (round 6): corr_build_fused_kernel<NT, LOOP, NATIVE, NATIVE_B> -- the eight-wave forms described above (maps up
+// to 32 wide, tiled planes that miss the sixteen-wave form's conditions, widths that are multiples of 8 on linear planes, 128-wide
+// tiled planes); corr_build_fused16_kernel -- the strip walk on sixteen waves, tiled planes, 64 columns (the headline shapes);
+// corr_build_fused16g_kernel<W2C> -- the same walk on linear planes, 33..63 columns whose 16-byte pieces are not aligned (55 x 55);
+// corr_build_fused16w_kernel -- one strip per workgroup on sixteen waves, linear planes, 65..128 columns (28 x 107).  The host
+// function at the end of the file picks one; DBA_BUILD_WAVES=8 / DBA_BUILD_KERNEL / DBA_BUILD_OPERANDS force the older forms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
