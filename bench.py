@@ -841,8 +841,7 @@ def main():
                        "ranks_seen": ranks_seen},
             "roofline": {
                 "kernel": "%s (fused 4-level r=3 lookup%s, f16, %d edges on rank 0, "
-                          "%s)" % ("corr_lookup_rowtile_kernel<3>" if (w % 64 == 0 and h % 4 == 0) else
-                                   "corr_lookup_sheared_kernel<3>" if w % 64 == 0 else "corr_lookup_resident_kernel<3>",
+                          "%s)" % ("corr_lookup_rowtile_kernel<3>" if _lib.load().dba_corr_sheared_tiled(h, w) else "corr_lookup_resident_kernel<3>",
                                    " with the reprojection in its prologue" if fused else "", n_loc,
                                    "MALL-cold: rotating pyramid copies and output buffers" if ncopies > 1
                                    else "MALL-warm: one pyramid copy replayed"),

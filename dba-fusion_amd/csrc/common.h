@@ -109,11 +109,17 @@ __device__ __forceinline__ int group8_minmax(int x) {  // result in all 8 lanes 
 // pixels' windows: the fewer distinct window origins among the 64 pixels, the fewer lines.  The flow varies with DISTANCE,
 // so 64 pixels should be close together: a 4 x 16 tile of the map instead of a 64 x 1 strip of a row (bench scene: 79
 // instead of 92 lines per wave and level; the lookup's time is proportional to that number, profiles/r04_lookup_lines.txt).
-//   tiled  (h1 % 4 == 0 and w1 % 16 == 0):  p = ((y1 >> 2) * (w1 >> 4) + (x1 >> 4)) * 64 + (y1 & 3) * 16 + (x1 & 15)
-//   linear (any other map):                 p = y1 * w1 + x1, planes padded to a multiple of 64 pixels
-// Which one a map shape gets is decided here and nowhere else (build, re-layout and lookup kernels all ask shear_tiled);
+//   tiled:   p = ((y1 >> 2) * (w1g >> 4) + (x1 >> 4)) * 64 + (y1 & 3) * 16 + (x1 & 15) on the GRID (h1g, w1g) = the map's size
+//            rounded up to multiples of (4, 64): maps whose rows are whole 64-pixel segments exactly, and -- opt-in, DBA_SHEAR_PAD=1
+//            (round 6, last session) -- maps that reach such a grid with at most 25 % of padding: 28 x 107 on 28 x 128, 55 x 55 on
+//            56 x 64.  The pad pixels' entries of a plane are never read as taps and never returned: coordinates, inverse depths
+//            and the returned tensor keep the map's own [h1, w1] indexing.  Measured: lookups 4-5 % faster, builds 20-30 % slower
+//            (profiles/LOOKUP_NOTES.md), hence not the default
+//   linear (any other map):  p = y1 * w1 + x1, planes padded to a multiple of 64 pixels
+// Which one a map shape gets is decided here and nowhere else (build, re-layout and lookup kernels all ask shear_grid);
 // DBA_SHEAR_TILES=0 (read once per process) keeps every shape linear.
-bool shear_tiled(int h1, int w1);
+bool shear_grid(int h1, int w1, int *h1g, int *w1g);   // true: tiled, on the grid (h1g, w1g); false: linear, (h1g, w1g) = (h1, w1)
+inline bool shear_tiled(int h1, int w1) { int a, b; return shear_grid(h1, w1, &a, &b); }
 #ifndef SH_TILE_WLOG
 #define SH_TILE_WLOG 4   // tile width 16 (x 4 rows); 5: 2 x 32, 3: 8 x 8 (experiments)
 #endif

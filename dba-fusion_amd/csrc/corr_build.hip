@@ -32,12 +32,15 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // channels (round 3; 2-byte accesses before: 23.4 us per 32-edge map, two launches).
 // w_tiled > 0: the output pixel axis is in the 4 x 16 tile order of common.h (the source operand of the flow-aligned build,
 // whose 64-pixel strips are then tiles of the map); 0: linear.
+// HWo / w_grid (w_tiled > 0): the output's pixels per map and the width of the grid its tiles are counted on -- the map's own
+// (HW, w_tiled), or the padded grid of common.h (the pad pixels' rows are never written: whatever they hold only ever reaches the
+// pad pixels' own entries of the planes)
 __device__ __forceinline__ void fmap_pixel_major_body(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int C, int HW,
-                                                      int kb, int w_tiled, int e) {
+                                                      int kb, int w_tiled, int e, int HWo, int w_grid) {
   __shared__ _Float16 tile[64][72];   // [channel][pixel]; pitch 144 B: the 8 lanes of a channel row write 16 B each
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const _Float16 *src = in + (size_t)e * C * HW;
-  _Float16 *dst = out + (size_t)e * HW * C;
+  _Float16 *dst = out + (size_t)e * HWo * C;
   const int t = threadIdx.x;
   const bool vec_in = ((HW & 7) == 0) && (p0 + 64 <= HW);
 #pragma unroll
@@ -62,16 +65,16 @@ __device__ __forceinline__ void fmap_pixel_major_body(const _Float16 *__restrict
     const int pl = idx >> 3, oct = idx & 7;
     const int pin = p0 + pl, c = c0 + 8 * oct;
     if (pin < HW && c < C) {
-      const int p = w_tiled ? sh_pixel_index(pin / w_tiled, pin % w_tiled, w_tiled, true) : pin;
+      const int p = w_tiled ? sh_pixel_index(pin / w_tiled, pin % w_tiled, w_grid, true) : pin;
       half8 v;
 #pragma unroll
       for (int k = 0; k < 8; k++) v[k] = tile[8 * oct + k][pl];
       if ((kb & 7) == 0 && c + 8 <= C) {
-        *reinterpret_cast<half8 *>(dst + ((size_t)(c / kb) * HW + p) * kb + (c % kb)) = v;
+        *reinterpret_cast<half8 *>(dst + ((size_t)(c / kb) * HWo + p) * kb + (c % kb)) = v;
       } else {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-          if (c + k < C) dst[((size_t)((c + k) / kb) * HW + p) * kb + ((c + k) % kb)] = v[k];
+          if (c + k < C) dst[((size_t)((c + k) / kb) * HWo + p) * kb + ((c + k) % kb)] = v[k];
       }
     }
   }
@@ -79,8 +82,8 @@ __device__ __forceinline__ void fmap_pixel_major_body(const _Float16 *__restrict
 
 __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *__restrict__ in,
                                                                _Float16 *__restrict__ out, int C, int HW, int kb,
-                                                               int w_tiled) {
-  fmap_pixel_major_body(in, out, C, HW, kb, w_tiled, (int)blockIdx.z);
+                                                               int w_tiled, int HWo, int w_grid) {
+  fmap_pixel_major_body(in, out, C, HW, kb, w_tiled, (int)blockIdx.z, HWo, w_grid);
 }
 
 // both maps of a build in ONE launch (maps of the same size: grid.z = 2 n; the first n slices are map 1 in the pixel order
@@ -88,10 +91,11 @@ __global__ __launch_bounds__(256) void fmap_pixel_major_kernel(const _Float16 *_
 // filter, the six of a new keyframe)
 __global__ __launch_bounds__(256) void fmap_pixel_major_pair_kernel(const _Float16 *__restrict__ in1, _Float16 *__restrict__ out1,
                                                                     int w_tiled1, const _Float16 *__restrict__ in2,
-                                                                    _Float16 *__restrict__ out2, int C, int HW, int kb, int n) {
+                                                                    _Float16 *__restrict__ out2, int C, int HW, int kb, int n,
+                                                                    int HWo1, int w_grid1) {
   const int z = (int)blockIdx.z;
-  if (z < n) fmap_pixel_major_body(in1, out1, C, HW, kb, w_tiled1, z);
-  else fmap_pixel_major_body(in2, out2, C, HW, kb, 0, z - n);
+  if (z < n) fmap_pixel_major_body(in1, out1, C, HW, kb, w_tiled1, z, HWo1, w_grid1);
+  else fmap_pixel_major_body(in2, out2, C, HW, kb, 0, z - n, HW, 0);
 }
 
 // C must be a multiple of 16.  A = fmap1 pixel-major [HW1][C], B = fmap2 pixel-major [HW2][C].
@@ -175,7 +179,9 @@ extern "C" {
 
 size_t dba_corr_volume_scratch_bytes(int n, int C, int h1, int w1, int h2, int w2) {
   if (n < 0 || C <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0) return 0;
-  return align_up((size_t)n * C * h1 * w1 * 2, 256) + align_up((size_t)n * C * h2 * w2 * 2, 256);
+  // (the source map's copy may live on the padded grid of its planes: dba_corr_sheared_plane_elems >= h1 * w1)
+  const size_t hw1 = (size_t)dba_corr_sheared_plane_elems(h1, w1);
+  return align_up((size_t)n * C * hw1 * 2, 256) + align_up((size_t)n * C * h2 * w2 * 2, 256);
 }
 
 int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *levels, int n, int C, int h1,
@@ -191,9 +197,9 @@ int dba_corr_volume_build(const void *fmap1, const void *fmap2, void *const *lev
   _Float16 *A = static_cast<_Float16 *>(scratch);
   _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, 0);
+                     static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, 0, HW1, 0);
   hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
+                     static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0, HW2, 0);
   hipLaunchKernelGGL(corr_gemm_kernel, dim3((HW2 + 127) / 128, (HW1 + 127) / 128, n), dim3(256), 0, s, A, Bm,
                      static_cast<_Float16 *>(levels[0]), C, HW1, HW2);
   DBA_LAUNCH_CHECK();

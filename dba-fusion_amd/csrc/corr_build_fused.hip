@@ -1639,9 +1639,9 @@ __global__ __launch_bounds__(1024) void corr_build_fused16w_kernel(const _Float1
 }
 
 // defined in corr_build.hip
-__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled);
+__global__ void fmap_pixel_major_kernel(const _Float16 *in, _Float16 *out, int C, int HW, int kb, int w_tiled, int HWo, int w_grid);
 __global__ void fmap_pixel_major_pair_kernel(const _Float16 *in1, _Float16 *out1, int w_tiled1, const _Float16 *in2, _Float16 *out2,
-                                             int C, int HW, int kb, int n);
+                                             int C, int HW, int kb, int n, int HWo1, int w_grid1);
 
 }  // namespace dba
 
@@ -1676,8 +1676,14 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
   const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
   hipStream_t s = (hipStream_t)stream;
   _Float16 *A = static_cast<_Float16 *>(scratch);
-  _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1 * 2, 256));
-  const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the source pixels in 4 x 16 tiles: the plane's pixel order (common.h)
+  _Float16 *Bm = reinterpret_cast<_Float16 *>(static_cast<char *>(scratch) + align_up((size_t)n * C * HW1p * 2, 256));
+  // the source pixels in 4 x 16 tiles of the grid (h1g, w1g) >= the map: the planes' pixel order (common.h).  On a padded grid the
+  // kernels below are handed the GRID as their source map -- a strip is a tile of it, the operand copy has a row per grid pixel,
+  // and what the pad pixels' rows hold only ever reaches their own entries of the planes, which nobody reads
+  int h1g, w1g;
+  const int tiled = shear_grid(h1, w1, &h1g, &w1g) ? 1 : 0;
+  const bool padded = tiled && (h1g != h1 || w1g != w1);
+  const int h1k = tiled ? h1g : h1, w1k = tiled ? w1g : w1;
   // DBA_BUILD_KERNEL=classic|loop forces one form where both apply (tests, A/B runs); read once per process
   static const int force = [] {
     const char *e = getenv("DBA_BUILD_KERNEL");
@@ -1698,18 +1704,20 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
   // (where 16-byte pieces of the maps are aligned -- widths that are multiples of 8 -- the eight-wave walk on the caller's own maps
   // is as fast or faster: 40 x 56 6.1 against 6.2 us per edge, 30 x 40 2.6 against 2.8; profiles/r06_build_g16.txt)
   const bool general16 = loop_form && waves16 && !tiled && w2 > 32 && h1 == h2 && w1 == w2 && ((w2 % 8) != 0 || (HW2 % 8) != 0);
-  const bool native_b = loop_form && !general16 && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
+  const bool native_b = loop_form && !general16 && !padded && native_mode != 0 && (w2 % 8 == 0) && (HW2 % 8 == 0);
   const bool native = native_b && native_mode == 1 && (HW1 % 8 == 0) && (w1 % 8 == 0);
+  const int HW1o = tiled ? HW1p : HW1;   // pixels per map of the source operand's copy
   if (!native && !native_b && HW1 == HW2 && 2 * (long long)n <= 65535)   // both copies in one launch
     hipLaunchKernelGGL(fmap_pixel_major_pair_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, 2 * n), dim3(256), 0, s,
-                       static_cast<const _Float16 *>(fmap1), A, tiled ? w1 : 0, static_cast<const _Float16 *>(fmap2), Bm, C, HW1, 16, n);
+                       static_cast<const _Float16 *>(fmap1), A, tiled ? w1 : 0, static_cast<const _Float16 *>(fmap2), Bm, C, HW1, 16, n,
+                       HW1o, w1g);
   else {
     if (!native)
       hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW1 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                         static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0);
+                         static_cast<const _Float16 *>(fmap1), A, C, HW1, 16, tiled ? w1 : 0, HW1o, w1g);
     if (!native_b)
       hipLaunchKernelGGL(fmap_pixel_major_kernel, dim3((HW2 + 63) / 64, (C + 63) / 64, n), dim3(256), 0, s,
-                         static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0);
+                         static_cast<const _Float16 *>(fmap2), Bm, C, HW2, 16, 0, HW2, 0);
   }
   FusedLevels L;
   for (int l = 0; l < 4; l++) L.vs[l] = static_cast<_Float16 *>(sheared_levels[l]);
@@ -1728,7 +1736,7 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
-  const float inv_w1 = 1.0f / (float)w1;
+  const float inv_w1 = 1.0f / (float)w1k;
 #ifdef FB_PROF
   static unsigned long long *prof = nullptr;
   if (!prof) { (void)hipMalloc(&prof, (size_t)64 << 20); }
@@ -1834,18 +1842,18 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
       F16_PROF_DUMP();
     } else if (native)
       hipLaunchKernelGGL((corr_build_fused_kernel<2, true, true>), lgrid, dim3(512), lds, s, static_cast<const _Float16 *>(fmap1),
-                         static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
+                         static_cast<const _Float16 *>(fmap2), L, C, h1k, w1k, h2, w2, HW1p, inv_w1, spw, out_slots,
                          tiled FB_PROF_ARG);
     else if (native_b)
       hipLaunchKernelGGL((corr_build_fused_kernel<2, true, false, true>), lgrid, dim3(512), lds, s, A,
-                         static_cast<const _Float16 *>(fmap2), L, C, h1, w1, h2, w2, HW1p, inv_w1, spw, out_slots,
+                         static_cast<const _Float16 *>(fmap2), L, C, h1k, w1k, h2, w2, HW1p, inv_w1, spw, out_slots,
                          tiled FB_PROF_ARG);
     else
-      hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p,
+      hipLaunchKernelGGL((corr_build_fused_kernel<2, true>), lgrid, dim3(512), lds, s, A, Bm, L, C, h1k, w1k, h2, w2, HW1p,
                          inv_w1, spw, out_slots, tiled FB_PROF_ARG);
   } else if (w2 <= 64) {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (64 + 4) + 4);  // the pooled levels live inside the dead tile
-    hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
+    hipLaunchKernelGGL((corr_build_fused_kernel<2, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1k, w1k, h2, w2, HW1p, inv_w1,
                        1, out_slots, tiled FB_PROF_ARG);
   } else {
     const size_t lds = sizeof(_Float16) * (size_t)64 * (FT_ROWS * (128 + 4) + 4);
@@ -1857,9 +1865,9 @@ int dba_corr_volume_build_sheared_slots(const void *fmap1, const void *fmap2, vo
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr16w_once.done();
       }
-      hipLaunchKernelGGL(corr_build_fused16w_kernel, grid, dim3(1024), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1, out_slots);
+      hipLaunchKernelGGL(corr_build_fused16w_kernel, grid, dim3(1024), lds, s, A, Bm, L, C, h1k, w1k, h2, w2, HW1p, inv_w1, out_slots);
     } else
-      hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1, w1, h2, w2, HW1p, inv_w1,
+      hipLaunchKernelGGL((corr_build_fused_kernel<4, false>), grid, dim3(512), lds, s, A, Bm, L, C, h1k, w1k, h2, w2, HW1p, inv_w1,
                          1, out_slots, tiled FB_PROF_ARG);
   }
   DBA_LAUNCH_CHECK();

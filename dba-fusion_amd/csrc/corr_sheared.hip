@@ -28,11 +28,20 @@
 
 namespace dba {
 
-bool shear_tiled(int h1, int w1) {
+bool shear_grid(int h1, int w1, int *h1g, int *w1g) {
   static const bool enabled = [] { const char *e = getenv("DBA_SHEAR_TILES"); return !(e && e[0] == '0'); }();
+  // (opt-in: measured in the round's last session, the padded grids make the lookups 4-5 % faster and the builds 20-30 % slower --
+  // a lookup's cost goes with its 64-column segments, not with its valid pixels; profiles/LOOKUP_NOTES.md)
+  static const bool pad = [] { const char *e = getenv("DBA_SHEAR_PAD"); return e && e[0] == '1'; }();
+  *h1g = h1, *w1g = w1;
+  if (!enabled || h1 <= 0 || w1 <= 0) return false;
   // (maps whose rows are whole 64-pixel segments: the shapes the rows-over-tiles lookup serves; the other forms read tiled
   // planes slower than linear ones because their stores then come in 32-byte pieces)
-  return enabled && h1 > 0 && w1 > 0 && (h1 & (SH_TH - 1)) == 0 && (w1 & (SH_TW - 1)) == 0 && (w1 & 63) == 0;
+  const int hg = (h1 + SH_TH - 1) & ~(SH_TH - 1), wg = (w1 + 63) & ~63;
+  const bool exact = (hg == h1) && (wg == w1);
+  if (!exact && !(pad && (long)hg * wg * 4 <= (long)h1 * w1 * 5)) return false;
+  *h1g = hg, *w1g = wg;
+  return true;
 }
 
 constexpr int SH_MAX_LEVELS = 8;
@@ -58,7 +67,7 @@ struct ShReproj {
 __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restrict__ V,
                                                          _Float16 *__restrict__ Vs, int h1, int w1, int h2l,
                                                          int w2l, int lvl, int HW1p, const int *__restrict__ src_idx,
-                                                         const int *__restrict__ dst_slots, int tiled) {
+                                                         const int *__restrict__ dst_slots, int tiled, int w1g) {
   extern __shared__ _Float16 tile[];  // [64][w2l + 2]
   const int pitch = w2l + 2;
   const int x0 = blockIdx.x * 64;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void corr_shear_kernel(const _Float16 *__restr
   for (int idx = threadIdx.x; idx < nx * w2l; idx += blockDim.x) {
     const int dx = idx / nx, xi = idx - dx * nx;
     const int tx = (((x0 + xi) >> lvl) + dx) % w2l;
-    Vs[(((size_t)ed * h2l + dy) * w2l + dx) * HW1 + (size_t)sh_pixel_index(y1, x0 + xi, w1, tiled != 0)] = tile[xi * pitch + tx];
+    Vs[(((size_t)ed * h2l + dy) * w2l + dx) * HW1 + (size_t)sh_pixel_index(y1, x0 + xi, tiled ? w1g : w1, tiled != 0)] = tile[xi * pitch + tx];
   }
 }
 
@@ -250,7 +259,7 @@ __device__ __forceinline__ int sh2_mod(int v, int n, float inv_n, bool pow2) {
 template <int R>
 __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_resident_kernel(
     ShLevels L, const float2 *__restrict__ coords, _Float16 *__restrict__ out, int n, int h1, int w1, int h2, int w2,
-    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP, int tiled) {
+    int num_levels, int HW1p, float inv_w1, int lvl0, int cflags, const int *__restrict__ slots, ShReproj RP, int tiled, int w1g) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -283,10 +292,17 @@ __global__ __launch_bounds__(SH2_WAVES * 64, SH2_MINOCC_CFG) void corr_lookup_re
   }
 
   const int p = p0 + lane;            // index on the planes' pixel axis (linear or 4 x 16 tiles: common.h)
-  const bool active = p < HW1;
-  const int pc = min(p, HW1 - 1);
   int y1, x1;
-  sh_pixel_yx(pc, w1, inv_w1, tiled != 0, y1, x1);
+  bool active;
+  if (tiled) {   // tiles of the grid (h1g, w1g >= the map): a pixel of the padding is no pixel (p < HW1p = the grid's size)
+    sh_pixel_yx(p, w1g, 0.f, true, y1, x1);
+    active = (y1 < h1) && (x1 < w1);
+    y1 = active ? y1 : 0;
+    x1 = active ? x1 : 0;
+  } else {
+    active = p < HW1;
+    sh_pixel_yx(min(p, HW1 - 1), w1, inv_w1, false, y1, x1);
+  }
   const int plin = y1 * w1 + x1;      // the pixel in row-major order: coordinates, inverse depths, outputs
   float2 cxy;
   if (cflags & 4) {  // the reprojection taken along (see ShReproj): this wave's edge geometry, then one pixel per lane
@@ -547,7 +563,7 @@ template <int R>
 __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(ShLevels L, const float2 *__restrict__ coords,
                                                                   _Float16 *__restrict__ out, int n, int h1, int w1, int h2,
                                                                   int w2, int num_levels, int lvl0, int cflags,
-                                                                  const int *__restrict__ slots, ShReproj RP) {
+                                                                  const int *__restrict__ slots, ShReproj RP, int h1g, int w1g) {
   constexpr int RD = 2 * R + 1, WN = 2 * R + 2;
   static_assert(WN == 8, "written for radius 3");
   static_assert(SH_TW == 16 && SH_TH == 4, "a band is one row of 4 x 16 tiles");
@@ -563,8 +579,10 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
   __shared__ int ocount;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int HW1 = h1 * w1;
-  const int segs = w1 >> 6, units = (h1 >> 2) * segs;   // (w1 % 64 == 0: a band is cut into segments of four tiles)
+  // (h1g, w1g): the grid the planes are tiled on -- the map's size rounded up to multiples of (4, 64), common.h; HW1g entries per
+  // plane.  Coordinates, inverse depths and outputs keep the map's own [h1, w1] indexing; a pixel of the padding is no pixel.
+  const int HW1 = h1 * w1, HW1g = h1g * w1g;
+  const int segs = w1g >> 6, units = (h1g >> 2) * segs;   // (w1g % 64 == 0: a band is cut into segments of four tiles)
   const int q8 = (int)(gridDim.x >> 3), r8 = (int)(gridDim.x & 7), xk = (int)(blockIdx.x & 7);
   const int bid = xk * q8 + min(xk, r8) + (int)(blockIdx.x >> 3);
   const int lvl = blockIdx.y + lvl0;
@@ -581,7 +599,8 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
 
   // ---- worker pixel: (row 4 band + wave, x1 = lane) ------------------------------------------------------------------------
   const int y1 = (band << 2) + wave, x1 = xseg + lane;
-  const unsigned pix = (unsigned)(y1 * w1 + x1);
+  const bool pvalid = (y1 < h1) && (x1 < w1);
+  const unsigned pix = pvalid ? (unsigned)(y1 * w1 + x1) : 0u;
   float2 cxy;
   if (cflags & 4) {
     const int ix = (int)RP.ii[e];
@@ -589,14 +608,14 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
     const EdgeGeom G = edge_geom(RP.poses, RP.intr_b4, ix, (int)RP.jj[e]);   // uniform
     float ok;
     cxy = reproject_pixel(G, (float)x1, (float)y1, dsrc, ok);
-    if (lvl == 0) {
+    if (lvl == 0 && pvalid) {
       if (RP.coords_out) RP.coords_out[(size_t)e * HW1 + pix] = cxy;
       if (RP.valid_out) RP.valid_out[(size_t)e * HW1 + pix] = ok;
     }
   } else {
     cxy = sh_coord(coords, cplanar, (size_t)e, HW1, (int)pix);
   }
-  const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, true, slvl);
+  const ShPixel P = sh_pixel<R>(cxy, lvl, x1, y1, h2l, w2l, pvalid, slvl);
   const bool touches = P.touches;
   org_x[wave][lane] = P.ox;
   org_y[wave][lane] = P.oy;
@@ -610,7 +629,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
   const int trow = lane >> 4, tcol = (wave << 4) + (lane & 15);
   const int tox = org_x[trow][tcol], toy = org_y[trow][tcol];
   const bool ttouch = ((touch_row[trow] >> tcol) & 1ull) != 0ull;
-  const bool can_stream = ((size_t)h2l * w2l * HW1 * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
+  const bool can_stream = ((size_t)h2l * w2l * HW1g * 2 < ((size_t)1 << 31)) && ((size_t)RD * RD * HW1 * 2 < ((size_t)1 << 31));
   bool tinl;
   {
     const unsigned long long tmask = __ballot(ttouch);
@@ -658,7 +677,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
   _Float16 *obase = olvl + (size_t)e * estride;
 
   if (!any) {
-    if (!outlier) {   // nothing streams in this band: untouched pixels are exact zeros
+    if (!outlier && pvalid) {   // nothing streams in this band: untouched pixels are exact zeros
       _Float16 *o = obase + pix;
 #pragma unroll
       for (int ch = 0; ch < RD * RD; ch++) o[(size_t)ch * HW1] = (_Float16)0.f;
@@ -679,7 +698,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
     unsigned goff[2], jlo[2], jlen[2], kbits[2];
     int ldsoff[2];
     bool edge_any = false;
-    const unsigned p0 = (unsigned)((band * (w1 >> 4) + (seg << 2) + wave) << 6);   // plane index of the tile's first pixel
+    const unsigned p0 = (unsigned)((band * (w1g >> 4) + (seg << 2) + wave) << 6);   // plane index of the tile's first pixel
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const int jx = (lane >> 3) + 8 * t;
@@ -698,7 +717,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
       // only in the waves that have such a border at all)
       kbits[t] = (qb > qa) ? ((0xffu >> (8 - (qb - qa))) << qa) : 0u;
       edge_any |= act && (qa > 0 || qb < 8);
-      goff[t] = 2u * ((unsigned)m * (unsigned)HW1 + p0 + (unsigned)sub * 8u);
+      goff[t] = 2u * ((unsigned)m * (unsigned)HW1g + p0 + (unsigned)sub * 8u);
       ldsoff[t] = jx * 64 + sub * 8;
     }
     const bool masked = __ballot(edge_any) != 0ull;
@@ -706,7 +725,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
     if (pow2) dym = BY0 & (h2l - 1);
     else { dym = BY0 % h2l; dym += (dym < 0) ? h2l : 0; }
     dym = __builtin_amdgcn_readfirstlane(dym);
-    const size_t rowstride = (size_t)w2l * HW1;
+    const size_t rowstride = (size_t)w2l * HW1g;
     const unsigned rowbytes = (unsigned)(2 * rowstride);
     constexpr unsigned OOR = 0x80000000u;
     const int es = slots ? slots[e] : e;
@@ -719,7 +738,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
     W01.x = W01.y = P.h01;
     W10.x = W10.y = P.h10;
     W11.x = W11.y = P.h11;
-    const bool writes = !outlier;
+    const bool writes = !outlier && pvalid;
     // worker's taps: the LDS row of its tile (buffer 0 / 1 alternate), line rx, slot
     const _Float16 *tp0 = inlier ? &stage_all[0][mytile][rx * 64 + slot] : zero_taps + lane;
     const _Float16 *tp1 = inlier ? &stage_all[1][mytile][rx * 64 + slot] : zero_taps + lane;
@@ -822,7 +841,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
     }
     const ShPixel Q = sh_pixel<R>(c, lvl, gx, gy, h2l, w2l, true, slvl);
     const int ges = slots ? slots[ge] : ge;
-    const _Float16 *vol = L.vol[lvl] + (size_t)ges * h2l * w2l * HW1 + (size_t)sh_pixel_index(gy, gx, w1, true);
+    const _Float16 *vol = L.vol[lvl] + (size_t)ges * h2l * w2l * HW1g + (size_t)sh_pixel_index(gy, gx, w1g, true);
     _Float16 *o = olvl + (size_t)ge * estride + (size_t)gy * w1 + gx;
     int dxm[WN];
     bool cok[WN];
@@ -844,7 +863,7 @@ __global__ __launch_bounds__(256, SB_MIN_WAVES) void corr_lookup_rowtile_kernel(
       const bool rok = (ty >= 0) && (ty < h2l);
       _Float16 cur[WN];
 #pragma unroll
-      for (int i = 0; i < WN; i++) cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1] : (_Float16)0.f;
+      for (int i = 0; i < WN; i++) cur[i] = (rok && cok[i]) ? vol[((size_t)dym * w2l + dxm[i]) * HW1g] : (_Float16)0.f;
       if (j >= 1) {
 #pragma unroll
         for (int a = 0; a < RD; a++) o[(size_t)(a * RD + (j - 1)) * HW1] = sh_blend(prev[a], cur[a], prev[a + 1], cur[a + 1], Q);
@@ -886,8 +905,18 @@ int dba_corr_lookup_select(int kernel) {
 
 int dba_corr_sheared_tiled(int h1, int w1) { return shear_tiled(h1, w1) ? SH_TW : 0; }
 
+int dba_corr_sheared_grid(int h1, int w1, int *h1g, int *w1g) {
+  int a = h1, b = w1;
+  const bool t = shear_grid(h1, w1, &a, &b);
+  if (h1g) *h1g = a;
+  if (w1g) *w1g = b;
+  return t ? SH_TW : 0;
+}
+
 int dba_corr_sheared_plane_elems(int h1, int w1) {
   if (h1 <= 0 || w1 <= 0) return 0;
+  int hg, wg;
+  if (shear_grid(h1, w1, &hg, &wg)) return hg * wg;   // (a multiple of 64)
   return (h1 * w1 + 63) / 64 * 64;
 }
 
@@ -904,9 +933,11 @@ int dba_corr_shear_level_slots(const void *ref_level, void *sheared_store, const
   const size_t lds = (size_t)64 * (w2l + 2) * sizeof(_Float16);
   if (lds > 64 * 1024) return DBA_ERR_UNSUPPORTED;
   dim3 grid((w1 + 63) / 64, h2l, n * h1);
+  int h1g_, w1g_;
+  const bool tiled_ = shear_grid(h1, w1, &h1g_, &w1g_);
   hipLaunchKernelGGL(corr_shear_kernel, grid, dim3(256), lds, (hipStream_t)stream,
                      static_cast<const _Float16 *>(ref_level), static_cast<_Float16 *>(sheared_store), h1, w1, h2l,
-                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1), src_idx, dst_slots, shear_tiled(h1, w1) ? 1 : 0);
+                     w2l, lvl, dba_corr_sheared_plane_elems(h1, w1), src_idx, dst_slots, tiled_ ? 1 : 0, w1g_);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }
@@ -919,16 +950,17 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   const int HW1p = dba_corr_sheared_plane_elems(h1, w1);
   // "rows over tiles" on tiled planes (maps whose rows are whole 64-pixel segments, common.h), "resident" on every other
   // shape and on planes too large for the row walk's 32-bit offsets; dba_corr_lookup_select() / DBA_LOOKUP_KERNEL override.
-  const int tiled = shear_tiled(h1, w1) ? 1 : 0;   // the planes' pixel order (common.h): a wave owns a 4 x 16 tile of the map
+  int h1g, w1g;
+  const int tiled = shear_grid(h1, w1, &h1g, &w1g) ? 1 : 0;   // the planes' pixel order (common.h): a wave owns a 4 x 16 tile of the grid
   const int sel = g_lookup_select.load(std::memory_order_relaxed);
   hipEvent_t e0 = g_time_start, e1 = g_time_stop;
   g_time_start = g_time_stop = nullptr;
-  const bool rowtile_ok = tiled && SH_TW == 16 && (w1 & 63) == 0 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * h1 * w1 * 2 < ((size_t)1 << 31);
+  const bool rowtile_ok = tiled && SH_TW == 16 && (w1g & 63) == 0 && (size_t)(h2 >> lvl0) * (w2 >> lvl0) * HW1p * 2 < ((size_t)1 << 31);
   if ((sel == 5 || sel == 0) && rowtile_ok) {   // loaders per tile, workers per map row
-    dim3 grid((unsigned)((long)n * (h1 / 4) * (w1 / 64)), nlv);
+    dim3 grid((unsigned)((long)n * (h1g / 4) * (w1g / 64)), nlv);
     hipExtLaunchKernelGGL((corr_lookup_rowtile_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, L,
                           reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2, nlv, lvl0,
-                          cflags, slots, RP);
+                          cflags, slots, RP, h1g, w1g);
     DBA_LAUNCH_CHECK();
     return DBA_OK;
   }
@@ -945,7 +977,7 @@ static int lookup_sheared_launch(const ShLevels &L, const float *coords, void *c
   }
   hipExtLaunchKernelGGL((corr_lookup_resident_kernel<3>), grid, dim3(SH2_WAVES * 64), lds, (hipStream_t)stream, e0, e1, 0, L,
                         reinterpret_cast<const float2 *>(coords), static_cast<_Float16 *>(corr), n, h1, w1, h2, w2,
-                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP, tiled);
+                        nlv, HW1p, 1.0f / (float)w1, lvl0, cflags, slots, RP, tiled, w1g);
   DBA_LAUNCH_CHECK();
   return DBA_OK;
 }

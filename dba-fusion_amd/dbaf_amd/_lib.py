@@ -87,6 +87,7 @@ SYMBOLS = {
     "dba_corr_volume_build_sheared": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
     "dba_corr_sheared_plane_elems": (c_int, [c_int, c_int]),
     "dba_corr_sheared_tiled": (c_int, [c_int, c_int]),
+    "dba_corr_sheared_grid": (c_int, [c_int, c_int, _P, _P]),
     "dba_corr_lookup_select": (c_int, [c_int]),
     "dba_corr_lookup_arm_timing": (c_int, [_P, _P]),
     "dba_corr_shear_level": (c_int, [_P, _P] + [c_int] * 6 + [_P]),

@@ -291,11 +291,13 @@ class CorrBlock:
         un-tiled where the planes keep their pixels in 4 x 16 tiles (dba_corr_sheared_tiled; the last tile of a row may reach
         past the map: those padding pixels are dropped)"""
         lib = _lib.load()
-        tw = lib.dba_corr_sheared_tiled(int(h1), int(w1))     # tile width (0: row-major)
-        if tw:
-            th, tx = 64 // tw, (w1 + tw - 1) // tw
-            v = level.unflatten(-1, (h1 // th, tx, th, tw)).movedim(-2, -3)      # [..., h1 / th, th, tiles_x, tw]
-            return v.reshape(v.shape[:-4] + (h1, tx * tw))[..., :w1]
+        hg, wg = ctypes.c_int(0), ctypes.c_int(0)
+        tw = lib.dba_corr_sheared_grid(int(h1), int(w1), ctypes.byref(hg), ctypes.byref(wg))   # tile width (0: row-major) and the
+        if tw:                                                                                 # grid the tiles are counted on
+            hg, wg = hg.value, wg.value
+            th, tx = 64 // tw, wg // tw
+            v = level.unflatten(-1, (hg // th, tx, th, tw)).movedim(-2, -3)      # [..., hg / th, th, tiles_x, tw]
+            return v.reshape(v.shape[:-4] + (hg, wg))[..., :h1, :w1]
         return level[..., :h1 * w1].unflatten(-1, (h1, w1))
 
     def sheared_level(self, lvl):

@@ -378,8 +378,8 @@ int dba_corr_lookup_pyramid(const void *const *volumes /* host array of L device
 
 /* Flow-aligned ("sheared") volume: Vs_l[n][dy][dx][pixel] = V_l[n][y1][x1][ty][tx] with pixel = y1 * w1 + x1,
  * dy = (ty - (y1 >> l)) mod h2l, dx = (tx - (x1 >> l)) mod w2l; the pixel axis is padded to
- * dba_corr_sheared_plane_elems(h1, w1) = h1 * w1 rounded up to a multiple of 64 (padding is never read for a real
- * pixel) -- the size of the reference tensor of dbaf/modules/corr.py:31-36 (+ padding), but the taps that
+ * dba_corr_sheared_plane_elems(h1, w1) = h1 * w1 rounded up to a multiple of 64, or the size of the tile grid for tiled planes
+ * (dba_corr_sheared_grid; padding is never read for a real pixel) -- the size of the reference tensor of dbaf/modules/corr.py:31-36 (+ padding), but the taps that
  * neighbouring source pixels read become contiguous, so a wave fetches full, aligned 128-byte lines for ANY map
  * size (csrc/corr_sheared.hip).  Used by the CorrBlock mirror; the lookup result is bit-identical to
  * corr_index_forward on the reference layout.  f16 only, radius 3. */
@@ -391,6 +391,12 @@ int dba_corr_sheared_plane_elems(int h1, int w1);
  * maps: pixel = y1 * w1 + x1.  Returns the tile width (16) for the tiled order, 0 for the row-major one (DBA_SHEAR_TILES=0
  * keeps every shape row-major). */
 int dba_corr_sheared_tiled(int h1, int w1);
+/* ... and the grid the tiles are counted on: (h1g, w1g) = (h1, w1) rounded up to multiples of (4, 64) for tiled planes (then
+ * dba_corr_sheared_plane_elems = h1g * w1g; the pad pixels' entries are never read as taps), (h1, w1) itself for linear ones.
+ * Returns the tile width like dba_corr_sheared_tiled.  With DBA_SHEAR_PAD=1 (opt-in, read once per process) maps within 25 % of
+ * such a grid are tiled on it (28 x 107 on 28 x 128, 55 x 55 on 56 x 64); coordinates and the returned tensors keep the map's own
+ * [h1, w1] indexing.  By default only the maps that ARE such a grid are tiled. */
+int dba_corr_sheared_grid(int h1, int w1, int *h1g, int *w1g);
 /* which form of the sheared lookup dba_corr_lookup_pyramid_sheared launches: 0 = automatic (by map shape), 2 = resident
  * (any shape), 5 = rows over tiles (tiled planes only, falls back to resident otherwise).  Process-wide; results are
  * bit-identical.  (1, 3, 4 were round 4's streaming / pair / band forms, which no longer ship: DBA_ERR_ARG.) */

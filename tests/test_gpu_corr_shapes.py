@@ -173,3 +173,28 @@ def test_zero_edit_route_is_served_from_a_flow_aligned_shadow_bit_for_bit(name):
     gc.collect()
     assert len(_SHADOWS.seen) <= n_before - 4
     _SHADOWS._min_uses = uses
+
+
+def test_padded_tile_grids_are_an_opt_in_that_changes_no_result():
+    """DBA_SHEAR_PAD=1 (read once per process, so: a process of its own) tiles the planes of maps that are within 25 % of a grid of
+    whole 4 x 64-pixel bands -- 28 x 107 on 28 x 128, 55 x 55 on 56 x 64 -- and serves them with the rows-over-tiles lookup and the
+    tiled build walks: every parity test of the config shapes, of the fused build against the unfused pipeline and of the slot-addressed
+    block passes there too, bit for bit (the pad pixels' entries are never read as taps and never returned)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DBA_SHEAR_PAD="1")
+    probe = ("import sys, ctypes; sys.path.insert(0, %r); from dbaf_amd import _lib; lib = _lib.load(); a = ctypes.c_int(); b = ctypes.c_int();"
+             "t = lib.dba_corr_sheared_grid(28, 107, ctypes.byref(a), ctypes.byref(b)); print(t, a.value, b.value, lib.dba_corr_sheared_plane_elems(55, 55))"
+             % os.path.join(root, "dba-fusion_amd"))
+    out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-4:] == ["16", "28", "128", str(56 * 64)], out.stdout
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(root, "tests", "test_gpu_corr_shapes.py"), os.path.join(root, "tests", "test_gpu_corr.py"),
+                          os.path.join(root, "tests", "test_gpu_corr_slots.py"),
+                          "-k", "config_shape or fused_sheared_build or sheared_volume_is or cat_and_index or looked_up_once"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-1000:]
+    assert " passed" in run.stdout
